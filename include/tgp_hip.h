@@ -1,0 +1,214 @@
+/*
+ * tgp_hip.h -- C ABI of libtgp_hip.so: the MI355X (gfx950) dense DirectSolver hot path.
+ *
+ * This is the drop-in boundary for tinygp's dense `DirectSolver` path.  The reference
+ * (dfm/tinygp) is pure Python on JAX and has NO native FFI of its own; the seam a
+ * replacement binds to is the `Solver` protocol (src/tinygp/solvers/solver.py:15-82)
+ * consumed by `GaussianProcess(..., solver=Cls)` (src/tinygp/gp.py:101-112).  Each entry
+ * point below names the reference interface it replaces.  The ctypes binding a maintainer
+ * would add is shown in INTEGRATION.md and lives in tinygp_amd/_ffi.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in any signature
+ *     (`void* stream` is a hipStream_t passed opaquely, NULL = library-owned stream);
+ *   - device matrices are COLUMN-major (element (i,j) at j*ld + i); host matrices in the
+ *     `tgp_solver_*` layer are ROW-major like the reference's (N,N) arrays
+ *     (a row-major lower-triangular L is byte-identical to a column-major upper L^T, so
+ *     the copy-out transposes);
+ *   - every function returns an int status: 0 = ok, < 0 = TGP_E_* (see tgp_last_error()),
+ *     > 0 = LAPACK-style `info` (1-based index of the first non-positive pivot).
+ *     Numerical failure never aborts: the factor then holds NaNs exactly like
+ *     jax.scipy.linalg.cholesky (direct.py:53) and log_probability becomes -inf (gp.py:316);
+ *   - blocking unless stated: results in host memory are valid on return;
+ *   - a ctx / solver handle is not re-entrant (one thread at a time).
+ */
+#ifndef TGP_HIP_H
+#define TGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGP_ABI_VERSION 1
+
+/* element types: follows the dtype of the caller's arrays (gp.py:89) */
+#define TGP_F32 0
+#define TGP_F64 1
+
+/* status codes */
+#define TGP_OK 0
+#define TGP_E_ARG (-1)     /* bad argument (maps to Python ValueError) */
+#define TGP_E_HIP (-2)     /* HIP runtime error */
+#define TGP_E_NOMEM (-3)   /* device allocation failed */
+#define TGP_E_UNSUPPORTED (-4)
+
+/* all device matrices are padded to a multiple of TGP_TILE rows/cols */
+#define TGP_TILE 128
+
+/* ---- kernel program -------------------------------------------------------------
+ * A tinygp kernel tree (kernels/base.py:170-209 Sum/Product/Constant over the stationary
+ * leaves of kernels/stationary.py:59-235) flattened to postfix.  Leaves push a value,
+ * ADD/MUL pop two and push one.  `metric` selects kernels/distance.py:41-59.
+ *   CONST : p0 = value                               (base.py:205-209)
+ *   EXP   : exp(-dist/p0)                            (stationary.py:76-82)
+ *   EXPSQ : exp(-0.5 * sqdist/p0^2)                  (stationary.py:104-106)
+ *   M32   : a = sqrt(3)*dist/p0; (1+a) exp(-a)       (stationary.py:126-129)
+ *   M52   : a = sqrt(5)*dist/p0; (1+a+a^2/3) exp(-a) (stationary.py:150-153)
+ *   COS   : cos(2 pi dist/p0)                        (stationary.py:173-175)
+ *   ESS   : exp(-p1 sin^2(pi dist/p0))               (stationary.py:202-205)
+ *   RQ    : (1 + 0.5 sqdist/p0^2 / p1)^(-p1)         (stationary.py:232-235)
+ * dist / sqdist: L1 -> sum|d|, (sum|d|)^2 ; L2 -> zero-safe sqrt(sum d^2), sum d^2.
+ */
+enum {
+  TGP_K_CONST = 0, TGP_K_EXP = 1, TGP_K_EXPSQ = 2, TGP_K_M32 = 3, TGP_K_M52 = 4,
+  TGP_K_COS = 5, TGP_K_ESS = 6, TGP_K_RQ = 7, TGP_K_ADD = 16, TGP_K_MUL = 17
+};
+enum { TGP_METRIC_L1 = 0, TGP_METRIC_L2 = 1 };
+
+typedef struct tgp_kop {
+  int32_t op;
+  int32_t metric;
+  double p0;
+  double p1;
+} tgp_kop;
+
+#define TGP_KPROG_MAX 32  /* ops per program */
+#define TGP_KSTACK_MAX 8  /* evaluation-stack depth */
+#define TGP_MAX_DIM 16    /* input dimension D */
+
+typedef struct tgp_ctx tgp_ctx;
+typedef struct tgp_solver tgp_solver;
+
+/* ---- library / context ---------------------------------------------------------- */
+int tgp_abi_version(void);
+const char* tgp_last_error(void); /* thread-local message of the last failing call */
+
+/* device: HIP ordinal; stream: hipStream_t to launch on (NULL: create an own stream) */
+int tgp_ctx_create(int device, void* stream, tgp_ctx** out);
+int tgp_ctx_destroy(tgp_ctx* ctx);
+int tgp_ctx_sync(tgp_ctx* ctx);
+/* tuning knobs: key in {"nb_outer","lookahead","profile"}; returns previous value via *old */
+int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* old);
+/* name (<=255 chars), CU count, memory bytes, clock kHz of the ctx's device */
+int tgp_ctx_device_info(tgp_ctx* ctx, char* name, int name_len, int32_t* cus, int64_t* mem_bytes,
+                        int32_t* clock_khz);
+
+/* raw device buffers for hosts without a HIP binding (ctypes) */
+int tgp_malloc(tgp_ctx* ctx, size_t bytes, void** dev);
+int tgp_free(tgp_ctx* ctx, void* dev);
+int tgp_memcpy_h2d(tgp_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int tgp_memcpy_d2h(tgp_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int tgp_memset(tgp_ctx* ctx, void* dst_dev, int byte, size_t bytes);
+
+/* ---- device-pointer kernels (async on the ctx stream) ------------------------------ */
+
+/* K1+K3: out[i,j] = k(X1[i], X2[j]) (+ diag[i] if i==j and diag != NULL), column-major,
+ * replaces Kernel.__call__ (kernels/base.py:84-103) + Diagonal._add (noise.py:77-78).
+ * X1 (n1,d), X2 (n2,d) row-major device arrays.  out is rows_out x cols_out (>= n1,n2);
+ * the padding region is filled with the identity (1 on i==j, else 0).
+ * lower_only != 0 (square, X1==X2): only 128-tiles on/below the diagonal are written. */
+int tgp_kmat(tgp_ctx* ctx, int dtype, const tgp_kop* prog, int nops, int64_t n1, int64_t n2,
+             int32_t d, const void* X1, const void* X2, const void* diag, void* out, int64_t ld,
+             int64_t rows_out, int64_t cols_out, int lower_only);
+
+/* K2: out[i] = k(X[i], X[i]) -- Kernel.__call__(X) / evaluate_diag (base.py:59-66,85-93) */
+int tgp_kdiag(tgp_ctx* ctx, int dtype, const tgp_kop* prog, int nops, int64_t n, int32_t d,
+              const void* X, void* out);
+
+/* K9 fused: out[i] = sum_j k(X1[i], X2[j]) * v[j]; never materialises K(X1,X2).
+ * Replaces Kernel.matmul (kernels/base.py:68-82) as used by gp.py:357. */
+int tgp_kmat_gemv(tgp_ctx* ctx, int dtype, const tgp_kop* prog, int nops, int64_t n1, int64_t n2,
+                  int32_t d, const void* X1, const void* X2, const void* v, void* out);
+
+/* K4: in-place lower Cholesky of the column-major n x n matrix A (n % TGP_TILE == 0);
+ * replaces jax.scipy.linalg.cholesky(K, lower=True) at solvers/direct.py:53.
+ * Only the lower triangle is read/written.  *info (host) = 0 or the failing pivot.
+ * Blocking (reads info back). */
+int tgp_potrf(tgp_ctx* ctx, int dtype, int64_t n, void* A, int64_t ld, int32_t* info);
+
+/* K5/K6: y <- L^-1 y (transpose=0) or L^-T y (transpose=1), single right-hand side;
+ * replaces solve_triangular at solvers/direct.py:66-70 for y of shape (N,). */
+int tgp_trsv(tgp_ctx* ctx, int dtype, int64_t n, const void* L, int64_t ld, int transpose,
+             void* y);
+
+/* K5 with R right-hand sides in transposed form: B (m x n, column-major, rows = RHS
+ * index) <- B L^-T, i.e. row r of B becomes (L^-1 b_r)^T.  m % 64 == 0, n % TGP_TILE == 0.
+ * Replaces solve_triangular(L, Ks) at solvers/direct.py:94. */
+int tgp_trsm_right_lt(tgp_ctx* ctx, int dtype, int64_t m, int64_t n, const void* L, int64_t ldl,
+                      void* B, int64_t ldb);
+
+/* C (m x n) <- beta*C + alpha * A (m x k) * B(n x k)^T, all column-major; m,n % TGP_TILE == 0,
+ * k % 16 == 0; alpha,beta in {(-1,1),(1,0)}.  lower != 0: only tiles with row >= col
+ * (same origin for A and B rows).  The fp64/fp32 MFMA building block (K4 trailing update,
+ * K10 = A^T A at solvers/direct.py:95). */
+int tgp_gemm_nt(tgp_ctx* ctx, int dtype, int64_t m, int64_t n, int64_t k, double alpha,
+                const void* A, int64_t lda, const void* B, int64_t ldb, double beta, void* C,
+                int64_t ldc, int lower);
+
+/* K7/K8 reductions: *out_host = sum log L[i,i] over i < n   /   sum y[i]^2 over i < n */
+int tgp_sum_log_diag(tgp_ctx* ctx, int dtype, int64_t n, const void* L, int64_t ld,
+                     double* out_host);
+int tgp_sum_squares(tgp_ctx* ctx, int dtype, int64_t n, const void* y, double* out_host);
+
+/* f64/f32 MFMA issue-rate microbenchmark: returns measured TFLOP/s of
+ * v_mfma_f64_16x16x4_f64 (dtype F64) / v_mfma_f32_32x32x2_f32 (F32) over all CUs. */
+int tgp_ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops_out);
+
+/* ---- solver handle: replaces tinygp.solvers.DirectSolver (solvers/direct.py:17-95) ---- */
+
+/* Allocates the padded n_pad^2 matrix and uploads X (n,d) row-major and the noise diagonal
+ * (n,) once (DirectSolver.__init__ args, direct.py:30-37).  Host pointers. */
+int tgp_solver_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X_host,
+                      const void* noise_diag_host, tgp_solver** out);
+int tgp_solver_destroy(tgp_solver* s);
+
+/* Assemble K = k(X,X) + diag (or take cov_host (n,n) row-major if non-NULL, direct.py:50-52)
+ * and factor in place (direct.py:53).  Re-callable with new hyper-parameters: the
+ * optimiser loop of SURVEY 3.4.  *info = potrf info. */
+int tgp_solver_factor(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
+                      int32_t* info);
+/* replace the noise diagonal (n,) without re-uploading X */
+int tgp_solver_set_noise(tgp_solver* s, const void* noise_diag_host);
+
+/* DirectSolver.normalization (direct.py:61-64): sum log L_ii + n/2 log(2 pi) */
+int tgp_solver_normalization(tgp_solver* s, double* out);
+/* DirectSolver.solve_triangular (direct.py:66-70); y,x host (n,) if nrhs==1 else (n,nrhs)
+ * row-major */
+int tgp_solver_solve_tri(tgp_solver* s, int transpose, int64_t nrhs, const void* y_host,
+                         void* x_host);
+/* DirectSolver.dot_triangular (direct.py:72-73): out = L @ y */
+int tgp_solver_dot_tri(tgp_solver* s, int64_t nrhs, const void* y_host, void* out_host);
+/* fused GaussianProcess._get_alpha + _compute_log_prob (gp.py:313-320) on resid = y - loc;
+ * resid_host == NULL re-uses the residual uploaded by tgp_solver_set_resid */
+int tgp_solver_set_resid(tgp_solver* s, const void* resid_host);
+int tgp_solver_logprob(tgp_solver* s, const void* resid_host, double* out);
+/* GaussianProcess._condition (gp.py:330-334): alpha = K^-1 resid (host, (n,)) and log-prob */
+int tgp_solver_alpha(tgp_solver* s, const void* resid_host, void* alpha_host, double* logprob);
+/* mean = K(Xt, X) alpha (gp.py:353-357; K9 fused). Xt host (m,d) row-major */
+int tgp_solver_cond_mean(tgp_solver* s, const tgp_kop* prog, int nops, int64_t m,
+                         const void* Xt_host, const void* alpha_host, void* mean_host);
+/* DirectSolver.condition (direct.py:75-95): out (m,m) row-major = Kss + diag(noise_t) - A^T A.
+ * Xt_host NULL -> X itself (m = n).  var_only != 0: out is (m,) = diag of that matrix. */
+int tgp_solver_condition_cov(tgp_solver* s, const tgp_kop* prog, int nops, int64_t m,
+                             const void* Xt_host, const void* noise_t_host, int var_only,
+                             void* out_host);
+/* DirectSolver.covariance (direct.py:58-59): K recomputed (the factor overwrote it) */
+int tgp_solver_covariance(tgp_solver* s, void* out_host);
+/* DirectSolver.variance (direct.py:49,55-56): k(x_i,x_i) + diag_i */
+int tgp_solver_variance(tgp_solver* s, void* out_host);
+/* scale_tril (direct.py:28): (n,n) row-major, upper triangle zero */
+int tgp_solver_get_factor(tgp_solver* s, void* L_host);
+/* device pointers of the padded factor (column-major, ld = n_pad) for zero-copy hosts */
+int tgp_solver_device_factor(tgp_solver* s, void** L_dev, int64_t* n_pad);
+/* last-call timings measured with HIP events on the ctx stream when option "profile"=1:
+ * ms[0]=assembly, ms[1]=potrf total, ms[2]=sum of trailing-update (syrk) kernels,
+ * ms[3]=number of trailing-update launches, ms[4]=trsv, ms[5]=panel (potf2+trsm) kernels */
+int tgp_solver_timings(tgp_solver* s, double* ms, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGP_HIP_H */

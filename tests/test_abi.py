@@ -1,0 +1,47 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol include/tgp_hip.h declares."""
+import re
+from pathlib import Path
+
+import pytest
+
+from tinygp_amd import _ffi
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def header_symbols():
+    text = (ROOT / "include" / "tgp_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tgp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert header_symbols() == sorted(_ffi.SIGNATURES)
+
+
+def test_library_exports_every_symbol():
+    lib = _ffi.load_library()  # raises if the .so is missing or a symbol is absent
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    assert lib.tgp_abi_version() == 1
+
+
+def test_missing_library_is_loud(tmp_path):
+    with pytest.raises(_ffi.TgpError, match="no CPU fallback"):
+        _ffi.load_library(tmp_path / "libtgp_hip.so")
+
+
+def test_no_gpu_is_loud():
+    """Without a HIP device every compute entry point must fail, never fall back."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises((_ffi.TgpError, ValueError)):
+        _ffi.Ctx(0)
+
+
+def test_product_never_imports_the_oracle():
+    for py in (ROOT / "tinygp_amd").rglob("*.py"):
+        src = py.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, py

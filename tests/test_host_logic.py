@@ -1,0 +1,116 @@
+"""Host-side logic that needs no GPU: kernel-tree lowering, argument validation and the
+reference's structural error conventions (SURVEY.md 8b "Error conventions")."""
+import numpy as np
+import pytest
+
+import _cases
+from tinygp_amd import kernels, noise
+from tinygp_amd.kernels import base
+
+
+def test_programs_are_postfix():
+    k = 1.5**2 * kernels.ExpSquared(2.5)
+    assert k.program() == [(base.K_CONST, 0, 2.25, 0.0), (base.K_EXPSQ, 1, 2.5, 0.0),
+                           (base.K_MUL, 0, 0.0, 0.0)]
+    k = kernels.Matern32(1.5) + kernels.ExpSineSquared(0.5, gamma=1.5) * 2.0
+    ops = [op for op, *_ in k.program()]
+    assert ops == [base.K_M32, base.K_ESS, base.K_CONST, base.K_MUL, base.K_ADD]
+    # metric tags: L1 default, L2 for ExpSquared, overridable (stationary.py:56,102)
+    assert kernels.Matern52(1.0).program()[0][1] == 0
+    assert kernels.ExpSquared(1.0).program()[0][1] == 1
+    assert kernels.Matern52(1.0, distance=kernels.L2Distance()).program()[0][1] == 1
+    assert kernels.RationalQuadratic(alpha=2.0).program()[0] == (base.K_RQ, 0, 1.0, 2.0)
+
+
+def test_every_zoo_kernel_lowers():
+    for name, k in _cases.kernel_zoo(kernels).items():
+        prog = k.program()
+        assert 1 <= len(prog) <= base.KPROG_MAX, name
+
+
+def test_sum_builtin_and_operators():
+    ks = [kernels.Exp(1.0), kernels.Matern32(2.0), kernels.Cosine(3.0)]
+    total = sum(ks)  # 0 + k hits __radd__ (base.py:110-113)
+    assert [op for op, *_ in total.program()] == [base.K_EXP, base.K_M32, base.K_ADD, base.K_COS, base.K_ADD]
+    assert isinstance(2.0 * ks[0], kernels.Product) and isinstance(ks[0] * 2.0, kernels.Product)
+    assert isinstance(2.0 + ks[0], kernels.Sum) and isinstance(ks[0] + 2.0, kernels.Sum)
+
+
+def test_structural_errors_raise_valueerror():
+    with pytest.raises(ValueError):  # base.py:207-208
+        kernels.Constant(np.ones(3)).program()
+    with pytest.raises(ValueError):
+        (np.ones(3) * kernels.Matern32(1.5)).program()
+    with pytest.raises(ValueError):  # stationary.py:77-81
+        kernels.Exp(np.ones(2)).program()
+    for cls in (kernels.ExpSineSquared, kernels.RationalQuadratic):  # stationary.py:198-200,228-230
+        with pytest.raises(ValueError):
+            cls(0.5)
+    with pytest.raises(ValueError):  # noise.py:67-72
+        noise.Diagonal(0.1)
+    with pytest.raises(ValueError):
+        noise.Diagonal(np.ones((3, 3)))
+
+
+def test_too_deep_or_long_programs_rejected():
+    k = kernels.Exp(1.0)
+    for _ in range(20):
+        k = k + kernels.Exp(1.0)
+    with pytest.raises(ValueError):
+        k.program()  # 41 ops > 32
+    deep = kernels.Exp(1.0)
+    for _ in range(9):
+        deep = kernels.Exp(1.0) * deep  # right-nested: stack grows
+    with pytest.raises(ValueError):
+        deep.program()
+
+
+def test_custom_metric_is_refused_loudly():
+    class MyDistance(kernels.Distance):
+        def distance(self, X1, X2):
+            return np.abs(X1 - X2).max()
+
+    with pytest.raises(NotImplementedError):
+        kernels.Matern32(1.0, distance=MyDistance()).program()
+
+
+def test_distance_scalar_protocol():
+    # test_distance.py:17-33 value checks (gradients are JAX-only)
+    a, b = np.array([0.1, -0.4, 2.0]), np.array([0.3, 0.4, -1.0])
+    assert np.isclose(kernels.L1Distance().distance(a, b), np.abs(a - b).sum())
+    assert np.isclose(kernels.L2Distance().distance(a, b), np.sqrt(((a - b) ** 2).sum()))
+    assert np.isclose(kernels.L2Distance().squared_distance(a, b), ((a - b) ** 2).sum())
+    assert kernels.L2Distance().distance(a, a) == 0.0
+    assert np.isclose(kernels.L1Distance().squared_distance(a, b), np.abs(a - b).sum() ** 2)
+
+
+def check_noise_model(nz, dense_rep):
+    # reference tests/test_noise.py:10-24
+    rng = np.random.default_rng(6675)
+    np.testing.assert_allclose(nz.diagonal(), np.diag(dense_rep))
+    np.testing.assert_allclose(nz + np.zeros_like(dense_rep), dense_rep)
+    y1 = rng.normal(size=dense_rep.shape)
+    np.testing.assert_allclose(nz + y1, dense_rep + y1)
+    np.testing.assert_allclose(y1 + nz, y1 + dense_rep)
+    np.testing.assert_allclose(nz @ y1, dense_rep @ y1)
+    y2 = rng.normal(size=(dense_rep.shape[1], 3))
+    np.testing.assert_allclose(nz @ y2, dense_rep @ y2)
+    y3 = rng.normal(size=dense_rep.shape[1])
+    np.testing.assert_allclose(nz @ y3, dense_rep @ y3)
+
+
+def test_noise_diagonal_and_dense():
+    rng = np.random.default_rng(9432)
+    diag = rng.normal(size=50)
+    check_noise_model(noise.Diagonal(diag=diag), np.diag(diag))
+    M = rng.normal(size=(50, 50))
+    check_noise_model(noise.Dense(value=M), M)
+
+
+def test_synthetic_inputs_are_reproducible():
+    X, y = _cases.synthetic.make_inputs(1024, 1)
+    X2, y2 = _cases.synthetic.make_inputs(1024, 1)
+    assert np.array_equal(X, X2) and np.array_equal(y, y2)
+    assert np.all(np.diff(X) >= 0) and X.max() <= 10.24
+    X3, _ = _cases.synthetic.make_inputs(4096, 3)
+    assert X3.shape == (4096, 3) and X3.max() <= (40.96) ** (1 / 3)

@@ -1,0 +1,179 @@
+"""CPU tests of the oracle itself: regression against the committed golden vectors and the
+pins the reference's own tests use (agreement between independent implementations)."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import _cases
+from oracle import tinygp_np as o
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+# ---- golden regression -------------------------------------------------------------------
+def test_kernels_match_golden(golden_dir):
+    g = np.load(golden_dir / "kernels.npz")
+    x1, x2 = _cases.data_kernels()
+    xs, _, ts = _cases.data_solver()
+    for name, k in _cases.kernel_zoo(o).items():
+        np.testing.assert_allclose(k(x1, x2), g[f"{name}__5d"], rtol=1e-14, atol=1e-15)
+        np.testing.assert_allclose(k(xs, ts), g[f"{name}__1d"], rtol=1e-14, atol=1e-15)
+        np.testing.assert_allclose(k(x1), g[f"{name}__diag"], rtol=1e-14, atol=1e-15)
+
+
+def test_gp_matches_golden(golden_dir):
+    g = np.load(golden_dir / "gp.npz")
+    for name, (gp, y, t) in _cases.gp_cases(o, o.GaussianProcess).items():
+        np.testing.assert_allclose(gp.log_probability(y), g[f"{name}__logp"], rtol=1e-12)
+        c1 = gp.condition(y, t)
+        np.testing.assert_allclose(c1.gp.loc, g[f"{name}__test_loc"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(c1.gp.covariance, g[f"{name}__test_cov"], rtol=1e-8, atol=1e-10)
+
+
+def test_config1_matches_golden_and_survey_datum(golden_dir):
+    g = np.load(golden_dir / "configs.npz")
+    X, y, c = _cases.data_config("c1")
+    gp = o.GaussianProcess(_cases.synthetic.config_kernel(o, c["kernel"]), X, diag=c["diag"])
+    lp = float(gp.log_probability(y))
+    np.testing.assert_allclose(lp, g["expsq_n1024__logp"], rtol=1e-12)
+    # SURVEY.md 8(c) sanity datum, measured independently during the survey
+    np.testing.assert_allclose(lp, 853.7063780492, rtol=1e-11)
+
+
+# ---- pins: closed forms and independent linear algebra -------------------------------------
+def test_closed_form_expsquared():
+    # reference tests/test_kernels/test_kernels.py:43-52
+    x1, x2 = _cases.data_kernels()
+    scale = 1.5
+    want = np.exp(-0.5 * np.sum(np.square((x1[:, None, :] - x2[None, :, :]) / scale), axis=-1))
+    o.assert_allclose(o.ExpSquared(scale)(x1, x2), want)
+
+
+def test_closed_forms_1d():
+    xs, _, ts = _cases.data_solver()
+    r = np.abs(xs[:, None] - ts[None, :]) / 1.5
+    o.assert_allclose(o.Exp(1.5)(xs, ts), np.exp(-r))
+    o.assert_allclose(o.Matern32(1.5)(xs, ts), (1 + np.sqrt(3) * r) * np.exp(-np.sqrt(3) * r))
+    o.assert_allclose(o.Matern52(1.5)(xs, ts),
+                      (1 + np.sqrt(5) * r + 5 * r**2 / 3) * np.exp(-np.sqrt(5) * r))
+    o.assert_allclose(o.Cosine(1.5)(xs, ts), np.cos(2 * np.pi * r))
+    o.assert_allclose(o.ExpSineSquared(1.5, gamma=0.3)(xs, ts), np.exp(-0.3 * np.sin(np.pi * r) ** 2))
+    o.assert_allclose(o.RationalQuadratic(1.5, alpha=0.7)(xs, ts), (1 + r**2 / 1.4) ** -0.7)
+
+
+def test_metric_defaults():
+    # stationary.py:56,102: L1 everywhere except ExpSquared; RationalQuadratic squares the L1 norm
+    x1, x2 = _cases.data_kernels()
+    d = x1[:, None, :] - x2[None, :, :]
+    l1 = np.abs(d).sum(-1)
+    o.assert_allclose(o.Matern32(1.5)(x1, x2), (1 + np.sqrt(3) * l1 / 1.5) * np.exp(-np.sqrt(3) * l1 / 1.5))
+    o.assert_allclose(o.RationalQuadratic(alpha=1.5)(x1, x2), (1 + 0.5 * l1**2 / 1.5) ** -1.5)
+
+
+def test_constant_and_ops():
+    # test_kernels.py:23-40,62-69
+    x1, x2 = _cases.data_kernels()
+    k1 = o.Matern32(2.5)
+    o.assert_allclose(2.5 * k1(x1, x2), (2.5 * k1)(x1, x2))
+    ka = 1.5 * o.Matern32(2.5)
+    kb = 0.9 * o.ExpSineSquared(scale=1.5, gamma=0.3)
+    o.assert_allclose(ka(x1, x2) + kb(x1, x2), (ka + kb)(x1, x2))
+    o.assert_allclose(ka(x1, x2) * kb(x1, x2), (ka * kb)(x1, x2))
+    with pytest.raises(ValueError):
+        o.Constant(np.ones(3)).evaluate(np.ones(3), np.ones(3))
+    assert sum([k1, k1]) is not None
+
+
+def test_conditioned_vs_dense_solve():
+    # test_kernels.py:72-83
+    x1, x2 = _cases.data_kernels()
+    k1 = 1.5 * o.Matern32(2.5)
+    k2 = 0.9 * o.ExpSineSquared(scale=1.5, gamma=0.3)
+    K = k1(x1, x1) + 0.1 * np.eye(x1.shape[0])
+    solver = o.DirectSolver.init(k1, x1, o.Diagonal(np.full(x1.shape[0], 0.1)))
+    cond = o.Conditioned(x1, solver, k2)
+    o.assert_allclose(cond(x1, x2), k2(x1, x2) - k2(x1, x1) @ np.linalg.solve(K, k2(x1, x2)))
+
+
+def test_gp_vs_textbook_formulas():
+    """The identities george implements (test_george_compat.py:116-154), by np.linalg."""
+    for nd in (1, 3):
+        x, y, t, diag = _cases.data_george(nd)
+        for name in ["exp", "expsq", "matern32", "matern52", "ratquad"]:
+            k = _cases.kernel_zoo(o)[name]
+            gp = o.GaussianProcess(k, x, diag=diag)
+            K = k(x, x) + np.diag(diag)
+            sign, logdet = np.linalg.slogdet(K)
+            want = -0.5 * y @ np.linalg.solve(K, y) - 0.5 * logdet - 0.5 * len(y) * np.log(2 * np.pi)
+            o.assert_allclose(gp.log_probability(y), want)
+            Ks = k(t, x)
+            mu = Ks @ np.linalg.solve(K, y)
+            cov = k(t, t) - Ks @ np.linalg.solve(K, Ks.T)
+            loc, c = gp.predict(y, t, return_cov=True)
+            o.assert_allclose(loc, mu)
+            o.assert_allclose(c - np.sqrt(np.finfo(float).eps) * np.eye(len(t)), cov)
+            o.assert_allclose(gp.predict(y), k(x, x) @ np.linalg.solve(K, y))
+            o.assert_allclose(gp.predict(y, x), k(x, x) @ np.linalg.solve(K, y))
+
+
+def test_means_equivalent():
+    # test_gp.py:41-51 (y is a scalar there: it broadcasts against loc)
+    rng = np.random.default_rng(1058390)
+    X = rng.uniform(-3, 3, (50, 5))
+    y = rng.normal(len(X))
+    gp1 = o.GaussianProcess(o.Matern32(1.5), X, diag=0.01, mean=lambda x: 0.0)
+    gp2 = o.GaussianProcess(o.Matern32(1.5), X, diag=0.01, mean=0.0)
+    gp3 = o.GaussianProcess(o.Matern32(1.5), X, diag=0.01)
+    o.assert_allclose(gp1.log_probability(y), gp2.log_probability(y))
+    o.assert_allclose(gp1.log_probability(y), gp3.log_probability(y))
+
+
+def test_nonpd_gives_minus_inf():
+    x = np.linspace(0, 1, 20)
+    gp = o.GaussianProcess(o.ExpSquared(5.0), x, diag=-0.5)
+    assert gp.log_probability(np.sin(x)) == -np.inf
+
+
+# ---- independent plain-C restatement --------------------------------------------------------
+@pytest.fixture(scope="module")
+def refc():
+    so = ROOT / "oracle" / "_build" / "libref_c.so"
+    if not so.exists():
+        subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
+    lib = C.CDLL(str(so))
+    lib.ref_log_probability.restype = C.c_double
+    return lib
+
+
+def _prog(kernel):
+    from tinygp_amd import _ffi
+    return _ffi.as_kprog(kernel.program())
+
+
+def test_c_oracle_agrees(refc):
+    from tinygp_amd import kernels as pk
+
+    dp = C.POINTER(C.c_double)
+    zoo_o, zoo_p = _cases.kernel_zoo(o), _cases.kernel_zoo(pk)
+    x1, x2 = _cases.data_kernels()
+    for name in zoo_o:
+        kp, nops = _prog(zoo_p[name])
+        out = np.empty((50, 50))
+        refc.ref_kmat(kp, nops, C.c_int64(50), C.c_int64(50), 5, x1.ctypes.data_as(dp),
+                      x2.ctypes.data_as(dp), None, out.ctypes.data_as(dp))
+        np.testing.assert_allclose(out, zoo_o[name](x1, x2), rtol=1e-13, atol=1e-15, err_msg=name)
+    # whole log_probability through the textbook unblocked Cholesky
+    X, y, c = _cases.data_config("c1")
+    n = 512
+    X, y = np.ascontiguousarray(X[:n]), np.ascontiguousarray(y[:n])
+    kp, nops = _prog(_cases.synthetic.config_kernel(pk, "expsq"))
+    diag = np.full(n, 0.01)
+    work = np.empty((n, n))
+    got = refc.ref_log_probability(kp, nops, C.c_int64(n), 1, X.ctypes.data_as(dp),
+                                   diag.ctypes.data_as(dp), y.ctypes.data_as(dp),
+                                   work.ctypes.data_as(dp))
+    want = float(o.GaussianProcess(_cases.synthetic.config_kernel(o, "expsq"), X, diag=0.01).log_probability(y))
+    np.testing.assert_allclose(got, want, rtol=1e-10)

@@ -1,0 +1,120 @@
+"""NumPy-in / NumPy-out wrappers over the device-pointer C ABI.
+
+Used by ``Kernel.__call__`` / ``Kernel.matmul`` (stand-alone kernel evaluation,
+reference ``kernels/base.py:68-103``).  The solver keeps its own resident
+buffers (``solvers/direct.py``) and does not go through here.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from tinygp_amd import _ffi
+
+__all__ = ["points", "common_dtype", "kmat", "kdiag", "kmat_gemv"]
+
+
+def common_dtype(*arrays) -> np.dtype:
+    """float32 only if every floating input is float32, else float64 (the reference's
+    dtype follows JAX's global x64 flag, docs/troubleshooting.md:21-25; here it follows
+    the inputs)."""
+    dts = [np.asarray(a).dtype for a in arrays if a is not None]
+    if dts and all(dt == np.float32 for dt in dts):
+        return np.dtype(np.float32)
+    return np.dtype(np.float64)
+
+
+def points(X, dtype=None) -> np.ndarray:
+    """Coordinates as a C-contiguous (N, D) array: (N,) -> (N, 1)."""
+    if isinstance(X, (dict, list, tuple)):
+        raise NotImplementedError(
+            "pytree inputs need a custom kernel evaluated on the host; the HIP path takes "
+            "X of shape (N,) or (N, D)")
+    X = np.asarray(X)
+    if X.ndim == 0:
+        raise ValueError("expected an array of coordinates with a leading data axis")
+    if X.ndim == 1:
+        X = X[:, None]
+    if X.ndim != 2:
+        raise ValueError(f"coordinates must have shape (N,) or (N, D); got ndim={X.ndim}")
+    if X.shape[1] > 16:
+        raise ValueError("the HIP kernel evaluator supports at most D = 16 input dimensions")
+    dtype = common_dtype(X) if dtype is None else dtype
+    return np.ascontiguousarray(X, dtype=dtype)
+
+
+def kmat(prog, X1, X2, *, ctx=None) -> np.ndarray:
+    """K[i, j] = k(X1[i], X2[j]) as a row-major (n1, n2) host array (K1)."""
+    ctx = _ffi.default_ctx() if ctx is None else ctx
+    dt = common_dtype(X1, X2)
+    P1, P2 = points(X1, dt), points(X2, dt)
+    if P1.shape[1] != P2.shape[1]:
+        raise ValueError("X1 and X2 must have the same number of input dimensions")
+    n1, n2, d = P1.shape[0], P2.shape[0], P1.shape[1]
+    if n1 == 0 or n2 == 0:
+        return np.zeros((n1, n2), dtype=dt)
+    kp, nops = _ffi.as_kprog(prog)
+    lib = _ffi.lib()
+    # The device writes column-major.  Evaluating k(X2[j], X1[i]) into a column-major
+    # (n2 x n1) buffer is byte-identical to the row-major (n1, n2) result we want
+    # (|d| and d^2 are exactly symmetric in floating point).
+    d1, d2 = ctx.upload(P1), ctx.upload(P2)
+    out = ctx.malloc(n1 * n2 * dt.itemsize)
+    try:
+        _ffi.check(lib.tgp_kmat(ctx.handle, _ffi.dtype_code(dt), kp, nops, n2, n1, d,
+                                C.c_void_p(d2), C.c_void_p(d1), None, C.c_void_p(out), n2, n2, n1,
+                                0), "tgp_kmat")
+        return ctx.download(out, (n1, n2), dt)
+    finally:
+        ctx.free(d1), ctx.free(d2), ctx.free(out)
+
+
+def kdiag(prog, X, *, ctx=None) -> np.ndarray:
+    """k(X[i], X[i]) as an (n,) host array (K2)."""
+    ctx = _ffi.default_ctx() if ctx is None else ctx
+    P = points(X)
+    dt = P.dtype
+    n, d = P.shape
+    if n == 0:
+        return np.zeros((0,), dtype=dt)
+    kp, nops = _ffi.as_kprog(prog)
+    dX = ctx.upload(P)
+    out = ctx.malloc(n * dt.itemsize)
+    try:
+        _ffi.check(_ffi.lib().tgp_kdiag(ctx.handle, _ffi.dtype_code(dt), kp, nops, n, d,
+                                        C.c_void_p(dX), C.c_void_p(out)), "tgp_kdiag")
+        return ctx.download(out, (n,), dt)
+    finally:
+        ctx.free(dX), ctx.free(out)
+
+
+def kmat_gemv(prog, X1, X2, v, *, ctx=None) -> np.ndarray:
+    """sum_j k(X1[i], X2[j]) v[j, ...] without materialising K (K9)."""
+    ctx = _ffi.default_ctx() if ctx is None else ctx
+    v = np.asarray(v)
+    dt = common_dtype(X1, X2, v)
+    P1, P2 = points(X1, dt), points(X2, dt)
+    if P1.shape[1] != P2.shape[1]:
+        raise ValueError("X1 and X2 must have the same number of input dimensions")
+    if v.shape[0] != P2.shape[0]:
+        raise ValueError("dimension mismatch between X2 and y in Kernel.matmul")
+    n1, n2, d = P1.shape[0], P2.shape[0], P1.shape[1]
+    cols = np.ascontiguousarray(v.reshape(n2, -1).T, dtype=dt)  # (R, n2)
+    res = np.empty((cols.shape[0], n1), dtype=dt)
+    kp, nops = _ffi.as_kprog(prog)
+    d1, d2 = ctx.upload(P1), ctx.upload(P2)
+    dv, do = ctx.malloc(n2 * dt.itemsize), ctx.malloc(n1 * dt.itemsize)
+    lib = _ffi.lib()
+    try:
+        for r in range(cols.shape[0]):
+            _ffi.check(lib.tgp_memcpy_h2d(ctx.handle, C.c_void_p(dv), _ffi.ptr(cols[r]),
+                                          cols[r].nbytes), "tgp_memcpy_h2d")
+            _ffi.check(lib.tgp_kmat_gemv(ctx.handle, _ffi.dtype_code(dt), kp, nops, n1, n2, d,
+                                         C.c_void_p(d1), C.c_void_p(d2), C.c_void_p(dv),
+                                         C.c_void_p(do)), "tgp_kmat_gemv")
+            res[r] = ctx.download(do, (n1,), dt)
+    finally:
+        ctx.free(d1), ctx.free(d2), ctx.free(dv), ctx.free(do)
+    return res.T.reshape((n1,) + v.shape[1:])

@@ -1,0 +1,227 @@
+"""ctypes binding of ``libtgp_hip.so`` (the C ABI declared in ``include/tgp_hip.h``).
+
+This is the only place the Python host touches native code.  There is NO CPU
+fallback: if the shared library is missing or no MI355X is visible, every
+entry point raises.  (The NumPy oracle under ``oracle/`` is test infrastructure
+and is never imported from here.)
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from pathlib import Path
+
+import numpy as np
+
+__all__ = [
+    "lib", "library_path", "default_ctx", "Ctx", "KOp", "check", "TgpError",
+    "dtype_code", "F32", "F64", "TILE",
+]
+
+F32, F64 = 0, 1
+TILE = 128
+E_ARG = -1
+
+_LIB_NAME = "libtgp_hip.so"
+_lock = threading.Lock()
+_lib = None
+_default_ctx = None
+
+
+class TgpError(RuntimeError):
+    pass
+
+
+class KOp(C.Structure):
+    """``tgp_kop`` -- one postfix op of a kernel program."""
+
+    _fields_ = [("op", C.c_int32), ("metric", C.c_int32), ("p0", C.c_double), ("p1", C.c_double)]
+
+
+def library_path() -> Path:
+    env = os.environ.get("TGP_HIP_LIBRARY")
+    if env:
+        return Path(env)
+    return Path(__file__).resolve().parent / "lib" / _LIB_NAME
+
+
+_i32, _i64, _dbl, _vp, _int = C.c_int32, C.c_int64, C.c_double, C.c_void_p, C.c_int
+_pi32, _pi64, _pdbl, _pvp = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_void_p)
+_pkop = C.POINTER(KOp)
+
+# name -> argtypes; every symbol include/tgp_hip.h declares (checked by tests/test_abi.py)
+SIGNATURES = {
+    "tgp_abi_version": [],
+    "tgp_last_error": [],
+    "tgp_ctx_create": [_int, _vp, _pvp],
+    "tgp_ctx_destroy": [_vp],
+    "tgp_ctx_sync": [_vp],
+    "tgp_ctx_set_option": [_vp, C.c_char_p, _i64, _pi64],
+    "tgp_ctx_device_info": [_vp, C.c_char_p, _int, _pi32, _pi64, _pi32],
+    "tgp_malloc": [_vp, C.c_size_t, _pvp],
+    "tgp_free": [_vp, _vp],
+    "tgp_memcpy_h2d": [_vp, _vp, _vp, C.c_size_t],
+    "tgp_memcpy_d2h": [_vp, _vp, _vp, C.c_size_t],
+    "tgp_memset": [_vp, _vp, _int, C.c_size_t],
+    "tgp_kmat": [_vp, _int, _pkop, _int, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],
+    "tgp_kdiag": [_vp, _int, _pkop, _int, _i64, _i32, _vp, _vp],
+    "tgp_kmat_gemv": [_vp, _int, _pkop, _int, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
+    "tgp_potrf": [_vp, _int, _i64, _vp, _i64, _pi32],
+    "tgp_trsv": [_vp, _int, _i64, _vp, _i64, _int, _vp],
+    "tgp_trsm_right_lt": [_vp, _int, _i64, _i64, _vp, _i64, _vp, _i64],
+    "tgp_gemm_nt": [_vp, _int, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64, _int],
+    "tgp_sum_log_diag": [_vp, _int, _i64, _vp, _i64, _pdbl],
+    "tgp_sum_squares": [_vp, _int, _i64, _vp, _pdbl],
+    "tgp_ubench_mfma": [_vp, _int, _pdbl],
+    "tgp_solver_create": [_vp, _int, _i64, _i32, _vp, _vp, _pvp],
+    "tgp_solver_destroy": [_vp],
+    "tgp_solver_factor": [_vp, _pkop, _int, _vp, _pi32],
+    "tgp_solver_set_noise": [_vp, _vp],
+    "tgp_solver_normalization": [_vp, _pdbl],
+    "tgp_solver_solve_tri": [_vp, _int, _i64, _vp, _vp],
+    "tgp_solver_dot_tri": [_vp, _i64, _vp, _vp],
+    "tgp_solver_set_resid": [_vp, _vp],
+    "tgp_solver_logprob": [_vp, _vp, _pdbl],
+    "tgp_solver_alpha": [_vp, _vp, _vp, _pdbl],
+    "tgp_solver_cond_mean": [_vp, _pkop, _int, _i64, _vp, _vp, _vp],
+    "tgp_solver_condition_cov": [_vp, _pkop, _int, _i64, _vp, _vp, _int, _vp],
+    "tgp_solver_covariance": [_vp, _vp],
+    "tgp_solver_variance": [_vp, _vp],
+    "tgp_solver_get_factor": [_vp, _vp],
+    "tgp_solver_device_factor": [_vp, _pvp, _pi64],
+    "tgp_solver_timings": [_vp, _pdbl, _int],
+}
+
+
+def load_library(path: Path | None = None) -> C.CDLL:
+    """dlopen the library and attach signatures.  Needs no GPU (used by the ABI test)."""
+    path = library_path() if path is None else Path(path)
+    if not path.exists():
+        raise TgpError(
+            f"{path} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C tinygp_amd/csrc`). "
+            "tinygp_amd has no CPU fallback."
+        )
+    lib_ = C.CDLL(str(path))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib_, name)  # AttributeError = ABI drift, deliberately loud
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "tgp_last_error" else C.c_int
+    return lib_
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                _lib = load_library()
+    return _lib
+
+
+def check(status: int, what: str = "") -> int:
+    """Raise on a negative status; positive values (potrf info) pass through."""
+    if status >= 0:
+        return status
+    msg = lib().tgp_last_error()
+    msg = msg.decode() if msg else "unknown error"
+    if status == E_ARG:
+        raise ValueError(f"{what}: {msg}" if what else msg)
+    raise TgpError(f"{what}: {msg} (status {status})" if what else f"{msg} (status {status})")
+
+
+def dtype_code(dtype) -> int:
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return F64
+    if dtype == np.float32:
+        return F32
+    raise ValueError(f"tinygp_amd computes in float32 or float64, got {dtype}")
+
+
+class Ctx:
+    """A ``tgp_ctx``: one HIP device + one stream."""
+
+    def __init__(self, device: int | None = None, stream: int | None = None):
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device
+        h = C.c_void_p()
+        check(lib().tgp_ctx_create(device, C.c_void_p(stream or 0), C.byref(h)), "tgp_ctx_create")
+        self.handle = h
+
+    def sync(self):
+        check(lib().tgp_ctx_sync(self.handle), "tgp_ctx_sync")
+
+    def set_option(self, key: str, value: int) -> int:
+        old = C.c_int64()
+        check(lib().tgp_ctx_set_option(self.handle, key.encode(), int(value), C.byref(old)),
+              "tgp_ctx_set_option")
+        return old.value
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cus, mem, clk = C.c_int32(), C.c_int64(), C.c_int32()
+        check(lib().tgp_ctx_device_info(self.handle, name, 256, C.byref(cus), C.byref(mem),
+                                        C.byref(clk)), "tgp_ctx_device_info")
+        return {"name": name.value.decode(), "cus": cus.value, "mem_bytes": mem.value,
+                "clock_khz": clk.value}
+
+    # raw buffers ------------------------------------------------------------
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        check(lib().tgp_malloc(self.handle, max(int(nbytes), 8), C.byref(p)), "tgp_malloc")
+        return p.value
+
+    def free(self, ptr: int):
+        if ptr:
+            lib().tgp_free(self.handle, C.c_void_p(ptr))
+
+    def upload(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(arr.nbytes)
+        if arr.nbytes:
+            check(lib().tgp_memcpy_h2d(self.handle, C.c_void_p(p), arr.ctypes.data_as(C.c_void_p),
+                                       arr.nbytes), "tgp_memcpy_h2d")
+        return p
+
+    def download(self, ptr: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes:
+            check(lib().tgp_memcpy_d2h(self.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr),
+                                       out.nbytes), "tgp_memcpy_d2h")
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().tgp_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def default_ctx() -> Ctx:
+    global _default_ctx
+    if _default_ctx is None:
+        with _lock:
+            if _default_ctx is None:
+                _default_ctx = Ctx()
+    return _default_ctx
+
+
+def as_kprog(ops):
+    """list of (op, metric, p0, p1) -> (ctypes array, n)."""
+    arr = (KOp * max(len(ops), 1))()
+    for i, (op, metric, p0, p1) in enumerate(ops):
+        arr[i] = KOp(int(op), int(metric), float(p0), float(p1))
+    return arr, len(ops)
+
+
+def ptr(a: np.ndarray | None):
+    return C.c_void_p(0) if a is None else a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,749 @@
+// capi.hip -- the extern "C" boundary of libtgp_hip.so (include/tgp_hip.h).
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "tgp_common.h"
+
+namespace tgp {
+
+static thread_local std::string g_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+}
+
+static int grow(void** p, size_t* cur, size_t bytes) {
+  if (bytes <= *cur) return TGP_OK;
+  if (*p) TGP_HIP_TRY(hipFree(*p));
+  *p = nullptr;
+  *cur = 0;
+  TGP_HIP_TRY(hipMalloc(p, bytes));
+  *cur = bytes;
+  return TGP_OK;
+}
+
+int ensure_dinv(tgp_ctx* ctx, size_t bytes) { return grow(&ctx->d_dinv, &ctx->dinv_bytes, bytes); }
+int ensure_work(tgp_ctx* ctx, size_t bytes) { return grow(&ctx->d_work, &ctx->work_bytes, bytes); }
+
+template <typename F>
+static int dispatch(int dtype, F&& f) {
+  if (dtype == TGP_F64) return f(double{});
+  if (dtype == TGP_F32) return f(float{});
+  set_error("dtype must be TGP_F32 (0) or TGP_F64 (1), got %d", dtype);
+  return TGP_E_ARG;
+}
+
+static inline size_t esize(int dtype) { return dtype == TGP_F64 ? 8 : 4; }
+
+}  // namespace tgp
+
+using namespace tgp;
+
+struct tgp_solver {
+  tgp_ctx* ctx = nullptr;
+  int dtype = TGP_F64;
+  int64_t n = 0, npad = 0;
+  int d = 1;
+  void* X = nullptr;     // (n, d) row-major
+  void* diag = nullptr;  // (n,)
+  void* A = nullptr;     // npad x npad column-major: K, then L in place
+  void* dinv = nullptr;  // (npad/128) * 8 * 256 inverse 16x16 diagonal blocks
+  void* vec = nullptr;   // npad work vectors
+  void* vec2 = nullptr;
+  void* resid = nullptr;  // resident residual (tgp_solver_set_resid)
+  void* scratch = nullptr;  // per-solver workspace (multi-RHS / conditional products)
+  size_t scratch_bytes = 0;
+  KProg kp{};
+  bool has_prog = false, factored = false, has_resid = false;
+  int32_t info = 0;
+  double logdet_half = 0;  // sum log L_ii
+  double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+#define CTX_GUARD(ctx)                                                \
+  do {                                                                \
+    TGP_ARG_CHECK((ctx) != nullptr, "null context");                  \
+    TGP_HIP_TRY(hipSetDevice((ctx)->device));                         \
+  } while (0)
+
+#define SOLVER_GUARD(s)                                               \
+  do {                                                                \
+    TGP_ARG_CHECK((s) != nullptr && (s)->ctx != nullptr, "null solver"); \
+    TGP_HIP_TRY(hipSetDevice((s)->ctx->device));                      \
+  } while (0)
+
+extern "C" {
+
+int tgp_abi_version(void) { return TGP_ABI_VERSION; }
+const char* tgp_last_error(void) { return g_error.c_str(); }
+
+int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
+  TGP_ARG_CHECK(out != nullptr, "null output pointer");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    set_error("no HIP device visible (%s); tinygp_amd has no CPU fallback",
+              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return TGP_E_HIP;
+  }
+  TGP_ARG_CHECK(device >= 0 && device < count, "device %d out of range (0..%d)", device, count - 1);
+  TGP_HIP_TRY(hipSetDevice(device));
+  tgp_ctx* ctx = new tgp_ctx();
+  ctx->device = device;
+  if (stream) {
+    ctx->stream = static_cast<hipStream_t>(stream);
+  } else {
+    TGP_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  int lo = 0, hi = 0;
+  TGP_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->panel_stream, hipStreamNonBlocking, hi));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+  TGP_HIP_TRY(hipMalloc(&ctx->d_scal, 16 * sizeof(double)));
+  TGP_HIP_TRY(hipMalloc(&ctx->d_info, sizeof(int32_t)));
+  hipDeviceProp_t prop;
+  TGP_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  ctx->cus = prop.multiProcessorCount;
+  *out = ctx;
+  return TGP_OK;
+}
+
+int tgp_ctx_destroy(tgp_ctx* ctx) {
+  if (!ctx) return TGP_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->panel_stream) hipStreamSynchronize(ctx->panel_stream);
+  for (auto e : ctx->ev_pool) hipEventDestroy(e);
+  if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
+  if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
+  if (ctx->d_scal) hipFree(ctx->d_scal);
+  if (ctx->d_info) hipFree(ctx->d_info);
+  if (ctx->d_dinv) hipFree(ctx->d_dinv);
+  if (ctx->d_work) hipFree(ctx->d_work);
+  if (ctx->panel_stream) hipStreamDestroy(ctx->panel_stream);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return TGP_OK;
+}
+
+int tgp_ctx_sync(tgp_ctx* ctx) {
+  CTX_GUARD(ctx);
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* old) {
+  TGP_ARG_CHECK(ctx != nullptr && key != nullptr, "null argument");
+  int64_t* slot = nullptr;
+  if (!strcmp(key, "nb_outer")) slot = &ctx->nb_outer;
+  else if (!strcmp(key, "lookahead")) slot = &ctx->lookahead;
+  else if (!strcmp(key, "profile")) slot = &ctx->profile;
+  TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
+  if (slot == &ctx->nb_outer)
+    TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);
+  if (old) *old = *slot;
+  *slot = value;
+  return TGP_OK;
+}
+
+int tgp_ctx_device_info(tgp_ctx* ctx, char* name, int name_len, int32_t* cus, int64_t* mem_bytes,
+                        int32_t* clock_khz) {
+  CTX_GUARD(ctx);
+  hipDeviceProp_t prop;
+  TGP_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+  if (name && name_len > 0) {
+    snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (cus) *cus = prop.multiProcessorCount;
+  if (mem_bytes) *mem_bytes = (int64_t)prop.totalGlobalMem;
+  if (clock_khz) *clock_khz = prop.clockRate;
+  return TGP_OK;
+}
+
+int tgp_malloc(tgp_ctx* ctx, size_t bytes, void** dev) {
+  CTX_GUARD(ctx);
+  TGP_ARG_CHECK(dev != nullptr, "null output pointer");
+  TGP_HIP_TRY(hipMalloc(dev, bytes ? bytes : 8));
+  return TGP_OK;
+}
+int tgp_free(tgp_ctx* ctx, void* dev) {
+  CTX_GUARD(ctx);
+  if (dev) {
+    TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    TGP_HIP_TRY(hipFree(dev));
+  }
+  return TGP_OK;
+}
+int tgp_memcpy_h2d(tgp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  CTX_GUARD(ctx);
+  TGP_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+int tgp_memcpy_d2h(tgp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  CTX_GUARD(ctx);
+  TGP_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+int tgp_memset(tgp_ctx* ctx, void* dst, int byte, size_t bytes) {
+  CTX_GUARD(ctx);
+  TGP_HIP_TRY(hipMemsetAsync(dst, byte, bytes, ctx->stream));
+  return TGP_OK;
+}
+
+// ---- device-pointer kernels ----------------------------------------------------------
+int tgp_kmat(tgp_ctx* ctx, int dtype, const tgp_kop* prog, int nops, int64_t n1, int64_t n2,
+             int32_t d, const void* X1, const void* X2, const void* diag, void* out, int64_t ld,
+             int64_t rows_out, int64_t cols_out, int lower_only) {
+  CTX_GUARD(ctx);
+  KProg kp;
+  TGP_TRY(make_kprog(prog, nops, &kp));
+  TGP_ARG_CHECK(n1 >= 0 && n2 >= 0 && X1 && X2 && out, "kmat: null or negative argument");
+  return dispatch(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int flags = (lower_only ? KMAT_LOWER : 0) | KMAT_PAD_IDENTITY;
+    return launch_kmat<T>(ctx, kp, n1, n2, d, (const T*)X1, (const T*)X2, (const T*)diag, (T*)out,
+                          ld, rows_out, cols_out, flags);
+  });
+}
+
+int tgp_kdiag(tgp_ctx* ctx, int dtype, const tgp_kop* prog, int nops, int64_t n, int32_t d,
+              const void* X, void* out) {
+  CTX_GUARD(ctx);
+  KProg kp;
+  TGP_TRY(make_kprog(prog, nops, &kp));
+  return dispatch(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_kdiag<T>(ctx, kp, n, d, (const T*)X, (const T*)nullptr, (T*)out);
+  });
+}
+
+int tgp_kmat_gemv(tgp_ctx* ctx, int dtype, const tgp_kop* prog, int nops, int64_t n1, int64_t n2,
+                  int32_t d, const void* X1, const void* X2, const void* v, void* out) {
+  CTX_GUARD(ctx);
+  KProg kp;
+  TGP_TRY(make_kprog(prog, nops, &kp));
+  return dispatch(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_kmat_gemv<T>(ctx, kp, n1, n2, d, (const T*)X1, (const T*)X2, (const T*)v, (T*)out);
+  });
+}
+
+int tgp_potrf(tgp_ctx* ctx, int dtype, int64_t n, void* A, int64_t ld, int32_t* info) {
+  CTX_GUARD(ctx);
+  TGP_ARG_CHECK(A != nullptr && n >= 0, "potrf: null matrix");
+  TGP_TRY(ensure_dinv(ctx, size_t(n / TILE + 1) * 2048 * esize(dtype)));
+  return dispatch(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return potrf<T>(ctx, n, (T*)A, ld, (T*)ctx->d_dinv, info);
+  });
+}
+
+int tgp_trsv(tgp_ctx* ctx, int dtype, int64_t n, const void* L, int64_t ld, int transpose, void* y) {
+  CTX_GUARD(ctx);
+  TGP_TRY(ensure_dinv(ctx, size_t(n / TILE + 1) * 2048 * esize(dtype)));
+  return dispatch(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    TGP_TRY(compute_dinv<T>(ctx, n, (const T*)L, ld, (T*)ctx->d_dinv));
+    return trsv<T>(ctx, n, (const T*)L, ld, (const T*)ctx->d_dinv, transpose, (T*)y);
+  });
+}
+
+int tgp_trsm_right_lt(tgp_ctx* ctx, int dtype, int64_t m, int64_t n, const void* L, int64_t ldl,
+                      void* B, int64_t ldb) {
+  CTX_GUARD(ctx);
+  TGP_TRY(ensure_dinv(ctx, size_t(n / TILE + 1) * 2048 * esize(dtype)));
+  return dispatch(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    TGP_TRY(compute_dinv<T>(ctx, n, (const T*)L, ldl, (T*)ctx->d_dinv));
+    return trsm_right_lt<T>(ctx, m, n, (const T*)L, ldl, (const T*)ctx->d_dinv, (T*)B, ldb);
+  });
+}
+
+int tgp_gemm_nt(tgp_ctx* ctx, int dtype, int64_t m, int64_t n, int64_t k, double alpha,
+                const void* A, int64_t lda, const void* B, int64_t ldb, double beta, void* C,
+                int64_t ldc, int lower) {
+  CTX_GUARD(ctx);
+  int mode;
+  if (alpha == -1.0 && beta == 1.0) mode = 0;
+  else if (alpha == 1.0 && beta == 0.0) mode = 1;
+  else {
+    set_error("gemm_nt: (alpha, beta) must be (-1, 1) or (1, 0)");
+    return TGP_E_UNSUPPORTED;
+  }
+  return dispatch(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_gemm_nt<T>(ctx, ctx->stream, m, n, k, (const T*)A, lda, (const T*)B, ldb, (T*)C,
+                             ldc, lower, mode, 1);
+  });
+}
+
+int tgp_sum_log_diag(tgp_ctx* ctx, int dtype, int64_t n, const void* L, int64_t ld, double* out) {
+  CTX_GUARD(ctx);
+  TGP_TRY(dispatch(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_sum_log_diag<T>(ctx, n, (const T*)L, ld, 0);
+  }));
+  TGP_HIP_TRY(hipMemcpyAsync(out, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_sum_squares(tgp_ctx* ctx, int dtype, int64_t n, const void* y, double* out) {
+  CTX_GUARD(ctx);
+  TGP_TRY(dispatch(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_sum_squares<T>(ctx, n, (const T*)y, 0);
+  }));
+  TGP_HIP_TRY(hipMemcpyAsync(out, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops_out) {
+  CTX_GUARD(ctx);
+  TGP_ARG_CHECK(tflops_out != nullptr && (dtype == TGP_F32 || dtype == TGP_F64), "bad argument");
+  return ubench_mfma(ctx, dtype, tflops_out);
+}
+
+// ---- solver handle ----------------------------------------------------------------------
+static int solver_scratch(tgp_solver* s, size_t bytes) {
+  return tgp::grow(&s->scratch, &s->scratch_bytes, bytes);
+}
+
+int tgp_solver_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X_host,
+                      const void* noise_diag_host, tgp_solver** out) {
+  CTX_GUARD(ctx);
+  TGP_ARG_CHECK(out != nullptr, "null output pointer");
+  TGP_ARG_CHECK(dtype == TGP_F32 || dtype == TGP_F64, "dtype must be TGP_F32 or TGP_F64");
+  TGP_ARG_CHECK(n >= 1, "need at least one data point (n = %lld)", (long long)n);
+  TGP_ARG_CHECK(d >= 1 && d <= TGP_MAX_DIM, "input dimension must be 1..%d (got %d)", TGP_MAX_DIM, d);
+  TGP_ARG_CHECK(X_host != nullptr && noise_diag_host != nullptr, "null input array");
+  tgp_solver* s = new tgp_solver();
+  s->ctx = ctx;
+  s->dtype = dtype;
+  s->n = n;
+  s->npad = round_up(n, TILE);
+  s->d = d;
+  const size_t es = esize(dtype);
+  auto fail = [&](int code) { tgp_solver_destroy(s); return code; };
+#define S_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    set_error("%s failed: %s", #expr, hipGetErrorString(_e));            \
+    return fail(_e == hipErrorOutOfMemory ? TGP_E_NOMEM : TGP_E_HIP); } } while (0)
+  S_TRY(hipMalloc(&s->X, size_t(n) * d * es));
+  S_TRY(hipMalloc(&s->diag, size_t(n) * es));
+  S_TRY(hipMalloc(&s->A, size_t(s->npad) * s->npad * es));
+  S_TRY(hipMalloc(&s->dinv, size_t(s->npad / TILE) * 2048 * es));
+  S_TRY(hipMalloc(&s->vec, size_t(s->npad) * es));
+  S_TRY(hipMalloc(&s->vec2, size_t(s->npad) * es));
+  S_TRY(hipMalloc(&s->resid, size_t(s->npad) * es));
+  S_TRY(hipMemcpyAsync(s->X, X_host, size_t(n) * d * es, hipMemcpyHostToDevice, ctx->stream));
+  S_TRY(hipMemcpyAsync(s->diag, noise_diag_host, size_t(n) * es, hipMemcpyHostToDevice, ctx->stream));
+  S_TRY(hipMemsetAsync(s->vec, 0, size_t(s->npad) * es, ctx->stream));
+  S_TRY(hipMemsetAsync(s->vec2, 0, size_t(s->npad) * es, ctx->stream));
+  S_TRY(hipMemsetAsync(s->resid, 0, size_t(s->npad) * es, ctx->stream));
+  S_TRY(hipStreamSynchronize(ctx->stream));
+#undef S_TRY
+  *out = s;
+  return TGP_OK;
+}
+
+int tgp_solver_destroy(tgp_solver* s) {
+  if (!s) return TGP_OK;
+  if (s->ctx) {
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+  }
+  void* bufs[] = {s->X, s->diag, s->A, s->dinv, s->vec, s->vec2, s->resid, s->scratch};
+  for (void* b : bufs)
+    if (b) hipFree(b);
+  delete s;
+  return TGP_OK;
+}
+
+int tgp_solver_set_noise(tgp_solver* s, const void* noise_diag_host) {
+  SOLVER_GUARD(s);
+  TGP_ARG_CHECK(noise_diag_host != nullptr, "null input array");
+  TGP_HIP_TRY(hipMemcpyAsync(s->diag, noise_diag_host, size_t(s->n) * esize(s->dtype),
+                             hipMemcpyHostToDevice, s->ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_solver_factor(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
+                      int32_t* info) {
+  SOLVER_GUARD(s);
+  tgp_ctx* ctx = s->ctx;
+  if (nops > 0) {
+    TGP_TRY(make_kprog(prog, nops, &s->kp));
+    s->has_prog = true;
+  } else {
+    s->has_prog = false;
+  }
+  TGP_ARG_CHECK(s->has_prog || cov_host != nullptr, "factor needs a kernel program or a covariance");
+  const size_t es = esize(s->dtype);
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  const bool prof = ctx->profile != 0;
+  if (prof) {
+    TGP_HIP_TRY(hipEventCreate(&e0));
+    TGP_HIP_TRY(hipEventCreate(&e1));
+    TGP_HIP_TRY(hipEventCreate(&e2));
+    TGP_HIP_TRY(hipEventRecord(e0, ctx->stream));
+  }
+  int status = dispatch(s->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    T* A = (T*)s->A;
+    if (cov_host != nullptr) {
+      TGP_TRY(solver_scratch(s, size_t(s->n) * s->n * es));
+      TGP_HIP_TRY(hipMemcpyAsync(s->scratch, cov_host, size_t(s->n) * s->n * es,
+                                 hipMemcpyHostToDevice, ctx->stream));
+      TGP_TRY(launch_set_lower_from_rowmajor<T>(ctx, s->n, s->npad, (const T*)s->scratch, A, s->npad));
+    } else {
+      TGP_TRY(launch_kmat<T>(ctx, s->kp, s->n, s->n, s->d, (const T*)s->X, (const T*)s->X,
+                             (const T*)s->diag, A, s->npad, s->npad, s->npad,
+                             KMAT_LOWER | KMAT_PAD_IDENTITY));
+    }
+    if (prof) TGP_HIP_TRY(hipEventRecord(e1, ctx->stream));
+    int32_t inf = 0;
+    int st = potrf<T>(ctx, s->npad, A, s->npad, (T*)s->dinv, &inf);
+    if (st < 0) return st;
+    s->info = inf;
+    if (prof) TGP_HIP_TRY(hipEventRecord(e2, ctx->stream));
+    TGP_TRY(launch_sum_log_diag<T>(ctx, s->n, A, s->npad, 1));
+    return TGP_OK;
+  });
+  if (status < 0) return status;
+  TGP_HIP_TRY(hipMemcpyAsync(&s->logdet_half, ctx->d_scal + 1, sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (prof) {
+    float a = 0, b = 0;
+    TGP_HIP_TRY(hipEventElapsedTime(&a, e0, e1));
+    TGP_HIP_TRY(hipEventElapsedTime(&b, e1, e2));
+    s->ms[0] = a;
+    s->ms[1] = b;
+    s->ms[2] = ctx->prof_syrk_ms;
+    s->ms[3] = (double)ctx->prof_syrk_launches;
+    s->ms[6] = ctx->prof_syrk_flops;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipEventDestroy(e2);
+  }
+  s->factored = true;
+  if (info) *info = s->info;
+  return s->info > 0 ? s->info : TGP_OK;
+}
+
+#define NEED_FACTOR(s) TGP_ARG_CHECK((s)->factored, "solver has not been factored yet")
+
+int tgp_solver_normalization(tgp_solver* s, double* out) {
+  SOLVER_GUARD(s);
+  NEED_FACTOR(s);
+  TGP_ARG_CHECK(out != nullptr, "null output pointer");
+  *out = s->logdet_half + 0.5 * double(s->n) * std::log(2.0 * M_PI);
+  return TGP_OK;
+}
+
+// upload a host vector (n,) into a zero-padded device vector
+static int upload_vec(tgp_solver* s, void* dst, const void* src_host) {
+  const size_t es = esize(s->dtype);
+  TGP_HIP_TRY(hipMemcpyAsync(dst, src_host, size_t(s->n) * es, hipMemcpyHostToDevice, s->ctx->stream));
+  if (s->npad > s->n)
+    TGP_HIP_TRY(hipMemsetAsync((char*)dst + size_t(s->n) * es, 0, size_t(s->npad - s->n) * es,
+                               s->ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_solver_solve_tri(tgp_solver* s, int transpose, int64_t nrhs, const void* y_host,
+                         void* x_host) {
+  SOLVER_GUARD(s);
+  NEED_FACTOR(s);
+  TGP_ARG_CHECK(nrhs >= 1 && y_host && x_host, "solve_tri: bad argument");
+  tgp_ctx* ctx = s->ctx;
+  const size_t es = esize(s->dtype);
+  return dispatch(s->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const T* L = (const T*)s->A;
+    if (nrhs == 1) {
+      TGP_TRY(upload_vec(s, s->vec, y_host));
+      TGP_TRY(trsv<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, transpose, (T*)s->vec));
+      TGP_HIP_TRY(hipMemcpyAsync(x_host, s->vec, size_t(s->n) * es, hipMemcpyDeviceToHost, ctx->stream));
+      TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+      return TGP_OK;
+    }
+    if (!transpose) {
+      // host (n, nrhs) row-major == column-major (nrhs x n): the transposed form B L^-T
+      const int64_t mpad = round_up(nrhs, TILE);
+      TGP_TRY(solver_scratch(s, size_t(mpad) * s->npad * es));
+      TGP_HIP_TRY(hipMemsetAsync(s->scratch, 0, size_t(mpad) * s->npad * es, ctx->stream));
+      TGP_HIP_TRY(hipMemcpy2DAsync(s->scratch, size_t(mpad) * es, y_host, size_t(nrhs) * es,
+                                   size_t(nrhs) * es, size_t(s->n), hipMemcpyHostToDevice, ctx->stream));
+      TGP_TRY(trsm_right_lt<T>(ctx, mpad, s->npad, L, s->npad, (const T*)s->dinv, (T*)s->scratch, mpad));
+      TGP_HIP_TRY(hipMemcpy2DAsync(x_host, size_t(nrhs) * es, s->scratch, size_t(mpad) * es,
+                                   size_t(nrhs) * es, size_t(s->n), hipMemcpyDeviceToHost, ctx->stream));
+      TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+      return TGP_OK;
+    }
+    // L^T X = Y with several right-hand sides: one backward sweep per column
+    for (int64_t r = 0; r < nrhs; ++r) {
+      TGP_HIP_TRY(hipMemsetAsync(s->vec, 0, size_t(s->npad) * es, ctx->stream));
+      TGP_HIP_TRY(hipMemcpy2DAsync(s->vec, es, (const char*)y_host + r * es, size_t(nrhs) * es, es,
+                                   size_t(s->n), hipMemcpyHostToDevice, ctx->stream));
+      TGP_TRY(trsv<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, 1, (T*)s->vec));
+      TGP_HIP_TRY(hipMemcpy2DAsync((char*)x_host + r * es, size_t(nrhs) * es, s->vec, es, es,
+                                   size_t(s->n), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return TGP_OK;
+  });
+}
+
+int tgp_solver_dot_tri(tgp_solver* s, int64_t nrhs, const void* y_host, void* out_host) {
+  SOLVER_GUARD(s);
+  NEED_FACTOR(s);
+  TGP_ARG_CHECK(nrhs >= 1 && y_host && out_host, "dot_tri: bad argument");
+  tgp_ctx* ctx = s->ctx;
+  const size_t es = esize(s->dtype);
+  return dispatch(s->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    for (int64_t r = 0; r < nrhs; ++r) {
+      TGP_HIP_TRY(hipMemcpy2DAsync(s->vec, es, (const char*)y_host + r * es, size_t(nrhs) * es, es,
+                                   size_t(s->n), hipMemcpyHostToDevice, ctx->stream));
+      TGP_TRY(launch_trmv_lower<T>(ctx, s->n, (const T*)s->A, s->npad, (const T*)s->vec, (T*)s->vec2));
+      TGP_HIP_TRY(hipMemcpy2DAsync((char*)out_host + r * es, size_t(nrhs) * es, s->vec2, es, es,
+                                   size_t(s->n), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return TGP_OK;
+  });
+}
+
+int tgp_solver_set_resid(tgp_solver* s, const void* resid_host) {
+  SOLVER_GUARD(s);
+  TGP_ARG_CHECK(resid_host != nullptr, "null input array");
+  TGP_TRY(upload_vec(s, s->resid, resid_host));
+  TGP_HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+  s->has_resid = true;
+  return TGP_OK;
+}
+
+// alpha = L^-1 resid into s->vec; returns -0.5 |alpha|^2 - normalization
+static int logprob_device(tgp_solver* s, const void* resid_host, double* out) {
+  tgp_ctx* ctx = s->ctx;
+  const size_t es = esize(s->dtype);
+  if (resid_host) {
+    TGP_TRY(upload_vec(s, s->vec, resid_host));
+  } else {
+    TGP_ARG_CHECK(s->has_resid, "no resident residual: call tgp_solver_set_resid first");
+    TGP_HIP_TRY(hipMemcpyAsync(s->vec, s->resid, size_t(s->npad) * es, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool prof = ctx->profile != 0;
+  if (prof) {
+    TGP_HIP_TRY(hipEventCreate(&e0));
+    TGP_HIP_TRY(hipEventCreate(&e1));
+    TGP_HIP_TRY(hipEventRecord(e0, ctx->stream));
+  }
+  TGP_TRY(dispatch(s->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    TGP_TRY(trsv<T>(ctx, s->npad, (const T*)s->A, s->npad, (const T*)s->dinv, 0, (T*)s->vec));
+    return launch_sum_squares<T>(ctx, s->n, (const T*)s->vec, 0);
+  }));
+  if (prof) TGP_HIP_TRY(hipEventRecord(e1, ctx->stream));
+  double ss = 0;
+  TGP_HIP_TRY(hipMemcpyAsync(&ss, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (prof) {
+    float t = 0;
+    TGP_HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    s->ms[4] = t;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+  }
+  *out = -0.5 * ss - (s->logdet_half + 0.5 * double(s->n) * std::log(2.0 * M_PI));
+  return TGP_OK;
+}
+
+int tgp_solver_logprob(tgp_solver* s, const void* resid_host, double* out) {
+  SOLVER_GUARD(s);
+  NEED_FACTOR(s);
+  TGP_ARG_CHECK(out != nullptr, "null output pointer");
+  return logprob_device(s, resid_host, out);
+}
+
+int tgp_solver_alpha(tgp_solver* s, const void* resid_host, void* alpha_host, double* logprob) {
+  SOLVER_GUARD(s);
+  NEED_FACTOR(s);
+  TGP_ARG_CHECK(alpha_host != nullptr && logprob != nullptr, "null output pointer");
+  TGP_TRY(logprob_device(s, resid_host, logprob));
+  tgp_ctx* ctx = s->ctx;
+  TGP_TRY(dispatch(s->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return trsv<T>(ctx, s->npad, (const T*)s->A, s->npad, (const T*)s->dinv, 1, (T*)s->vec);
+  }));
+  TGP_HIP_TRY(hipMemcpyAsync(alpha_host, s->vec, size_t(s->n) * esize(s->dtype),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_solver_cond_mean(tgp_solver* s, const tgp_kop* prog, int nops, int64_t m,
+                         const void* Xt_host, const void* alpha_host, void* mean_host) {
+  SOLVER_GUARD(s);
+  TGP_ARG_CHECK(m >= 1 && Xt_host && alpha_host && mean_host, "cond_mean: bad argument");
+  KProg kp;
+  TGP_TRY(make_kprog(prog, nops, &kp));
+  tgp_ctx* ctx = s->ctx;
+  const size_t es = esize(s->dtype);
+  const size_t xt_bytes = round_up(size_t(m) * s->d * es, 256), out_bytes = round_up(size_t(m) * es, 256);
+  TGP_TRY(solver_scratch(s, xt_bytes + out_bytes));
+  char* xt = (char*)s->scratch;
+  char* outv = xt + xt_bytes;
+  TGP_HIP_TRY(hipMemcpyAsync(xt, Xt_host, size_t(m) * s->d * es, hipMemcpyHostToDevice, ctx->stream));
+  TGP_TRY(upload_vec(s, s->vec2, alpha_host));
+  TGP_TRY(dispatch(s->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_kmat_gemv<T>(ctx, kp, m, s->n, s->d, (const T*)xt, (const T*)s->X,
+                               (const T*)s->vec2, (T*)outv);
+  }));
+  TGP_HIP_TRY(hipMemcpyAsync(mean_host, outv, size_t(m) * es, hipMemcpyDeviceToHost, ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_solver_condition_cov(tgp_solver* s, const tgp_kop* prog, int nops, int64_t m,
+                             const void* Xt_host, const void* noise_t_host, int var_only,
+                             void* out_host) {
+  SOLVER_GUARD(s);
+  NEED_FACTOR(s);
+  TGP_ARG_CHECK(out_host != nullptr, "null output pointer");
+  if (!Xt_host) m = s->n;
+  TGP_ARG_CHECK(m >= 1, "condition: need at least one test point");
+  KProg kp;
+  TGP_TRY(make_kprog(prog, nops, &kp));
+  tgp_ctx* ctx = s->ctx;
+  const size_t es = esize(s->dtype);
+  const int64_t mpad = round_up(m, TILE);
+  // scratch layout: [Bp mpad x npad][Kss mpad x mpad | base,outv][Xt][noise]
+  const size_t b_bytes = size_t(mpad) * s->npad * es;
+  const size_t k_bytes = var_only ? 2 * size_t(mpad) * es : size_t(mpad) * mpad * es;
+  const size_t xt_bytes = round_up(size_t(m) * s->d * es, 256);
+  const size_t nz_bytes = round_up(size_t(mpad) * es, 256);
+  TGP_TRY(solver_scratch(s, b_bytes + round_up(k_bytes, 256) + xt_bytes + nz_bytes));
+  char* Bp = (char*)s->scratch;
+  char* Kss = Bp + b_bytes;
+  char* xt = Kss + round_up(k_bytes, 256);
+  char* nz = xt + xt_bytes;
+  const void* Xt = s->X;
+  if (Xt_host) {
+    TGP_HIP_TRY(hipMemcpyAsync(xt, Xt_host, size_t(m) * s->d * es, hipMemcpyHostToDevice, ctx->stream));
+    Xt = xt;
+  }
+  const void* nzp = nullptr;
+  if (noise_t_host) {
+    TGP_HIP_TRY(hipMemcpyAsync(nz, noise_t_host, size_t(m) * es, hipMemcpyHostToDevice, ctx->stream));
+    nzp = nz;
+  }
+  TGP_TRY(dispatch(s->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    // Bp[i, j] = k(Xt[i], X[j]) = Ks^T (direct.py:87-91), zero padding
+    TGP_TRY(launch_kmat<T>(ctx, kp, m, s->n, s->d, (const T*)Xt, (const T*)s->X, (const T*)nullptr,
+                           (T*)Bp, mpad, mpad, s->npad, 0));
+    // rows of Bp <- (L^-1 k(X, x_t))^T  (A = L^-1 Ks, direct.py:94)
+    TGP_TRY(trsm_right_lt<T>(ctx, mpad, s->npad, (const T*)s->A, s->npad, (const T*)s->dinv, (T*)Bp, mpad));
+    if (var_only) {
+      T* base = (T*)Kss;
+      T* outv = base + mpad;
+      TGP_TRY(launch_kdiag<T>(ctx, kp, m, s->d, (const T*)Xt, (const T*)nzp, base));
+      TGP_TRY(launch_row_sumsq<T>(ctx, m, s->npad, (const T*)Bp, mpad, base, outv));
+      TGP_HIP_TRY(hipMemcpyAsync(out_host, outv, size_t(m) * es, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+      // Kss + noise - A^T A (direct.py:92,95): SYRK-shaped MFMA GEMM, K = n
+      TGP_TRY(launch_kmat<T>(ctx, kp, m, m, s->d, (const T*)Xt, (const T*)Xt, (const T*)nzp,
+                             (T*)Kss, mpad, mpad, mpad, 0));
+      TGP_TRY(launch_gemm_nt<T>(ctx, ctx->stream, mpad, mpad, s->npad, (const T*)Bp, mpad,
+                                (const T*)Bp, mpad, (T*)Kss, mpad, 0, 0, 1));
+      TGP_HIP_TRY(hipMemcpy2DAsync(out_host, size_t(m) * es, Kss, size_t(mpad) * es, size_t(m) * es,
+                                   size_t(m), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return TGP_OK;
+  }));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_solver_covariance(tgp_solver* s, void* out_host) {
+  SOLVER_GUARD(s);
+  TGP_ARG_CHECK(s->has_prog, "covariance needs a kernel program");
+  TGP_ARG_CHECK(out_host != nullptr, "null output pointer");
+  tgp_ctx* ctx = s->ctx;
+  const size_t es = esize(s->dtype);
+  TGP_TRY(solver_scratch(s, size_t(s->n) * s->n * es));
+  TGP_TRY(dispatch(s->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_kmat<T>(ctx, s->kp, s->n, s->n, s->d, (const T*)s->X, (const T*)s->X,
+                          (const T*)s->diag, (T*)s->scratch, s->n, s->n, s->n, 0);
+  }));
+  TGP_HIP_TRY(hipMemcpyAsync(out_host, s->scratch, size_t(s->n) * s->n * es, hipMemcpyDeviceToHost,
+                             ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_solver_variance(tgp_solver* s, void* out_host) {
+  SOLVER_GUARD(s);
+  TGP_ARG_CHECK(s->has_prog, "variance needs a kernel program");
+  TGP_ARG_CHECK(out_host != nullptr, "null output pointer");
+  tgp_ctx* ctx = s->ctx;
+  TGP_TRY(dispatch(s->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_kdiag<T>(ctx, s->kp, s->n, s->d, (const T*)s->X, (const T*)s->diag, (T*)s->vec2);
+  }));
+  TGP_HIP_TRY(hipMemcpyAsync(out_host, s->vec2, size_t(s->n) * esize(s->dtype),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_solver_get_factor(tgp_solver* s, void* L_host) {
+  SOLVER_GUARD(s);
+  NEED_FACTOR(s);
+  TGP_ARG_CHECK(L_host != nullptr, "null output pointer");
+  tgp_ctx* ctx = s->ctx;
+  const size_t es = esize(s->dtype);
+  TGP_TRY(solver_scratch(s, size_t(s->n) * s->n * es));
+  TGP_TRY(dispatch(s->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_extract_lower_rowmajor<T>(ctx, s->n, (const T*)s->A, s->npad, (T*)s->scratch);
+  }));
+  TGP_HIP_TRY(hipMemcpyAsync(L_host, s->scratch, size_t(s->n) * s->n * es, hipMemcpyDeviceToHost,
+                             ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_solver_device_factor(tgp_solver* s, void** L_dev, int64_t* n_pad) {
+  SOLVER_GUARD(s);
+  if (L_dev) *L_dev = s->A;
+  if (n_pad) *n_pad = s->npad;
+  return TGP_OK;
+}
+
+int tgp_solver_timings(tgp_solver* s, double* ms, int n) {
+  SOLVER_GUARD(s);
+  TGP_ARG_CHECK(ms != nullptr && n >= 0, "bad argument");
+  for (int i = 0; i < n && i < 8; ++i) ms[i] = s->ms[i];
+  return TGP_OK;
+}
+
+}  // extern "C"

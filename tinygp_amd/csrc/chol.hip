@@ -1,0 +1,542 @@
+// chol.hip -- right-looking blocked LL^T (K4), blocked triangular solves (K5/K6).
+//
+// Replaces jax.scipy.linalg.cholesky / solve_triangular at reference
+// solvers/direct.py:53,66-70.  Column-major, in place, lower triangle only.
+//
+//   outer block NB (default 512):  panel = [potf2 128 | trsm | in-panel update] x NB/128
+//                                  trailing update = gemm_nt (fp64 MFMA), K = NB
+//   look-ahead: the next panel's block column is updated first, then factored on a
+//   high-priority side stream while the main stream updates the rest of the matrix.
+//
+// potf2   one workgroup factors a 128x128 diagonal block held in registers (8x8 per
+//         thread, 2-D cyclic) and emits the inverses of its eight 16x16 diagonal
+//         sub-blocks ("dinv"), which turn every later triangular solve into MFMAs.
+// trsm    X L^T = B for a 128-column panel: one wave per 16 rows, transposed recurrence
+//         Y_j = inv(L_jj) (B_j^T - sum_{k<j} L_jk Y_k) so that an MFMA result (D layout)
+//         is directly the next MFMA's B operand -- no LDS, no shuffles.
+#include "tgp_common.h"
+
+namespace tgp {
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+  using acc_t = d4;
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int drow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct Mfma<float> {
+  using acc_t = f4;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int drow(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+// ---------------------------------------------------------------------------------------
+// potf2: 128x128 diagonal block, one workgroup of 256 threads.
+// thread (tr = tid & 15, tc = tid >> 4) owns A[tr + 16 a][tc + 16 b], a, b in 0..7.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 1) void potf2_kernel(T* __restrict__ A, int64_t ld,
+                                                       T* __restrict__ dinv,
+                                                       int32_t* __restrict__ info,
+                                                       int32_t pivot_base) {
+  __shared__ T colbuf[2][128];
+  __shared__ T sD[8][16][16];  // sD[bb][c][i] = element (i, c) of diagonal sub-block bb
+  const int tid = threadIdx.x, tr = tid & 15, tc = tid >> 4;
+  T a[8][8];
+#pragma unroll
+  for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) a[ai][bi] = A[int64_t(tc + 16 * bi) * ld + tr + 16 * ai];
+
+  int p = 0;
+  for (int j = 0; j < 128; ++j) {
+    const int bj = j >> 4, cj = j & 15;
+    if (tc == cj) {
+#pragma unroll
+      for (int bi = 0; bi < 8; ++bi)
+        if (bi == bj) {
+#pragma unroll
+          for (int ai = 0; ai < 8; ++ai) colbuf[p][tr + 16 * ai] = a[ai][bi];
+        }
+    }
+    __syncthreads();
+    const T d = colbuf[p][j];
+    if (tid == 0 && !(d > T(0))) atomicCAS(info, 0, pivot_base + j + 1);
+    const T dj = sqrt(d);
+    const T r = T(1) / dj;
+    T lr[8], lc[8];
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) lr[ai] = colbuf[p][tr + 16 * ai] * r;
+#pragma unroll
+    for (int bi = 0; bi < 8; ++bi) {
+      const int c = tc + 16 * bi;
+      lc[bi] = (c > j) ? colbuf[p][c] * r : T(0);
+    }
+#pragma unroll
+    for (int bi = 0; bi < 8; ++bi) {
+      if (16 * bi + 15 > j) {  // uniform: skip finished block columns
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai) a[ai][bi] -= lr[ai] * lc[bi];
+      }
+    }
+    if (tc == cj) {
+#pragma unroll
+      for (int bi = 0; bi < 8; ++bi)
+        if (bi == bj) {
+#pragma unroll
+          for (int ai = 0; ai < 8; ++ai) {
+            const int i = tr + 16 * ai;
+            if (i > j) a[ai][bi] = lr[ai];
+            else if (i == j) a[ai][bi] = dj;
+          }
+        }
+    }
+    p ^= 1;
+  }
+
+  // write L (zeros above the diagonal: diagonal tiles of the factor are clean)
+#pragma unroll
+  for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) {
+      const int i = tr + 16 * ai, c = tc + 16 * bi;
+      A[int64_t(c) * ld + i] = (i >= c) ? a[ai][bi] : T(0);
+    }
+  // inverses of the eight 16x16 diagonal sub-blocks
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb) sD[bb][tc][tr] = (tr >= tc) ? a[bb][bb] : T(0);
+  __syncthreads();
+  if (tid < 128) {
+    const int bb = tid >> 4, c = tid & 15;
+    T x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      T s = (i == c) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < i; ++k) s -= sD[bb][k][i] * x[k];
+      x[i] = s / sD[bb][i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dinv[bb * 256 + c * 16 + i] = x[i];
+  }
+}
+
+// dinv for an existing factor: one thread per (16-block, column)
+template <typename T>
+__global__ __launch_bounds__(256) void dinv_kernel(int64_t n, const T* __restrict__ L, int64_t ld,
+                                                   T* __restrict__ dinv) {
+  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t blk = t >> 4;
+  const int c = int(t & 15);
+  if (blk * 16 >= n) return;
+  const T* D = L + blk * 16 * ld + blk * 16;
+  T x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    T s = (i == c) ? T(1) : T(0);
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= D[int64_t(k) * ld + i] * x[k];
+    x[i] = s / D[int64_t(i) * ld + i];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dinv[blk * 256 + c * 16 + i] = x[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// trsm: B (m x 128) <- B L^-T, L a 128x128 lower block with its dinv.  Wave per 16 rows.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void trsm_kernel(int64_t m, const T* __restrict__ L, int64_t ldl,
+                                                   const T* __restrict__ dinv, T* __restrict__ B,
+                                                   int64_t ldb) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  const int lane = threadIdx.x & 63;
+  const int64_t r0 = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16;
+  if (r0 >= m) return;
+  const int lrow = lane & 15;
+  acc_t Z[8];
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    acc_t acc;
+    T* bp = B + r0 + lrow + int64_t(jb * 16) * ldb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = bp[int64_t(M::drow(lane, r)) * ldb];
+#pragma unroll
+    for (int kb = 0; kb < jb; ++kb) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const T a = L[int64_t(kb * 16 + M::drow(lane, s)) * ldl + jb * 16 + lrow];
+        acc = M::mma(a, Z[kb][s], acc);
+      }
+    }
+    acc_t y = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const T a = dinv[jb * 256 + M::drow(lane, s) * 16 + lrow];
+      y = M::mma(a, acc[s], y);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bp[int64_t(M::drow(lane, r)) * ldb] = y[r];
+    Z[jb] = -y;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// trsv (single right-hand side): per 128-block, one diagonal solve + one panel update.
+// ---------------------------------------------------------------------------------------
+// forward: y_kb <- L_kk^-1 y_kb.  128 threads, thread r owns row r.
+template <typename T>
+__global__ __launch_bounds__(128, 1) void trsv_diag_fwd_kernel(const T* __restrict__ Lkk,
+                                                               int64_t ld,
+                                                               const T* __restrict__ dinv,
+                                                               T* __restrict__ y) {
+  __shared__ T st[128];
+  __shared__ T sx[16];
+  const int r = threadIdx.x, rb = r >> 4, rl = r & 15;
+  T Lr[7][16];
+#pragma unroll
+  for (int jb = 0; jb < 7; ++jb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Lr[jb][q] = (rb > jb) ? Lkk[int64_t(jb * 16 + q) * ld + r] : T(0);
+  T di[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) di[q] = dinv[rb * 256 + q * 16 + rl];
+  T t = y[r];
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    st[r] = t;
+    __syncthreads();
+    if (rb == jb) {
+      T x = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x += di[q] * st[jb * 16 + q];
+      sx[rl] = x;
+      t = x;
+    }
+    __syncthreads();
+    if (jb < 7) {
+      if (rb > jb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t -= Lr[jb][q] * sx[q];
+      }
+    }
+  }
+  y[r] = t;
+}
+
+// backward: y_kb <- L_kk^-T y_kb.  thread c owns column c.
+template <typename T>
+__global__ __launch_bounds__(128, 1) void trsv_diag_bwd_kernel(const T* __restrict__ Lkk,
+                                                               int64_t ld,
+                                                               const T* __restrict__ dinv,
+                                                               T* __restrict__ y) {
+  __shared__ T st[128];
+  __shared__ T sx[16];
+  const int c = threadIdx.x, cb = c >> 4, cl = c & 15;
+  T Lc[7][16];  // Lc[jb-1][q] = L[jb*16+q][c] for jb = 1..7
+#pragma unroll
+  for (int jb = 1; jb < 8; ++jb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Lc[jb - 1][q] = (cb < jb) ? Lkk[int64_t(c) * ld + jb * 16 + q] : T(0);
+  T di[16];  // row cl of dinv_cb^T = column cl of dinv_cb: element (q, cl) at cl*16 + q
+#pragma unroll
+  for (int q = 0; q < 16; ++q) di[q] = dinv[cb * 256 + cl * 16 + q];
+  T t = y[c];
+#pragma unroll
+  for (int jb = 7; jb >= 0; --jb) {
+    st[c] = t;
+    __syncthreads();
+    if (cb == jb) {
+      T x = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x += di[q] * st[jb * 16 + q];
+      sx[cl] = x;
+      t = x;
+    }
+    __syncthreads();
+    if (jb > 0) {
+      if (cb < jb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t -= Lc[jb - 1][q] * sx[q];
+      }
+    }
+  }
+  y[c] = t;
+}
+
+// forward update: y[r] -= sum_{c<128} P[r, c] x[c], P = L[rows below, block cols]. thread per row.
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_update_fwd_kernel(int64_t m, const T* __restrict__ P,
+                                                              int64_t ld, const T* __restrict__ x,
+                                                              T* __restrict__ y) {
+  __shared__ T sx[128];
+  if (threadIdx.x < 128) sx[threadIdx.x] = x[threadIdx.x];
+  __syncthreads();
+  const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (r >= m) return;
+  T acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#pragma unroll 8
+  for (int c = 0; c < 128; c += 4) {
+    acc0 += P[int64_t(c) * ld + r] * sx[c];
+    acc1 += P[int64_t(c + 1) * ld + r] * sx[c + 1];
+    acc2 += P[int64_t(c + 2) * ld + r] * sx[c + 2];
+    acc3 += P[int64_t(c + 3) * ld + r] * sx[c + 3];
+  }
+  y[r] -= (acc0 + acc1) + (acc2 + acc3);
+}
+
+// backward update: y[c] -= sum_{r<128} P[r, c] x[r] for c < ncols; P = L[block rows, cols 0..).
+// Workgroup = 32 columns; lanes run along r (coalesced), reduction through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_update_bwd_kernel(int64_t ncols,
+                                                              const T* __restrict__ P, int64_t ld,
+                                                              const T* __restrict__ x,
+                                                              T* __restrict__ y) {
+  __shared__ T sx[128];
+  __shared__ T tile[32][129];
+  if (threadIdx.x < 128) sx[threadIdx.x] = x[threadIdx.x];
+  __syncthreads();
+  const int r = threadIdx.x & 127, half = threadIdx.x >> 7;
+  const int64_t c0 = int64_t(blockIdx.x) * 32;
+#pragma unroll 4
+  for (int cc = 0; cc < 16; ++cc) {
+    const int cl = half * 16 + cc;
+    const int64_t c = c0 + cl;
+    tile[cl][r] = (c < ncols) ? P[c * ld + r] * sx[r] : T(0);
+  }
+  __syncthreads();
+  const int cl = threadIdx.x >> 3, part = threadIdx.x & 7;
+  T acc = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc += tile[cl][part * 16 + q];
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  if (part == 0 && c0 + cl < ncols) y[c0 + cl] -= acc;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+template <typename T>
+int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_t* info,
+                 int32_t pivot_base) {
+  (void)ctx;
+  hipLaunchKernelGGL((potf2_kernel<T>), dim3(1), dim3(256), 0, st, A, ld, dinv, info, pivot_base);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+template <typename T>
+int launch_trsm(tgp_ctx* ctx, hipStream_t st, int64_t m, const T* L, int64_t ldl, const T* dinv,
+                T* B, int64_t ldb) {
+  (void)ctx;
+  if (m == 0) return TGP_OK;
+  TGP_ARG_CHECK(m % 16 == 0, "trsm: m must be a multiple of 16");
+  hipLaunchKernelGGL((trsm_kernel<T>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, st, m, L,
+                     ldl, dinv, B, ldb);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+template <typename T>
+int compute_dinv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* dinv) {
+  if (n == 0) return TGP_OK;
+  hipLaunchKernelGGL((dinv_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     ctx->stream, n, L, ld, dinv);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+namespace {
+struct ProfSpan {
+  hipEvent_t e0, e1;
+  double flops;
+};
+
+int prof_event(tgp_ctx* ctx, hipEvent_t* out) {
+  if (ctx->ev_used == ctx->ev_pool.size()) {
+    hipEvent_t e;
+    TGP_HIP_TRY(hipEventCreate(&e));
+    ctx->ev_pool.push_back(e);
+  }
+  *out = ctx->ev_pool[ctx->ev_used++];
+  return TGP_OK;
+}
+}  // namespace
+
+template <typename T>
+int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host) {
+  TGP_ARG_CHECK(n % TILE == 0 && ld >= n, "potrf: n must be a multiple of %d and ld >= n", TILE);
+  if (info_host) *info_host = 0;
+  if (n == 0) return TGP_OK;
+  hipStream_t S0 = ctx->stream, S1 = ctx->panel_stream;
+  int64_t NB = ctx->nb_outer;
+  if (NB < TILE) NB = TILE;
+  NB = NB / TILE * TILE;
+  TGP_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int32_t), S0));
+  const bool prof = ctx->profile != 0;
+  std::vector<ProfSpan> spans;
+  ctx->ev_used = 0;
+
+  auto panel = [&](hipStream_t st, int64_t k0, int64_t kb) -> int {
+    for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
+      T* Ljj = A + j0 * ld + j0;
+      T* dj = dinv + (j0 / TILE) * 2048;
+      TGP_TRY(launch_potf2<T>(ctx, st, Ljj, ld, dj, ctx->d_info, (int32_t)j0));
+      const int64_t mb = n - (j0 + TILE);
+      if (mb > 0) TGP_TRY(launch_trsm<T>(ctx, st, mb, Ljj, ld, dj, Ljj + TILE, ld));
+      const int64_t nc = (k0 + kb) - (j0 + TILE);
+      if (mb > 0 && nc > 0)
+        TGP_TRY(launch_gemm_nt<T>(ctx, st, mb, nc, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
+                                  A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, 1));
+    }
+    return TGP_OK;
+  };
+  auto trailing = [&](int64_t m, int64_t nn, int64_t kb, const T* P, T* C) -> int {
+    ProfSpan sp{};
+    if (prof) {
+      TGP_TRY(prof_event(ctx, &sp.e0));
+      TGP_TRY(prof_event(ctx, &sp.e1));
+      TGP_HIP_TRY(hipEventRecord(sp.e0, S0));
+    }
+    TGP_TRY(launch_gemm_nt<T>(ctx, S0, m, nn, kb, P, ld, P, ld, C, ld, 1, 0, 0));
+    if (prof) {
+      TGP_HIP_TRY(hipEventRecord(sp.e1, S0));
+      // algorithmic flops of the lower-trapezoid update: entries (i >= j) x 2 kb
+      const double entries = double(nn) * double(m) - double(nn) * double(nn - 1) / 2.0;
+      sp.flops = 2.0 * entries * double(kb);
+      spans.push_back(sp);
+    }
+    return TGP_OK;
+  };
+
+  const bool la = ctx->lookahead != 0 && S1 != nullptr;
+  if (!la) {
+    for (int64_t k0 = 0; k0 < n; k0 += NB) {
+      const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
+      TGP_TRY(panel(S0, k0, kb));
+      const int64_t next = k0 + kb, mt = n - next;
+      if (mt > 0) TGP_TRY(trailing(mt, mt, kb, A + k0 * ld + next, A + next * ld + next));
+    }
+  } else {
+    TGP_TRY(panel(S0, 0, (n < NB) ? n : NB));
+    for (int64_t k0 = 0; k0 < n; k0 += NB) {
+      const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
+      const int64_t next = k0 + kb, mt = n - next;
+      if (mt <= 0) break;
+      const int64_t kbn = (mt < NB) ? mt : NB;
+      const T* P = A + k0 * ld + next;
+      // 1. block column of the next panel first ...
+      TGP_TRY(trailing(mt, kbn, kb, P, A + next * ld + next));
+      TGP_HIP_TRY(hipEventRecord(ctx->ev_a, S0));
+      TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
+      // 2. ... factor it on the side stream ...
+      TGP_TRY(panel(S1, next, kbn));
+      TGP_HIP_TRY(hipEventRecord(ctx->ev_b, S1));
+      // 3. ... while the main stream updates the rest
+      const int64_t m2 = mt - kbn;
+      if (m2 > 0)
+        TGP_TRY(trailing(m2, m2, kb, P + kbn, A + (next + kbn) * ld + next + kbn));
+      TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_b, 0));
+    }
+  }
+  int32_t info = 0;
+  TGP_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, S0));
+  TGP_HIP_TRY(hipStreamSynchronize(S0));
+  if (prof) {
+    ctx->prof_syrk_ms = 0;
+    ctx->prof_syrk_flops = 0;
+    ctx->prof_syrk_launches = (int64_t)spans.size();
+    for (auto& sp : spans) {
+      float ms = 0;
+      TGP_HIP_TRY(hipEventElapsedTime(&ms, sp.e0, sp.e1));
+      ctx->prof_syrk_ms += ms;
+      ctx->prof_syrk_flops += sp.flops;
+    }
+  }
+  if (info_host) *info_host = info;
+  return info > 0 ? info : TGP_OK;
+}
+
+template <typename T>
+int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int transpose, T* y) {
+  TGP_ARG_CHECK(n % TILE == 0, "trsv: n must be a multiple of %d", TILE);
+  hipStream_t st = ctx->stream;
+  const int64_t nb = n / TILE;
+  if (!transpose) {
+    for (int64_t kb = 0; kb < nb; ++kb) {
+      const int64_t j0 = kb * TILE;
+      hipLaunchKernelGGL((trsv_diag_fwd_kernel<T>), dim3(1), dim3(128), 0, st, L + j0 * ld + j0, ld,
+                         dinv + kb * 2048, y + j0);
+      const int64_t m = n - (j0 + TILE);
+      if (m > 0)
+        hipLaunchKernelGGL((trsv_update_fwd_kernel<T>), dim3((unsigned)((m + 255) / 256)),
+                           dim3(256), 0, st, m, L + j0 * ld + j0 + TILE, ld, y + j0, y + j0 + TILE);
+    }
+  } else {
+    for (int64_t kb = nb - 1; kb >= 0; --kb) {
+      const int64_t j0 = kb * TILE;
+      hipLaunchKernelGGL((trsv_diag_bwd_kernel<T>), dim3(1), dim3(128), 0, st, L + j0 * ld + j0, ld,
+                         dinv + kb * 2048, y + j0);
+      if (j0 > 0)
+        hipLaunchKernelGGL((trsv_update_bwd_kernel<T>), dim3((unsigned)((j0 + 31) / 32)), dim3(256),
+                           0, st, j0, L + j0, ld, y + j0, y);
+    }
+  }
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+template <typename T>
+int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, const T* dinv, T* B,
+                  int64_t ldb) {
+  TGP_ARG_CHECK(m % TILE == 0 && n % TILE == 0, "trsm_right_lt: m, n must be multiples of %d", TILE);
+  hipStream_t st = ctx->stream;
+  // two-level right-looking sweep: 128-column solve + in-block update, then one wide
+  // MFMA update of everything to the right per outer block of NB columns
+  int64_t NB = ctx->nb_outer;
+  if (NB < TILE) NB = TILE;
+  NB = NB / TILE * TILE;
+  for (int64_t k0 = 0; k0 < n; k0 += NB) {
+    const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
+    for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
+      TGP_TRY(launch_trsm<T>(ctx, st, m, L + j0 * ldl + j0, ldl, dinv + (j0 / TILE) * 2048,
+                             B + j0 * ldb, ldb));
+      const int64_t nc = (k0 + kb) - (j0 + TILE);
+      if (nc > 0)  // B[:, j0+128 .. k0+kb) -= X_j0 * L[j0+128 .. k0+kb, j0 block]^T
+        TGP_TRY(launch_gemm_nt<T>(ctx, st, m, nc, TILE, B + j0 * ldb, ldb,
+                                  L + j0 * ldl + j0 + TILE, ldl, B + (j0 + TILE) * ldb, ldb, 0, 0, 1));
+    }
+    const int64_t next = k0 + kb, nr = n - next;
+    if (nr > 0)
+      TGP_TRY(launch_gemm_nt<T>(ctx, st, m, nr, kb, B + k0 * ldb, ldb, L + k0 * ldl + next, ldl,
+                                B + next * ldb, ldb, 0, 0, 1));
+  }
+  return TGP_OK;
+}
+
+#define TGP_INST(T)                                                                              \
+  template int launch_potf2<T>(tgp_ctx*, hipStream_t, T*, int64_t, T*, int32_t*, int32_t);       \
+  template int launch_trsm<T>(tgp_ctx*, hipStream_t, int64_t, const T*, int64_t, const T*, T*,   \
+                              int64_t);                                                          \
+  template int compute_dinv<T>(tgp_ctx*, int64_t, const T*, int64_t, T*);                        \
+  template int potrf<T>(tgp_ctx*, int64_t, T*, int64_t, T*, int32_t*);                           \
+  template int trsv<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, int, T*);                 \
+  template int trsm_right_lt<T>(tgp_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*,     \
+                                int64_t);
+TGP_INST(float)
+TGP_INST(double)
+#undef TGP_INST
+
+}  // namespace tgp

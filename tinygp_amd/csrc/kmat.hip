@@ -1,0 +1,296 @@
+// kmat.hip -- pairwise-distance + stationary-kernel evaluator (K1/K2/K3/K9 of SURVEY 2a).
+//
+// Replaces reference kernels/base.py:84-103 (nested vmap of Kernel.evaluate) fused with
+// noise.py:77-78 (diagonal scatter-add).  HBM-write bound: every lane owns one ROW of a
+// 128x128 tile and walks 64 columns, so each wave store is 512 contiguous bytes of the
+// column-major output; the X tiles are staged once through LDS.
+//
+// Built with -ffp-contract=off: the scalar formulas below keep the reference's operation
+// order (kernels/stationary.py:76-235, kernels/distance.py:41-59) so entries agree with a
+// NumPy evaluation to the last ulp or two (libm-vs-ocml exp is the only difference).
+#include "tgp_common.h"
+
+namespace tgp {
+
+namespace {
+
+template <typename T> struct MathC;
+template <> struct MathC<double> {
+  static constexpr double SQRT3 = 1.7320508075688772;   // np.sqrt(3)
+  static constexpr double SQRT5 = 2.23606797749979;     // np.sqrt(5)
+  static constexpr double PI = 3.141592653589793;
+  static constexpr double TWO_PI = 6.283185307179586;   // 2 * np.pi
+};
+template <> struct MathC<float> {
+  static constexpr float SQRT3 = 1.7320508075688772f;
+  static constexpr float SQRT5 = 2.23606797749979f;
+  static constexpr float PI = 3.141592653589793f;
+  static constexpr float TWO_PI = 6.283185307179586f;
+};
+
+// Evaluate the postfix program for one pair given r1 = sum|d| and r2 = sum d^2.
+// The evaluation stack lives in 8 named registers (no runtime-indexed array -> no scratch).
+template <typename T>
+__device__ __forceinline__ T eval_kprog(const KProg& kp, T r1, T r2) {
+  T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+  // distance.py:51-56: zero-safe sqrt; distance.py:30-38: L1 "squared" = distance^2
+  const T l2dist = (r2 == T(0)) ? r1 : sqrt(r2);
+  const T l1sq = r1 * r1;
+  for (int i = 0; i < kp.n; ++i) {
+    const int op = kp.op[i];
+    if (op >= TGP_K_ADD) {
+      const T r = (op == TGP_K_ADD) ? (s1 + s0) : (s1 * s0);
+      s0 = r; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
+      continue;
+    }
+    const bool l2 = kp.metric[i] == TGP_METRIC_L2;
+    const T dist = l2 ? l2dist : r1;
+    const T sq = l2 ? r2 : l1sq;
+    const T p0 = T(kp.p0[i]);
+    const T p1 = T(kp.p1[i]);
+    T v;
+    switch (op) {
+      case TGP_K_CONST: v = p0; break;
+      case TGP_K_EXP: v = exp(-dist / p0); break;
+      case TGP_K_EXPSQ: v = exp(T(-0.5) * (sq / (p0 * p0))); break;
+      case TGP_K_M32: { const T a = MathC<T>::SQRT3 * (dist / p0); v = (T(1) + a) * exp(-a); } break;
+      case TGP_K_M52: { const T a = MathC<T>::SQRT5 * (dist / p0);
+                        v = (T(1) + a + (a * a) / T(3)) * exp(-a); } break;
+      case TGP_K_COS: v = cos(MathC<T>::TWO_PI * (dist / p0)); break;
+      case TGP_K_ESS: { const T s = sin(MathC<T>::PI * (dist / p0)); v = exp(-p1 * (s * s)); } break;
+      case TGP_K_RQ: v = pow(T(1) + T(0.5) * (sq / (p0 * p0)) / p1, -p1); break;
+      default: v = T(0);
+    }
+    s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
+  }
+  return s0;
+}
+
+constexpr int KT = 128;  // tile edge
+
+// D = 0: dynamic dimension (coordinates re-read from LDS); D > 0: row point in registers.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void kmat_kernel(KProg kp, int64_t n1, int64_t n2, int d,
+                                                   const T* __restrict__ X1,
+                                                   const T* __restrict__ X2,
+                                                   const T* __restrict__ diag, T* __restrict__ out,
+                                                   int64_t ld, int64_t rows_out, int64_t cols_out,
+                                                   int flags) {
+  const int tr = blockIdx.x, tc = blockIdx.y;
+  if ((flags & KMAT_LOWER) && tr < tc) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* s1 = reinterpret_cast<T*>(smem);  // [KT][d]
+  T* s2 = s1 + KT * d;                 // [KT][d]
+  const int64_t r0 = int64_t(tr) * KT, c0 = int64_t(tc) * KT;
+  for (int t = threadIdx.x; t < KT * d; t += 256) {
+    const int64_t gi = r0 + t / d, gj = c0 + t / d;
+    s1[t] = (gi < n1) ? X1[gi * d + t % d] : T(0);
+    s2[t] = (gj < n2) ? X2[gj * d + t % d] : T(0);
+  }
+  __syncthreads();
+
+  const int il = threadIdx.x & (KT - 1);
+  const int g = threadIdx.x >> 7;  // column half
+  const int64_t gi = r0 + il;
+  T xr[D > 0 ? D : 1];
+  if constexpr (D > 0) {
+#pragma unroll
+    for (int t = 0; t < D; ++t) xr[t] = s1[il * D + t];
+  }
+  const T dg = (diag != nullptr && gi < n1) ? diag[gi] : T(0);
+  if (gi >= rows_out) return;
+  for (int c = 0; c < KT / 2; ++c) {
+    const int jl = g * (KT / 2) + c;
+    const int64_t gj = c0 + jl;
+    if (gj >= cols_out) break;
+    T v;
+    if (gi < n1 && gj < n2) {
+      T r1 = 0, r2 = 0;
+      if constexpr (D > 0) {
+#pragma unroll
+        for (int t = 0; t < D; ++t) {
+          const T dx = xr[t] - s2[jl * D + t];
+          r1 += fabs(dx);
+          r2 += dx * dx;
+        }
+      } else {
+        for (int t = 0; t < d; ++t) {
+          const T dx = s1[il * d + t] - s2[jl * d + t];
+          r1 += fabs(dx);
+          r2 += dx * dx;
+        }
+      }
+      v = eval_kprog<T>(kp, r1, r2);
+      if (diag != nullptr && gi == gj) v += dg;  // noise.py:77-78 fused
+    } else {
+      v = ((flags & KMAT_PAD_IDENTITY) && gi == gj) ? T(1) : T(0);
+    }
+    out[gj * ld + gi] = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kdiag_kernel(KProg kp, int64_t n, const T* __restrict__ add,
+                                                    T* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  // evaluate_diag = evaluate(x, x) (base.py:59-66): every distance is exactly zero
+  T v = eval_kprog<T>(kp, T(0), T(0));
+  if (add != nullptr) v += add[i];
+  out[i] = v;
+}
+
+// Fused K9: partial[chunk][i] = sum_{j in chunk} k(X1[i], X2[j]) v[j].  One lane per row i,
+// X2/v chunks staged through LDS and broadcast-read.
+constexpr int GV_ROWS = 256, GV_JB = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void kmat_gemv_kernel(KProg kp, int64_t n1, int64_t n2, int d,
+                                                        const T* __restrict__ X1,
+                                                        const T* __restrict__ X2,
+                                                        const T* __restrict__ v,
+                                                        T* __restrict__ partial, int64_t jchunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sx = reinterpret_cast<T*>(smem);  // [GV_JB][d]
+  T* sv = sx + GV_JB * d;              // [GV_JB]
+  const int64_t i = int64_t(blockIdx.x) * GV_ROWS + threadIdx.x;
+  const int64_t j0 = int64_t(blockIdx.y) * jchunk;
+  const int64_t j1 = (j0 + jchunk < n2) ? j0 + jchunk : n2;
+  T xi[TGP_MAX_DIM];
+#pragma unroll
+  for (int t = 0; t < TGP_MAX_DIM; ++t) xi[t] = (t < d && i < n1) ? X1[i * d + t] : T(0);
+  T acc = 0;
+  for (int64_t jb = j0; jb < j1; jb += GV_JB) {
+    const int cnt = int((j1 - jb < GV_JB) ? (j1 - jb) : GV_JB);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt * d; t += 256) sx[t] = X2[jb * d + t];
+    for (int t = threadIdx.x; t < cnt; t += 256) sv[t] = v[jb + t];
+    __syncthreads();
+    for (int jj = 0; jj < cnt; ++jj) {
+      T r1 = 0, r2 = 0;
+#pragma unroll
+      for (int t = 0; t < TGP_MAX_DIM; ++t) {
+        if (t < d) {
+          const T dx = xi[t] - sx[jj * d + t];
+          r1 += fabs(dx);
+          r2 += dx * dx;
+        }
+      }
+      acc += eval_kprog<T>(kp, r1, r2) * sv[jj];
+    }
+  }
+  if (i < n1) partial[int64_t(blockIdx.y) * n1 + i] = acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t n1, int nchunks,
+                                                              const T* __restrict__ partial,
+                                                              T* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n1) return;
+  T acc = 0;
+  for (int c = 0; c < nchunks; ++c) acc += partial[int64_t(c) * n1 + i];
+  out[i] = acc;
+}
+
+}  // namespace
+
+int make_kprog(const tgp_kop* prog, int nops, KProg* out) {
+  TGP_ARG_CHECK(prog != nullptr && nops >= 1 && nops <= TGP_KPROG_MAX,
+                "kernel program must have 1..%d ops (got %d)", TGP_KPROG_MAX, nops);
+  int depth = 0;
+  out->n = nops;
+  for (int i = 0; i < nops; ++i) {
+    const int op = prog[i].op;
+    if (op == TGP_K_ADD || op == TGP_K_MUL) {
+      TGP_ARG_CHECK(depth >= 2, "kernel program: stack underflow at op %d", i);
+      depth -= 1;
+    } else {
+      TGP_ARG_CHECK(op >= TGP_K_CONST && op <= TGP_K_RQ, "kernel program: bad opcode %d at %d", op, i);
+      TGP_ARG_CHECK(prog[i].metric == TGP_METRIC_L1 || prog[i].metric == TGP_METRIC_L2,
+                    "kernel program: bad metric at op %d", i);
+      depth += 1;
+      TGP_ARG_CHECK(depth <= TGP_KSTACK_MAX, "kernel program: stack deeper than %d", TGP_KSTACK_MAX);
+    }
+    out->op[i] = op;
+    out->metric[i] = prog[i].metric;
+    out->p0[i] = prog[i].p0;
+    out->p1[i] = prog[i].p1;
+  }
+  TGP_ARG_CHECK(depth == 1, "kernel program leaves %d values on the stack", depth);
+  return TGP_OK;
+}
+
+template <typename T>
+int launch_kmat(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
+                const T* X2, const T* diag, T* out, int64_t ld, int64_t rows_out, int64_t cols_out,
+                int flags) {
+  TGP_ARG_CHECK(d >= 1 && d <= TGP_MAX_DIM, "input dimension must be 1..%d (got %d)", TGP_MAX_DIM, d);
+  TGP_ARG_CHECK(rows_out >= n1 && cols_out >= n2 && ld >= rows_out, "kmat: bad output extents");
+  if (rows_out == 0 || cols_out == 0) return TGP_OK;
+  const int64_t tr = (rows_out + KT - 1) / KT, tc = (cols_out + KT - 1) / KT;
+  TGP_ARG_CHECK(tc <= 65535, "kmat: too many column tiles");
+  dim3 grid((unsigned)tr, (unsigned)tc);
+  const size_t shmem = 2 * size_t(KT) * d * sizeof(T);
+#define TGP_KMAT_LAUNCH(DD)                                                                      \
+  hipLaunchKernelGGL((kmat_kernel<T, DD>), grid, dim3(256), shmem, ctx->stream, kp, n1, n2, d,   \
+                     X1, X2, diag, out, ld, rows_out, cols_out, flags)
+  switch (d) {
+    case 1: TGP_KMAT_LAUNCH(1); break;
+    case 2: TGP_KMAT_LAUNCH(2); break;
+    case 3: TGP_KMAT_LAUNCH(3); break;
+    case 4: TGP_KMAT_LAUNCH(4); break;
+    default: TGP_KMAT_LAUNCH(0); break;
+  }
+#undef TGP_KMAT_LAUNCH
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+template <typename T>
+int launch_kdiag(tgp_ctx* ctx, const KProg& kp, int64_t n, int d, const T* X, const T* add, T* out) {
+  (void)X; (void)d;
+  if (n == 0) return TGP_OK;
+  hipLaunchKernelGGL((kdiag_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     ctx->stream, kp, n, add, out);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+template <typename T>
+int launch_kmat_gemv(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
+                     const T* X2, const T* v, T* out) {
+  TGP_ARG_CHECK(d >= 1 && d <= TGP_MAX_DIM, "input dimension must be 1..%d (got %d)", TGP_MAX_DIM, d);
+  if (n1 == 0) return TGP_OK;
+  const int64_t rb = (n1 + GV_ROWS - 1) / GV_ROWS;
+  // enough column chunks to fill the chip when there are few rows of test points
+  int64_t nch = (2048 + rb - 1) / rb;
+  const int64_t max_ch = (n2 + GV_JB - 1) / GV_JB;
+  if (nch > max_ch) nch = max_ch;
+  if (nch < 1) nch = 1;
+  if (nch > 65535) nch = 65535;
+  int64_t jchunk = round_up((n2 + nch - 1) / nch, GV_JB);
+  if (jchunk < GV_JB) jchunk = GV_JB;
+  nch = (n2 + jchunk - 1) / jchunk;
+  if (nch < 1) nch = 1;
+  TGP_TRY(ensure_work(ctx, size_t(nch) * n1 * sizeof(T)));
+  T* partial = static_cast<T*>(ctx->d_work);
+  const size_t shmem = size_t(GV_JB) * (d + 1) * sizeof(T);
+  hipLaunchKernelGGL((kmat_gemv_kernel<T>), dim3((unsigned)rb, (unsigned)nch), dim3(256), shmem,
+                     ctx->stream, kp, n1, n2, d, X1, X2, v, partial, jchunk);
+  hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0,
+                     ctx->stream, n1, (int)nch, partial, out);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+#define TGP_INST(T)                                                                               \
+  template int launch_kmat<T>(tgp_ctx*, const KProg&, int64_t, int64_t, int, const T*, const T*,  \
+                              const T*, T*, int64_t, int64_t, int64_t, int);                      \
+  template int launch_kdiag<T>(tgp_ctx*, const KProg&, int64_t, int, const T*, const T*, T*);     \
+  template int launch_kmat_gemv<T>(tgp_ctx*, const KProg&, int64_t, int64_t, int, const T*,       \
+                                   const T*, const T*, T*);
+TGP_INST(float)
+TGP_INST(double)
+#undef TGP_INST
+
+}  // namespace tgp

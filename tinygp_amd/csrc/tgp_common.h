@@ -1,0 +1,147 @@
+// tgp_common.h -- shared host/device declarations of libtgp_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/tgp_hip.h"
+
+namespace tgp {
+
+constexpr int TILE = TGP_TILE;  // 128: matrix padding and GEMM tile
+constexpr int SUB = 16;         // MFMA 16x16 sub-block (diag-inverse granularity)
+
+void set_error(const char* fmt, ...);
+
+#define TGP_HIP_TRY(expr)                                                                  \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      ::tgp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                       __LINE__);                                                          \
+      return (_e == hipErrorOutOfMemory) ? TGP_E_NOMEM : TGP_E_HIP;                        \
+    }                                                                                      \
+  } while (0)
+
+#define TGP_ARG_CHECK(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::tgp::set_error(__VA_ARGS__);    \
+      return TGP_E_ARG;                 \
+    }                                   \
+  } while (0)
+
+#define TGP_TRY(expr)          \
+  do {                         \
+    int _s = (expr);           \
+    if (_s < 0) return _s;     \
+  } while (0)
+
+// Kernel program in kernarg form (wave-uniform scalar loads on the device).
+struct KProg {
+  int32_t n;
+  int32_t op[TGP_KPROG_MAX];
+  int32_t metric[TGP_KPROG_MAX];
+  double p0[TGP_KPROG_MAX];
+  double p1[TGP_KPROG_MAX];
+};
+
+int make_kprog(const tgp_kop* prog, int nops, KProg* out);  // validates (TGP_E_ARG)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace tgp
+
+// One HIP device + stream (+ a high-priority side stream for panel look-ahead).
+struct tgp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipStream_t panel_stream = nullptr;  // look-ahead panel factorisation
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  int64_t nb_outer = 512;
+  int64_t lookahead = 1;
+  int64_t profile = 0;
+  // small device scratch: scal[0..15] doubles, info int
+  double* d_scal = nullptr;
+  int32_t* d_info = nullptr;
+  void* d_dinv = nullptr;  // inverse 16x16 diagonal blocks, grown on demand
+  size_t dinv_bytes = 0;
+  void* d_work = nullptr;  // generic workspace, grown on demand
+  size_t work_bytes = 0;
+  // profiling (option "profile"): event pairs around trailing-update launches
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  double prof_syrk_ms = 0, prof_syrk_flops = 0, prof_panel_ms = 0;
+  int64_t prof_syrk_launches = 0;
+  int cus = 0;
+};
+
+namespace tgp {
+
+int ensure_dinv(tgp_ctx* ctx, size_t bytes);
+int ensure_work(tgp_ctx* ctx, size_t bytes);
+
+// ---- launchers (all async on the given stream) -------------------------------------
+template <typename T>
+int launch_kmat(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
+                const T* X2, const T* diag, T* out, int64_t ld, int64_t rows_out, int64_t cols_out,
+                int flags);
+constexpr int KMAT_LOWER = 1;         // only tiles on/below the diagonal
+constexpr int KMAT_PAD_IDENTITY = 2;  // padding = identity (else zeros)
+
+template <typename T>
+int launch_kdiag(tgp_ctx* ctx, const KProg& kp, int64_t n, int d, const T* X, const T* add, T* out);
+template <typename T>
+int launch_kmat_gemv(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
+                     const T* X2, const T* v, T* out);
+
+// C (m x n) = beta*C + alpha*A*B^T ; mode 0: C -= A B^T ; mode 1: C = A B^T.
+// role: 0 = trailing update (profiled as the dominant kernel), 1 = everything else.
+template <typename T>
+int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k, const T* A,
+                   int64_t lda, const T* B, int64_t ldb, T* C, int64_t ldc, int lower, int mode,
+                   int role);
+
+template <typename T>
+int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_t* info,
+                 int32_t pivot_base);
+template <typename T>
+int launch_trsm(tgp_ctx* ctx, hipStream_t st, int64_t m, const T* L, int64_t ldl, const T* dinv,
+                T* B, int64_t ldb);
+
+template <typename T>
+int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host);
+template <typename T>
+int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int transpose, T* y);
+template <typename T>
+int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, const T* dinv,
+                  T* B, int64_t ldb);
+template <typename T>
+int compute_dinv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* dinv);
+
+// reductions into ctx->d_scal[slot] (device), deterministic order
+template <typename T>
+int launch_sum_log_diag(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, int slot);
+template <typename T>
+int launch_sum_squares(tgp_ctx* ctx, int64_t n, const T* y, int slot);
+template <typename T>
+int launch_row_sumsq(tgp_ctx* ctx, int64_t m, int64_t n, const T* B, int64_t ldb, const T* base,
+                     T* out);  // out[i] = base[i] - sum_j B[i,j]^2
+template <typename T>
+int launch_trmv_lower(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* y, T* out);
+template <typename T>
+int launch_extract_lower_rowmajor(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* out);
+template <typename T>
+int launch_set_lower_from_rowmajor(tgp_ctx* ctx, int64_t n, int64_t npad, const T* src, T* A,
+                                   int64_t ld);
+template <typename T>
+int launch_add_diag(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, const T* diag);
+
+int ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops);
+
+}  // namespace tgp

@@ -1,0 +1,195 @@
+"""Kernel base class and kernel algebra (mirror of ``tinygp.kernels.base``).
+
+Where the reference evaluates ``vmap(vmap(evaluate))`` through XLA (reference
+``kernels/base.py:84-103``), a kernel here *compiles* to a small postfix
+"kernel program" (``tgp_kop`` array, ``include/tgp_hip.h``) that the HIP tile
+evaluator runs for every pair of points.  ``Sum`` / ``Product`` / ``Constant``
+(reference ``base.py:170-209``) are the ADD / MUL / CONST ops of that program.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+
+from tinygp_amd import _device
+
+__all__ = ["Kernel", "Conditioned", "Sum", "Product", "Constant"]
+
+# op codes of include/tgp_hip.h
+K_CONST, K_EXP, K_EXPSQ, K_M32, K_M52, K_COS, K_ESS, K_RQ, K_ADD, K_MUL = 0, 1, 2, 3, 4, 5, 6, 7, 16, 17
+KPROG_MAX, KSTACK_MAX = 32, 8
+
+
+class Kernel:
+    """Base class of every kernel.
+
+    Subclasses implement :meth:`_emit`, appending their postfix ops; the public
+    protocol (``__call__``, ``evaluate``, ``evaluate_diag``, ``matmul`` and the
+    ``+`` / ``*`` overloads) matches reference ``kernels/base.py:30-126``.
+    """
+
+    # ndarray (op) kernel must reach Kernel.__radd__/__rmul__ instead of broadcasting
+    __array_ufunc__ = None
+
+    # -- lowering --------------------------------------------------------------
+    def _emit(self, ops: list) -> None:
+        raise NotImplementedError(
+            f"{type(self).__name__} cannot be lowered to the HIP kernel evaluator")
+
+    def program(self) -> list[tuple[int, int, float, float]]:
+        """The validated postfix program ``[(op, metric, p0, p1), ...]``."""
+        ops: list = []
+        self._emit(ops)
+        if len(ops) > KPROG_MAX:
+            raise ValueError(f"kernel expression too large: {len(ops)} ops > {KPROG_MAX}")
+        depth = peak = 0
+        for op, *_ in ops:
+            depth += -1 if op in (K_ADD, K_MUL) else 1
+            peak = max(peak, depth)
+        if peak > KSTACK_MAX:
+            raise ValueError(f"kernel expression too deep: stack {peak} > {KSTACK_MAX}")
+        return ops
+
+    # -- reference protocol ----------------------------------------------------
+    def evaluate(self, X1, X2):
+        """k(x1, x2) for ONE pair of points (reference ``base.py:38-57``).  Runs the same
+        device evaluator as the matrix form on a 1x1 problem."""
+        x1, x2 = np.asarray(X1), np.asarray(X2)
+        if x1.ndim > 1 or x2.ndim > 1:
+            raise ValueError("Kernel.evaluate takes single data points; call the kernel "
+                             "instance to evaluate on arrays of points")
+        dt = _device.common_dtype(x1, x2)
+        return _device.kmat(self.program(), x1.reshape(1, -1).astype(dt),
+                            x2.reshape(1, -1).astype(dt))[0, 0]
+
+    def evaluate_diag(self, X):
+        """Reference ``base.py:59-66``."""
+        return self.evaluate(X, X)
+
+    def matmul(self, X1, X2=None, y=None):
+        """``k(X1, X2) @ y`` with the reference's argument juggling (``base.py:68-82``);
+        fused on the device -- the (N1, N2) matrix is never stored."""
+        if y is None:
+            assert X2 is not None
+            y = X2
+            X2 = None
+        if X2 is None:
+            X2 = X1
+        return _device.kmat_gemv(self.program(), X1, X2, y)
+
+    def __call__(self, X1, X2=None):
+        """Reference ``base.py:84-103``: diagonal (N,) when ``X2`` is None, else (N1, N2)."""
+        prog = self.program()
+        if X2 is None:
+            return _device.kdiag(prog, X1)
+        return _device.kmat(prog, X1, X2)
+
+    # -- algebra (reference base.py:105-126) -------------------------------------
+    def __add__(self, other: Any) -> "Kernel":
+        if isinstance(other, Kernel):
+            return Sum(self, other)
+        return Sum(self, Constant(other))
+
+    def __radd__(self, other: Any) -> "Kernel":
+        # `sum([...])` starts from the integer 0
+        if not isinstance(other, Kernel) and np.ndim(other) == 0 and other == 0:
+            return self
+        if isinstance(other, Kernel):
+            return Sum(other, self)
+        return Sum(Constant(other), self)
+
+    def __mul__(self, other: Any) -> "Kernel":
+        if isinstance(other, Kernel):
+            return Product(self, other)
+        return Product(self, Constant(other))
+
+    def __rmul__(self, other: Any) -> "Kernel":
+        if isinstance(other, Kernel):
+            return Product(other, self)
+        return Product(Constant(other), self)
+
+
+class Sum(Kernel):
+    """k1 + k2 (reference ``base.py:170-177``)."""
+
+    def __init__(self, kernel1: Kernel, kernel2: Kernel):
+        self.kernel1, self.kernel2 = kernel1, kernel2
+
+    def _emit(self, ops):
+        self.kernel1._emit(ops)
+        self.kernel2._emit(ops)
+        ops.append((K_ADD, 0, 0.0, 0.0))
+
+    def __repr__(self):
+        return f"Sum({self.kernel1!r}, {self.kernel2!r})"
+
+
+class Product(Kernel):
+    """k1 * k2 (reference ``base.py:180-187``)."""
+
+    def __init__(self, kernel1: Kernel, kernel2: Kernel):
+        self.kernel1, self.kernel2 = kernel1, kernel2
+
+    def _emit(self, ops):
+        self.kernel1._emit(ops)
+        self.kernel2._emit(ops)
+        ops.append((K_MUL, 0, 0.0, 0.0))
+
+    def __repr__(self):
+        return f"Product({self.kernel1!r}, {self.kernel2!r})"
+
+
+class Constant(Kernel):
+    """k(x_i, x_j) = c (reference ``base.py:190-209``); a non-scalar value raises
+    ``ValueError`` when the kernel is evaluated, as in the reference (``:207-208``)."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def _emit(self, ops):
+        if np.ndim(self.value) != 0:
+            raise ValueError("The value of a constant kernel must be a scalar")
+        ops.append((K_CONST, 0, float(self.value), 0.0))
+
+    def __repr__(self):
+        return f"Constant({self.value!r})"
+
+
+class Conditioned(Kernel):
+    """The kernel of a process conditioned on data (reference ``base.py:129-153``):
+
+        k*(x1, x2) = k(x1, x2) - (L^-1 k(X, x1))^T (L^-1 k(X, x2))
+
+    Evaluated in matrix form through the solver's batched triangular solve; it is not a
+    stationary expression, so it has no kernel program of its own.
+    """
+
+    def __init__(self, X, solver, kernel: Kernel):
+        self.X, self.solver, self.kernel = X, solver, kernel
+
+    def evaluate(self, X1, X2):
+        x1 = np.asarray(X1)[None]
+        x2 = np.asarray(X2)[None]
+        return self(x1, x2)[0, 0]
+
+    def evaluate_diag(self, X):
+        return self(np.asarray(X)[None])[0]
+
+    def matmul(self, X1, X2=None, y=None):
+        if y is None:
+            assert X2 is not None
+            y = X2
+            X2 = None
+        if X2 is None:
+            X2 = X1
+        return np.dot(self(X1, X2), y)
+
+    def __call__(self, X1, X2=None):
+        if X2 is None:
+            # diagonal: k(x,x) - |L^-1 k(X,x)|^2, one batched solve (base.py:150-153)
+            return self.solver.condition_variance(self.kernel, X1)
+        K1 = self.solver.solve_triangular(self.kernel(self.X, X1))
+        K2 = K1 if X2 is X1 else self.solver.solve_triangular(self.kernel(self.X, X2))
+        return self.kernel(X1, X2) - K1.T @ K2

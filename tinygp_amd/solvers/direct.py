@@ -1,0 +1,275 @@
+"""``DirectSolver`` on MI355X (replaces reference ``solvers/direct.py:17-95``).
+
+The reference builds ``K = kernel(X, X) + noise`` and calls
+``jax.scipy.linalg.cholesky`` / ``solve_triangular`` (``direct.py:51-53,66-70``), keeping
+both K and L resident (16 N^2 bytes).  Here a ``tgp_solver`` handle (C ABI,
+``include/tgp_hip.h``) owns ONE padded N x N device matrix: the HIP tile evaluator writes
+the lower triangle of K with the noise fused onto the diagonal, a right-looking blocked
+LL^T (fp64/fp32 MFMA trailing updates) overwrites it with L, and the triangular solves,
+reductions and conditional products run against that resident factor.  ``covariance()``
+is recomputed on demand.
+
+Numerical failure never raises (reference: NaN factor, ``gp.py:316`` -> ``-inf``): a
+positive ``potrf`` info is kept in ``self.info`` and the affected results are NaN.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any
+
+import numpy as np
+
+from tinygp_amd import _device, _ffi
+from tinygp_amd.noise import Diagonal, Noise
+from tinygp_amd.solvers.solver import Solver
+
+__all__ = ["DirectSolver"]
+
+
+class DirectSolver(Solver):
+    """Dense Cholesky solver whose O(N^3) / O(N^2) work runs in hand-written HIP kernels.
+
+    Args:
+        kernel: the kernel function (a tree of stationary kernels for on-device assembly).
+        X: input coordinates, shape (N,) or (N, D).
+        noise: the noise model.
+        covariance: optional pre-computed (N, N) covariance; like the reference
+            (``direct.py:44-46``) it is trusted to equal ``kernel(X, X) + noise``.
+        ctx: optional :class:`tinygp_amd._ffi.Ctx` (device + stream); extra keyword of
+            this implementation, reachable through ``GaussianProcess(**solver_kwargs)``.
+    """
+
+    def __init__(self, kernel, X, noise: Noise, *, covariance: Any | None = None, ctx=None):
+        self.kernel, self.X, self.noise = kernel, X, noise
+        self._ctx = _ffi.default_ctx() if ctx is None else ctx
+        self._handle = None
+        self._covariance_value = None
+        self._scale_tril = None
+
+        noise_diag = np.asarray(noise.diagonal())
+        if covariance is not None:
+            covariance = np.asarray(covariance)
+        dt = _device.common_dtype(np.asarray(X), noise_diag, covariance)
+        P = _device.points(X, dt)
+        self.dtype = dt
+        self._P = P
+        self.n, self.d = P.shape
+        if noise_diag.shape != (self.n,):
+            raise ValueError("the noise model must have one entry per data point")
+        self._noise_diag = np.ascontiguousarray(noise_diag, dtype=dt)
+
+        try:
+            self._prog = kernel.program()
+        except NotImplementedError:
+            self._prog = None  # e.g. kernels.Conditioned: host-evaluated, needs covariance=
+        if covariance is None and not isinstance(noise, Diagonal):
+            # e.g. noise.Dense: add on the host, ship through the covariance channel
+            covariance = kernel(X, X) + noise
+        if covariance is None and self._prog is None:
+            raise NotImplementedError(
+                f"{type(kernel).__name__} cannot be assembled on the device; pass covariance=")
+        if covariance is not None:
+            covariance = np.ascontiguousarray(covariance, dtype=dt)
+            if covariance.shape != (self.n, self.n):
+                raise ValueError("covariance must have shape (N, N)")
+            self._covariance_value = covariance
+
+        lib = _ffi.lib()
+        h = C.c_void_p()
+        _ffi.check(lib.tgp_solver_create(self._ctx.handle, _ffi.dtype_code(dt), self.n, self.d,
+                                         _ffi.ptr(P), _ffi.ptr(self._noise_diag), C.byref(h)),
+                   "tgp_solver_create")
+        self._handle = h
+        self.info = 0
+        self.refactor(kernel, covariance=self._covariance_value)
+
+    # -- factorisation -------------------------------------------------------------
+    def refactor(self, kernel=None, *, covariance=None) -> int:
+        """Re-assemble and re-factor in place with new hyper-parameters (same X / noise):
+        the optimiser / MCMC step of SURVEY 3.4 without re-uploading anything."""
+        if kernel is not None:
+            self.kernel = kernel
+            try:
+                self._prog = kernel.program()
+            except NotImplementedError:
+                self._prog = None
+        kp, nops = _ffi.as_kprog(self._prog or [])
+        info = C.c_int32(0)
+        _ffi.check(_ffi.lib().tgp_solver_factor(self._handle, kp, nops if self._prog else 0,
+                                                _ffi.ptr(covariance), C.byref(info)),
+                   "tgp_solver_factor")
+        self.info = int(info.value)
+        self._scale_tril = None
+        return self.info
+
+    # -- Solver protocol -------------------------------------------------------------
+    def variance(self):
+        """Reference ``direct.py:49,55-56``: ``kernel(X) + noise.diagonal()``."""
+        if self._prog is None:
+            return self.kernel(self.X) + self._noise_diag
+        out = np.empty(self.n, dtype=self.dtype)
+        _ffi.check(_ffi.lib().tgp_solver_variance(self._handle, _ffi.ptr(out)), "tgp_solver_variance")
+        return out
+
+    def covariance(self):
+        """Reference ``direct.py:58-59``.  Recomputed: the factor overwrote K on the device."""
+        if self._covariance_value is not None:
+            return self._covariance_value
+        out = np.empty((self.n, self.n), dtype=self.dtype)
+        _ffi.check(_ffi.lib().tgp_solver_covariance(self._handle, _ffi.ptr(out)),
+                   "tgp_solver_covariance")
+        return out
+
+    @property
+    def variance_value(self):
+        return self.variance()
+
+    @property
+    def covariance_value(self):
+        return self.covariance()
+
+    @property
+    def scale_tril(self):
+        """The lower Cholesky factor as an (N, N) host array, upper triangle zero."""
+        if self._scale_tril is None:
+            out = np.empty((self.n, self.n), dtype=self.dtype)
+            _ffi.check(_ffi.lib().tgp_solver_get_factor(self._handle, _ffi.ptr(out)),
+                       "tgp_solver_get_factor")
+            if self.info:
+                out[:] = np.nan  # jax.scipy.linalg.cholesky: all-NaN on failure
+            self._scale_tril = out
+        return self._scale_tril
+
+    def normalization(self):
+        """Reference ``direct.py:61-64``."""
+        out = C.c_double()
+        _ffi.check(_ffi.lib().tgp_solver_normalization(self._handle, C.byref(out)),
+                   "tgp_solver_normalization")
+        return self.dtype.type(np.nan if self.info else out.value)
+
+    def solve_triangular(self, y, *, transpose: bool = False):
+        """Reference ``direct.py:66-70``: ``L x = y`` or ``L^T x = y``; y (N,) or (N, R)."""
+        y = np.asarray(y)
+        if y.ndim not in (1, 2) or y.shape[0] != self.n:
+            raise ValueError(f"y must have shape ({self.n},) or ({self.n}, R); got {y.shape}")
+        dt = np.result_type(self.dtype, y.dtype) if y.dtype.kind == "f" else self.dtype
+        yy = np.ascontiguousarray(y, dtype=self.dtype)
+        nrhs = 1 if y.ndim == 1 else y.shape[1]
+        out = np.empty_like(yy)
+        if nrhs:
+            _ffi.check(_ffi.lib().tgp_solver_solve_tri(self._handle, int(bool(transpose)), nrhs,
+                                                       _ffi.ptr(yy), _ffi.ptr(out)),
+                       "tgp_solver_solve_tri")
+        if self.info:
+            out[:] = np.nan
+        return out.astype(dt, copy=False)
+
+    def dot_triangular(self, y):
+        """Reference ``direct.py:72-73``: ``einsum('ij,j...->i...', L, y)``."""
+        y = np.asarray(y)
+        if y.ndim < 1 or y.shape[0] != self.n:
+            raise ValueError(f"y must have leading dimension {self.n}")
+        yy = np.ascontiguousarray(y.reshape(self.n, -1), dtype=self.dtype)
+        out = np.empty_like(yy)
+        if yy.shape[1]:
+            _ffi.check(_ffi.lib().tgp_solver_dot_tri(self._handle, yy.shape[1], _ffi.ptr(yy),
+                                                     _ffi.ptr(out)), "tgp_solver_dot_tri")
+        if self.info:
+            out[:] = np.nan
+        return out.reshape(y.shape)
+
+    def _cond(self, kernel, X_test, noise_diag, var_only: bool):
+        prog = kernel.program()
+        kp, nops = _ffi.as_kprog(prog)
+        if X_test is None:
+            Pt, m = None, self.n
+        else:
+            Pt = _device.points(X_test, self.dtype)
+            if Pt.shape[1] != self.d:
+                raise ValueError("X_test must have the same number of input dimensions as X")
+            m = Pt.shape[0]
+        nd = None
+        if noise_diag is not None:
+            nd = np.ascontiguousarray(np.broadcast_to(noise_diag, (m,)), dtype=self.dtype)
+        out = np.empty((m,) if var_only else (m, m), dtype=self.dtype)
+        if m:
+            _ffi.check(_ffi.lib().tgp_solver_condition_cov(self._handle, kp, nops, m, _ffi.ptr(Pt),
+                                                           _ffi.ptr(nd), int(var_only),
+                                                           _ffi.ptr(out)),
+                       "tgp_solver_condition_cov")
+        if self.info:
+            out[:] = np.nan
+        return out
+
+    def condition(self, kernel, X_test, noise):
+        """Reference ``direct.py:75-95``: ``Kss + noise - A^T A`` with ``A = L^-1 Ks``.
+        Assembly of Ks/Kss, the M-RHS triangular solve and the SYRK all stay on the device."""
+        if isinstance(noise, Diagonal):
+            return self._cond(kernel, X_test, noise.diagonal(), False)
+        return self._cond(kernel, X_test, None, False) + noise  # e.g. noise.Dense
+
+    def condition_variance(self, kernel, X_test):
+        """diag of ``k(Xt,Xt) - A^T A`` without forming the (M, M) matrix
+        (what ``kernels.Conditioned.evaluate_diag`` computes per point, reference
+        ``kernels/base.py:150-153``)."""
+        return self._cond(kernel, X_test, None, True)
+
+    # -- fused hot path used by GaussianProcess ----------------------------------------
+    def log_probability(self, resid):
+        """``-0.5 |L^-1 r|^2 - normalization`` fused on the device (reference
+        ``gp.py:313-320``); non-finite -> ``-inf`` (``gp.py:316``)."""
+        r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
+        out = C.c_double()
+        _ffi.check(_ffi.lib().tgp_solver_logprob(self._handle, _ffi.ptr(r), C.byref(out)),
+                   "tgp_solver_logprob")
+        v = out.value
+        if self.info or not np.isfinite(v):
+            v = -np.inf
+        return self.dtype.type(v)
+
+    def alpha(self, resid):
+        """``(K^-1 r, log_probability)`` -- the two solves of reference ``gp.py:330-334``."""
+        r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
+        a = np.empty(self.n, dtype=self.dtype)
+        out = C.c_double()
+        _ffi.check(_ffi.lib().tgp_solver_alpha(self._handle, _ffi.ptr(r), _ffi.ptr(a), C.byref(out)),
+                   "tgp_solver_alpha")
+        v = out.value
+        if self.info or not np.isfinite(v):
+            v = -np.inf
+        if self.info:
+            a[:] = np.nan
+        return a, self.dtype.type(v)
+
+    def conditional_mean(self, kernel, X_test, alpha):
+        """``K(X_test, X) @ alpha`` fused (reference ``gp.py:357`` via ``base.py:68-82``)."""
+        Pt = _device.points(X_test, self.dtype)
+        if Pt.shape[1] != self.d:
+            raise ValueError("X_test must have the same number of input dimensions as X")
+        kp, nops = _ffi.as_kprog(kernel.program())
+        a = np.ascontiguousarray(alpha, dtype=self.dtype)
+        out = np.empty(Pt.shape[0], dtype=self.dtype)
+        if Pt.shape[0]:
+            _ffi.check(_ffi.lib().tgp_solver_cond_mean(self._handle, kp, nops, Pt.shape[0],
+                                                       _ffi.ptr(Pt), _ffi.ptr(a), _ffi.ptr(out)),
+                       "tgp_solver_cond_mean")
+        return out
+
+    def timings(self) -> dict:
+        ms = (C.c_double * 8)()
+        _ffi.check(_ffi.lib().tgp_solver_timings(self._handle, ms, 8), "tgp_solver_timings")
+        keys = ["assembly_ms", "potrf_ms", "syrk_ms", "syrk_launches", "trsv_ms", "panel_ms"]
+        return {k: ms[i] for i, k in enumerate(keys)}
+
+    # -- lifetime ----------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_handle", None):
+            _ffi.lib().tgp_solver_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass

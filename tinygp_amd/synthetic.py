@@ -1,0 +1,51 @@
+"""Synthetic inputs of BASELINE.json's configs: host NumPy only.
+
+"Constant density" (about 100 points per unit length / volume) keeps the conditioning of K
+independent of N, so the same noise level works from N = 1 024 to N = 131 072.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ["make_inputs", "CONFIGS", "config_kernel"]
+
+SEED = 49382  # the reference benchmark's seed (docs/benchmarks.ipynb:135)
+
+# name -> (N, D, dtype, diag, kernel spec)
+CONFIGS = {
+    "c1": dict(n=1024, d=1, dtype="float64", diag=0.01, kernel="expsq"),
+    "c2": dict(n=16384, d=1, dtype="float64", diag=0.01, kernel="expsq"),
+    "c3": dict(n=65536, d=3, dtype="float64", diag=0.01, kernel="matern52"),
+    "c4": dict(n=131072, d=1, dtype="float64", diag=0.01, kernel="expsq"),
+    "c5": dict(n=262144, d=1, dtype="float32", diag=0.1, kernel="sum", m_test=4096),
+}
+
+
+def make_inputs(n: int, d: int = 1, dtype="float64", seed: int = SEED):
+    """X then the noise from ONE fresh generator: X = sort(U(0, n/100, n)) for d = 1 or
+    U(0, (n/100)^(1/d), (n, d)) unsorted; y = sin(x_0) + 0.1 N(0, 1)."""
+    rng = np.random.default_rng(seed)
+    if d == 1:
+        X = np.sort(rng.uniform(0.0, n / 100.0, size=n))
+        x0 = X
+    else:
+        X = rng.uniform(0.0, (n / 100.0) ** (1.0 / d), size=(n, d))
+        x0 = X[:, 0]
+    y = np.sin(x0) + 0.1 * rng.normal(0.0, 1.0, n)
+    return X.astype(dtype), y.astype(dtype)
+
+
+def config_kernel(kernels_module, spec: str, amp: float = 1.5, scale: float = 2.5):
+    """Build the config's kernel from ANY module exposing the tinygp kernel classes
+    (``tinygp_amd.kernels`` or the oracle), so product and checker share one definition."""
+    k = kernels_module
+    if spec == "expsq":
+        return amp**2 * k.ExpSquared(scale)
+    if spec == "matern52":
+        return amp**2 * k.Matern52(scale)  # default L1 metric, as in the reference
+    if spec == "matern32":
+        return amp**2 * k.Matern32(scale)
+    if spec == "sum":
+        return amp**2 * k.ExpSquared(scale) + 0.5**2 * k.Matern32(1.0)
+    raise ValueError(spec)
