@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X.
+
+A "step" is ONE GP log_probability evaluation with fresh hyper-parameters, i.e. the
+optimiser / MCMC step every tinygp tutorial runs: assemble K = k(X,X) +
+diag on the device, blocked Cholesky in place, forward triangular solve, reductions, scalar
+back on the host.  X, the noise diagonal and the residual are resident in HBM before the
+timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c1|c3|n<int>]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards as REPLICAS --
+each rank evaluates its own hyper-parameter point on its own GPU, no data-path collective
+("scaling": "weak"); the only collectives are the timing barrier and the MAX over ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with the `roofline` of the
+dominant kernel (fp64 MFMA trailing update, gemm_nt_kernel<double, 0>) measured live with
+HIP events on the launching stream, and a `cpu_baseline` of the NumPy/SciPy oracle.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet: FP64 matrix = FP64 vector = 78.6 TFLOP/s
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="c2", help="c1|c2|c3 (BASELINE configs) or n<int>[d<int>]")
+    p.add_argument("--nb-outer", type=int, default=0, help="override the outer block (0 = default)")
+    p.add_argument("--lookahead", type=int, default=-1)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-profile", action="store_true", help="disable per-launch HIP-event timing")
+    p.add_argument("--stages", action="store_true", help="also print per-stage times to stderr")
+    return p.parse_args()
+
+
+def workload_spec(name: str):
+    from tinygp_amd import synthetic
+
+    if name in synthetic.CONFIGS:
+        c = dict(synthetic.CONFIGS[name])
+        c["name"] = name
+        return c
+    if name.startswith("n"):
+        body = name[1:]
+        d = 1
+        if "d" in body:
+            body, ds = body.split("d")
+            d = int(ds)
+        return dict(name=name, n=int(body), d=d, dtype="float64", diag=0.01,
+                    kernel="expsq" if d == 1 else "matern52")
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(spec, rank):
+    """The oracle (SciPy/OpenBLAS LAPACK) on this box's host cores, on a bounded sample:
+    the same workload at N_s <= 8192, extrapolated stage by stage (assembly and trsv ~ N^2,
+    dpotrf ~ N^3) to the workload's N.  Reported, never the target."""
+    import scipy.linalg as sla
+
+    from oracle import tinygp_np as o
+    from tinygp_amd import synthetic
+
+    n = spec["n"]
+    ns = min(n, 8192)
+    X, y = synthetic.make_inputs(ns, spec["d"], spec["dtype"])
+    kern = synthetic.config_kernel(o, spec["kernel"])
+    t0 = time.perf_counter()
+    K = kern(X, X)
+    K[np.diag_indices(ns)] += spec["diag"]
+    t1 = time.perf_counter()
+    L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+    t2 = time.perf_counter()
+    alpha = sla.solve_triangular(L, y, lower=True, check_finite=False)
+    ll = -0.5 * float(alpha @ alpha) - float(np.sum(np.log(np.diag(L)))) - 0.5 * ns * np.log(2 * np.pi)
+    t3 = time.perf_counter()
+    f2, f3 = (n / ns) ** 2, (n / ns) ** 3
+    t_full = (t1 - t0) * f2 + (t2 - t1) * f3 + (t3 - t2) * f2
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return {
+        "value": 1.0 / t_full, "unit": "evals/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle/tinygp_np.py (SciPy dpotrf/dtrtrs, OpenBLAS, all {cores} cores) timed at "
+                   f"N={ns}: assembly {t1 - t0:.2f}s potrf {t2 - t1:.2f}s solve+reduce {t3 - t2:.3f}s"
+                   + ("" if ns == n else f"; extrapolated to N={n} (N^2 / N^3 per stage)")),
+        "potrf_gflops": (ns**3 / 3) / (t2 - t1) / 1e9,
+        "loglik_sample": ll,
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False "
+                         "(tinygp_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    from tinygp_amd import _ffi, kernels, noise, synthetic
+    from tinygp_amd.solvers import DirectSolver
+
+    spec = workload_spec(args.workload)
+    n, d = spec["n"], spec["d"]
+    dt = np.dtype(spec["dtype"])
+    ctx = _ffi.Ctx(device=local_rank)
+    if args.nb_outer:
+        ctx.set_option("nb_outer", args.nb_outer)
+    if args.lookahead >= 0:
+        ctx.set_option("lookahead", args.lookahead)
+    ctx.set_option("profile", 0 if args.no_profile else 1)
+    nb_used = ctx.set_option("nb_outer", 512)
+    ctx.set_option("nb_outer", nb_used)
+
+    X, y = synthetic.make_inputs(n, d, spec["dtype"])
+
+    def kernel_at(step):
+        # a different hyper-parameter point per step and per rank (replicas), like an
+        # optimiser trajectory around the config's values (amp 1.5, scale 2.5)
+        u = ((step * 7 + rank * 3) % 11 - 5) / 5.0
+        return synthetic.config_kernel(kernels, spec["kernel"], amp=1.5 * (1 + 0.02 * u),
+                                       scale=2.5 * (1 + 0.03 * u))
+
+    # resident inputs: X + noise diagonal uploaded by the solver, residual uploaded once
+    solver = DirectSolver(kernel_at(-1), X, noise.Diagonal(np.full(n, spec["diag"], dtype=dt)), ctx=ctx)
+    import ctypes as C
+
+    _ffi.check(_ffi.lib().tgp_solver_set_resid(solver._handle, _ffi.ptr(np.ascontiguousarray(y))),
+               "tgp_solver_set_resid")
+
+    def one_step(step):
+        info = solver.refactor(kernel_at(step))
+        out = C.c_double()
+        _ffi.check(_ffi.lib().tgp_solver_logprob(solver._handle, None, C.byref(out)), "tgp_solver_logprob")
+        if info != 0 or not np.isfinite(out.value):
+            raise SystemExit(f"numerical failure in the bench step (info={info}, ll={out.value})")
+        return out.value
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        one_step(s)
+
+    acc = {"assembly_ms": 0.0, "potrf_ms": 0.0, "syrk_ms": 0.0, "syrk_launches": 0.0, "trsv_ms": 0.0,
+           "syrk_flops": 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(args.warmup + s)
+        if not args.no_profile:
+            ms = (C.c_double * 8)()
+            _ffi.lib().tgp_solver_timings(solver._handle, ms, 8)
+            acc["assembly_ms"] += ms[0]; acc["potrf_ms"] += ms[1]; acc["syrk_ms"] += ms[2]
+            acc["syrk_launches"] += ms[3]; acc["trsv_ms"] += ms[4]; acc["syrk_flops"] += ms[6]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        peak = FP64_MFMA_PEAK_TFLOPS if dt == np.float64 else FP32_MFMA_PEAK_TFLOPS
+        roofline = None
+        extra = {}
+        if not args.no_profile and acc["syrk_ms"] > 0:
+            achieved = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12
+            launches = max(acc["syrk_launches"], 1.0)
+            roofline = {
+                "kernel": f"gemm_nt_kernel<{'double' if dt == np.float64 else 'float'}, 0> (Cholesky trailing update)",
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": None,
+                "avg_launch_ms": acc["syrk_ms"] / launches,
+                "flops_per_launch": acc["syrk_flops"] / launches,
+                "launches_per_step": launches / args.steps,
+            }
+            potrf_tf = (n**3 / 3.0) / (acc["potrf_ms"] / args.steps * 1e-3) / 1e12
+            extra = {"cholesky_tflops": potrf_tf,
+                     "stage_ms": {"assembly": acc["assembly_ms"] / args.steps,
+                                  "potrf": acc["potrf_ms"] / args.steps,
+                                  "trailing_update_kernels": acc["syrk_ms"] / args.steps,
+                                  "trsv+reduce": acc["trsv_ms"] / args.steps}}
+            if args.stages:
+                print(json.dumps(extra, indent=1), file=sys.stderr)
+        out = {
+            "metric": "GP log_probability evals/sec + Cholesky TFLOP/s (fp64), N=16,384",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if dt == np.float64 else "f32", "data": "synthetic",
+            "config": {"workload": (f"{spec['name']}: {spec['kernel']} kernel, {d}-D X, N={n}, "
+                                    f"{'fp64' if dt == np.float64 else 'fp32'}, dense Cholesky + tri-solve"),
+                       "n": n, "d": d, "diag": spec["diag"],
+                       "parallelism": "replicas" if world > 1 else "single",
+                       "nb_outer": int(nb_used)},
+            "roofline": roofline,
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec, rank)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

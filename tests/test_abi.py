@@ -45,3 +45,26 @@ def test_product_never_imports_the_oracle():
     for py in (ROOT / "tinygp_amd").rglob("*.py"):
         src = py.read_text()
         assert "import oracle" not in src and "from oracle" not in src, py
+
+
+def test_default_ctx_does_not_deadlock():
+    """Regression: default_ctx() took a non-reentrant lock and then called lib()."""
+    import threading
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    res = []
+
+    def run():
+        try:
+            _ffi.default_ctx()
+        except Exception as e:  # loud failure expected on a CPU-only box
+            res.append(e)
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(30)
+    assert not t.is_alive(), "default_ctx() deadlocked"
+    assert res and isinstance(res[0], _ffi.TgpError)

@@ -1,0 +1,278 @@
+"""GPU parity, API layer: tinygp_amd.GaussianProcess / DirectSolver (HIP through the C ABI)
+against the oracle and the committed golden vectors, written the way the reference's own
+tests read (tests/test_gp.py, test_kernels.py, test_solver.py, test_george_compat.py).
+
+Tolerances: log-likelihood 1e-8 relative (BASELINE.json north_star); posterior mean /
+variance / covariance rtol = atol = 5e-7, the reference's fp64 tolerance
+(src/tinygp/test_utils.py:16); fp32 5e-4 (:15).
+"""
+import numpy as np
+import pytest
+
+import _cases
+from oracle import tinygp_np as o
+from tinygp_amd import GaussianProcess, kernels, noise
+from tinygp_amd.solvers import DirectSolver
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL = 1e-8
+TOL = dict(rtol=5e-7, atol=5e-7)
+
+
+def _loaded_native():
+    """The parity below must have run in native code: the in-tree .so is mapped."""
+    with open("/proc/self/maps") as f:
+        return any("libtgp_hip.so" in line for line in f)
+
+
+@pytest.mark.parametrize("name", sorted(_cases.gp_cases(o, o.GaussianProcess)))
+def test_gp_cases_match_oracle_and_golden(name, golden_dir):
+    g = np.load(golden_dir / "gp.npz")
+    gp, y, t = _cases.gp_cases(kernels, GaussianProcess)[name]
+    ref, _, _ = _cases.gp_cases(o, o.GaussianProcess)[name]
+    assert isinstance(gp.solver, DirectSolver) and gp.solver.info == 0
+
+    np.testing.assert_allclose(gp.log_probability(y), ref.log_probability(y), rtol=LL_RTOL)
+    np.testing.assert_allclose(gp.log_probability(y), g[f"{name}__logp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(gp.solver.normalization(), g[f"{name}__norm"], rtol=LL_RTOL)
+    np.testing.assert_allclose(gp.variance, g[f"{name}__var"], **TOL)
+    np.testing.assert_allclose(gp.covariance, ref.covariance, **TOL)
+    np.testing.assert_allclose(gp.solver.scale_tril, ref.solver.scale_tril, rtol=1e-9, atol=1e-9)
+
+    c0 = gp.condition(y)  # at the data (gp.py:342-346 fast path)
+    np.testing.assert_allclose(c0.log_probability, g[f"{name}__logp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(c0.gp.loc, g[f"{name}__self_loc"], **TOL)
+    np.testing.assert_allclose(c0.gp.variance, g[f"{name}__self_var"], **TOL)
+
+    c1 = gp.condition(y, t)  # at test points
+    np.testing.assert_allclose(c1.log_probability, g[f"{name}__test_logp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(c1.gp.loc, g[f"{name}__test_loc"], **TOL)
+    np.testing.assert_allclose(c1.gp.variance, g[f"{name}__test_var"], **TOL)
+    np.testing.assert_allclose(c1.gp.covariance, g[f"{name}__test_cov"], **TOL)
+    assert _loaded_native()
+
+
+def test_predict_variants_like_george_compat():
+    # test_george_compat.py:122-154
+    x, y, t, diag = _cases.data_george(1)
+    k, ko = kernels.Matern32(1.5), o.Matern32(1.5)
+    gp, ref = GaussianProcess(k, x, diag=diag), o.GaussianProcess(ko, x, diag=diag)
+    np.testing.assert_allclose(gp.predict(y), ref.predict(y), **TOL)
+    np.testing.assert_allclose(gp.predict(y, x), ref.predict(y, x), **TOL)
+    np.testing.assert_allclose(gp.predict(y, t), ref.predict(y, t), **TOL)
+    for kw in (dict(return_var=True), dict(return_cov=True)):
+        a, b = gp.predict(y, **kw), ref.predict(y, **kw)
+        np.testing.assert_allclose(a[0], b[0], **TOL), np.testing.assert_allclose(a[1], b[1], **TOL)
+        a, b = gp.predict(y, t, **kw), ref.predict(y, t, **kw)
+        np.testing.assert_allclose(a[0], b[0], **TOL), np.testing.assert_allclose(a[1], b[1], **TOL)
+
+
+def test_condition_with_other_kernel():
+    # test_solver.py:91-103: condition(y, kernel=kernel0) and condition(y, X_test=t, kernel=kernel0)
+    x, y, t = _cases.data_solver()
+    k, ko = 1.8**2 * kernels.Matern52(1.5), 1.8**2 * o.Matern52(1.5)
+    k0, k0o = 3.8**2 * kernels.Matern32(4.5), 3.8**2 * o.Matern32(4.5)
+    gp, ref = GaussianProcess(k, x, diag=0.1), o.GaussianProcess(ko, x, diag=0.1)
+    for kwargs, kwo in ((dict(kernel=k0), dict(kernel=k0o)),
+                        (dict(X_test=t, kernel=k0), dict(X_test=t, kernel=k0o)),
+                        (dict(X_test=t, include_mean=False), dict(X_test=t, include_mean=False))):
+        a, b = gp.condition(y, **kwargs), ref.condition(y, **kwo)
+        np.testing.assert_allclose(a.log_probability, b.log_probability, rtol=LL_RTOL)
+        np.testing.assert_allclose(a.gp.loc, b.gp.loc, **TOL)
+        np.testing.assert_allclose(a.gp.variance, b.gp.variance, **TOL)
+        np.testing.assert_allclose(a.gp.covariance, b.gp.covariance, **TOL)
+
+
+def test_conditioned_kernel_like_test_kernels():
+    # test_kernels.py:72-83 against np.linalg.solve
+    x1, x2 = _cases.data_kernels()
+    k1 = 1.5 * kernels.Matern32(2.5)
+    k2 = 0.9 * kernels.ExpSineSquared(scale=1.5, gamma=0.3)
+    K = k1(x1, x1) + 0.1 * np.eye(x1.shape[0])
+    solver = DirectSolver.init(k1, x1, noise.Diagonal(np.full(x1.shape[0], 0.1)))
+    cond = kernels.Conditioned(x1, solver, k2)
+    np.testing.assert_allclose(cond(x1, x2), k2(x1, x2) - k2(x1, x1) @ np.linalg.solve(K, k2(x1, x2)),
+                               **TOL)
+
+
+def test_means_and_scalar_y_like_test_gp():
+    # test_gp.py:14-21,41-51: y = rng.normal(len(X)) is a SCALAR with loc=50 that broadcasts
+    rng = np.random.default_rng(1058390)
+    X = rng.uniform(-3, 3, (50, 5))
+    y = rng.normal(len(X))
+    gp1 = GaussianProcess(kernels.Matern32(1.5), X, diag=0.01, mean=lambda x: 0.0)
+    gp2 = GaussianProcess(kernels.Matern32(1.5), X, diag=0.01, mean=0.0)
+    gp3 = GaussianProcess(kernels.Matern32(1.5), X, diag=0.01)
+    np.testing.assert_allclose(gp1.mean, gp2.mean), np.testing.assert_allclose(gp1.mean, gp3.mean)
+    np.testing.assert_allclose(gp1.log_probability(y), gp2.log_probability(y), **TOL)
+    np.testing.assert_allclose(gp1.log_probability(y), gp3.log_probability(y), **TOL)
+    ref = o.GaussianProcess(o.Matern32(1.5), X, diag=0.01)
+    np.testing.assert_allclose(gp3.log_probability(y), ref.log_probability(y), rtol=LL_RTOL)
+    gsum = GaussianProcess(kernels.Matern32(1.5), X, diag=0.01, mean=np.sum)
+    np.testing.assert_allclose(gsum.loc, X.sum(axis=1))
+
+
+def test_condition_shape_error_like_test_gp():
+    # test_gp.py:54-76 (array branch)
+    rng = np.random.default_rng(1058390)
+    X = rng.uniform(-3, 3, (50, 5))
+    y = rng.normal(size=50)
+    gp = GaussianProcess(kernels.ExpSquared(distance=kernels.L2Distance()), X, diag=0.1)
+    gp.condition(y, X[0][None])
+    with pytest.raises(ValueError):
+        gp.condition(y, X[0])
+    with pytest.raises(ValueError):
+        GaussianProcess(kernels.Exp(1.0), X, mean=lambda x: np.ones(2))  # gp.py:91-94
+
+
+def test_solver_protocol_pieces():
+    x, y, t = _cases.data_solver()
+    k, ko = 1.8**2 * kernels.Matern32(1.5), 1.8**2 * o.Matern32(1.5)
+    s = DirectSolver(k, x, noise.Diagonal(np.full(50, 0.1)))
+    r = o.DirectSolver(ko, x, o.Diagonal(np.full(50, 0.1)))
+    Y = np.random.default_rng(5).normal(size=(50, 7))
+    for tr in (False, True):
+        np.testing.assert_allclose(s.solve_triangular(y, transpose=tr), r.solve_triangular(y, transpose=tr), **TOL)
+        np.testing.assert_allclose(s.solve_triangular(Y, transpose=tr), r.solve_triangular(Y, transpose=tr), **TOL)
+    np.testing.assert_allclose(s.dot_triangular(y), r.dot_triangular(y), **TOL)
+    np.testing.assert_allclose(s.dot_triangular(Y), r.dot_triangular(Y), **TOL)
+    np.testing.assert_allclose(s.dot_triangular(Y.reshape(50, 7, 1)), r.dot_triangular(Y.reshape(50, 7, 1)), **TOL)
+    nz = noise.Diagonal(np.full(10, 0.02))
+    np.testing.assert_allclose(s.condition(k, t, nz), r.condition(ko, t, o.Diagonal(np.full(10, 0.02))), **TOL)
+    np.testing.assert_allclose(s.condition(k, None, noise.Diagonal(np.full(50, 0.02))),
+                               r.condition(ko, None, o.Diagonal(np.full(50, 0.02))), **TOL)
+
+
+def test_covariance_argument_and_dense_noise():
+    x, y, _ = _cases.data_solver()
+    k, ko = kernels.Matern52(1.1), o.Matern52(1.1)
+    rng = np.random.default_rng(2)
+    R = rng.normal(size=(50, 50)) * 0.05
+    M = R @ R.T + 0.1 * np.eye(50)
+    gp = GaussianProcess(k, x, noise=noise.Dense(M))
+    ref = o.GaussianProcess(ko, x, noise=o.Dense(M))
+    np.testing.assert_allclose(gp.log_probability(y), ref.log_probability(y), rtol=LL_RTOL)
+    np.testing.assert_allclose(gp.covariance, ref.covariance, **TOL)
+    cov = ko(x, x) + 0.2 * np.eye(50)
+    gp = GaussianProcess(k, x, diag=0.2, covariance_value=cov)
+    np.testing.assert_allclose(gp.log_probability(y), o.GaussianProcess(ko, x, diag=0.2).log_probability(y),
+                               rtol=LL_RTOL)
+
+
+def test_numerical_failure_never_raises():
+    # gp.py:316: non-finite log-likelihood -> -inf; the factor holds NaNs like jax's cholesky
+    x = np.linspace(0, 1, 200)
+    gp = GaussianProcess(kernels.ExpSquared(5.0), x, diag=-0.5)
+    assert gp.solver.info > 0
+    assert gp.log_probability(np.sin(x)) == -np.inf
+    assert np.all(np.isnan(gp.solver.solve_triangular(np.sin(x))))
+    assert np.isnan(gp.solver.normalization())
+    assert o.GaussianProcess(o.ExpSquared(5.0), x, diag=-0.5).log_probability(np.sin(x)) == -np.inf
+
+
+def test_default_jitter_and_fp32():
+    x, y, t = _cases.data_solver()
+    gp = GaussianProcess(kernels.Matern32(1.5), x)  # default diag = sqrt(eps) (gp.py:388-393)
+    ref = o.GaussianProcess(o.Matern32(1.5), x)
+    np.testing.assert_allclose(gp.noise.diagonal(), np.sqrt(np.finfo(np.float64).eps))
+    np.testing.assert_allclose(gp.log_probability(y), ref.log_probability(y), rtol=1e-7)
+    x32, y32, t32 = x.astype(np.float32), y.astype(np.float32), t.astype(np.float32)
+    gp32 = GaussianProcess(1.8**2 * kernels.Matern32(1.5), x32, diag=np.float32(0.1))
+    ref64 = o.GaussianProcess(1.8**2 * o.Matern32(1.5), x, diag=0.1)
+    assert gp32.dtype == np.float32 and gp32.log_probability(y32).dtype == np.float32
+    np.testing.assert_allclose(gp32.log_probability(y32), ref64.log_probability(y), rtol=5e-4)
+    c = gp32.condition(y32, t32)
+    assert c.gp.loc.dtype == np.float32
+    np.testing.assert_allclose(c.gp.loc, ref64.condition(y, t).gp.loc, rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(c.gp.variance, ref64.condition(y, t).gp.variance, rtol=5e-4, atol=5e-4)
+
+
+def test_refactor_is_the_optimizer_step():
+    X, y = _cases.synthetic.make_inputs(1024, 1)
+    gp = GaussianProcess(1.5**2 * kernels.ExpSquared(2.5), X, diag=0.01)
+    for amp, scale in ((1.2, 2.0), (0.8, 3.1)):
+        gp.solver.refactor(amp**2 * kernels.ExpSquared(scale))
+        want = o.GaussianProcess(amp**2 * o.ExpSquared(scale), X, diag=0.01).log_probability(y)
+        np.testing.assert_allclose(gp.solver.log_probability(y), want, rtol=LL_RTOL)
+
+
+# ---- BASELINE.json configs -----------------------------------------------------------------
+def test_config1_n1024(golden_dir):
+    g = np.load(golden_dir / "configs.npz")
+    X, y, c = _cases.data_config("c1")
+    gp = GaussianProcess(_cases.synthetic.config_kernel(kernels, c["kernel"]), X, diag=c["diag"])
+    np.testing.assert_allclose(gp.log_probability(y), g["expsq_n1024__logp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(gp.solver.normalization(), g["expsq_n1024__norm"], rtol=LL_RTOL)
+    alpha = gp.solver.solve_triangular(y)
+    np.testing.assert_allclose(alpha[:16], g["expsq_n1024__alpha_head"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(alpha[-16:], g["expsq_n1024__alpha_tail"], rtol=1e-7, atol=1e-9)
+    Ld = np.diag(gp.solver.scale_tril)
+    np.testing.assert_allclose(Ld[:16], g["expsq_n1024__Ldiag_head"], rtol=1e-10)
+    np.testing.assert_allclose(Ld[-16:], g["expsq_n1024__Ldiag_tail"], rtol=1e-9)
+    cnd = gp.condition(y, np.linspace(0, 10.24, 64))
+    np.testing.assert_allclose(cnd.gp.loc, g["expsq_n1024__test_loc"], **TOL)
+    np.testing.assert_allclose(cnd.gp.variance, g["expsq_n1024__test_var"], **TOL)
+
+
+def test_mid_sizes_against_golden(golden_dir):
+    g = np.load(golden_dir / "configs.npz")
+    X, y = _cases.synthetic.make_inputs(4096, 1)
+    gp = GaussianProcess(_cases.synthetic.config_kernel(kernels, "expsq"), X, diag=0.01)
+    np.testing.assert_allclose(gp.log_probability(y), g["expsq_n4096__logp"], rtol=LL_RTOL)
+    X3, y3 = _cases.synthetic.make_inputs(2048, 3)
+    gp = GaussianProcess(_cases.synthetic.config_kernel(kernels, "matern52"), X3, diag=0.01)
+    np.testing.assert_allclose(gp.log_probability(y3), g["m52_3d_n2048__logp"], rtol=LL_RTOL)
+    xb, yb = _cases.data_benchmark(2000)  # docs/benchmarks.ipynb recipe, non-multiple of 128
+    gp = GaussianProcess(_cases.kernel_zoo(kernels)["bench_m32"], xb, diag=0.01)
+    np.testing.assert_allclose(gp.log_probability(yb), g["bench_m32_n2000__logp"], rtol=LL_RTOL)
+
+
+def _factor_property_checks(gp, X, k, diag, seed):
+    """Size-independent properties: (i) L^-T L^-1 (K z) == z with K z from the fused
+    kernel mat-vec, which never touches the factor; (ii) L^-1 (L z) == z."""
+    n = len(X)
+    z = np.random.default_rng(seed).normal(size=n)
+    Kz = k.matmul(X, z) + diag * z
+    back = gp.solver.solve_triangular(gp.solver.solve_triangular(Kz), transpose=True)
+    err = np.linalg.norm(back - z) / np.linalg.norm(z)
+    assert err < 1e-9, err  # cond(K) ~ 1e3..1e5 for the constant-density inputs
+    rt = gp.solver.solve_triangular(gp.solver.dot_triangular(z))
+    assert np.linalg.norm(rt - z) / np.linalg.norm(z) < 1e-11
+
+
+def test_config2_n16384_full_size():
+    """BASELINE.json config 2 at full size: parity with the LAPACK oracle (1e-8 relative) and
+    the factor's defining properties."""
+    X, y, c = _cases.data_config("c2")
+    k = _cases.synthetic.config_kernel(kernels, c["kernel"])
+    gp = GaussianProcess(k, X, diag=c["diag"])
+    assert gp.solver.info == 0
+    got = float(gp.log_probability(y))
+    _factor_property_checks(gp, X, k, c["diag"], 1)
+    want = float(o.GaussianProcess(_cases.synthetic.config_kernel(o, c["kernel"]), X,
+                                   diag=c["diag"]).log_probability(y))
+    np.testing.assert_allclose(got, want, rtol=LL_RTOL)
+
+
+def test_indefinite_matrix_same_pivot_as_lapack():
+    """The reference's DEFAULT (L1) metric makes Matern-5/2 indefinite in 3-D: LAPACK stops at a
+    leading minor and so must the HIP factorisation, at the same 1-based pivot, with the
+    log-probability -inf on both sides (gp.py:316)."""
+    from scipy.linalg import lapack
+
+    X, y = _cases.synthetic.make_inputs(2048, 3)
+    gp = GaussianProcess(_cases.synthetic.config_kernel(kernels, "matern52_l1"), X, diag=0.01)
+    K = _cases.synthetic.config_kernel(o, "matern52_l1")(X, X) + 0.01 * np.eye(2048)
+    _, info = lapack.dpotrf(K, lower=1)
+    assert info > 0 and gp.solver.info == info
+    assert gp.log_probability(y) == -np.inf
+
+
+def test_matern52_3d_n8192_properties():
+    """Config 3's kernel / metric / dimension at a size the GPU test budget affords."""
+    X, y = _cases.synthetic.make_inputs(8192, 3)
+    k = _cases.synthetic.config_kernel(kernels, "matern52")
+    gp = GaussianProcess(k, X, diag=0.01)
+    assert gp.solver.info == 0 and np.isfinite(gp.log_probability(y))
+    _factor_property_checks(gp, X, k, 0.01, 2)

@@ -1,0 +1,167 @@
+"""GPU parity, device-pointer layer: each HIP kernel through the C ABI against the oracle
+(NumPy/SciPy) on the same seeded inputs.  fp64 tolerances are written next to each check."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+import _cases
+import _lowlevel as ll
+from conftest import ulp_diff
+from oracle import tinygp_np as o
+from tinygp_amd import kernels
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mfma_issue_rate_reported():
+    f64 = ll.ubench(np.float64)
+    f32 = ll.ubench(np.float32)
+    print(f"\n[ubench] v_mfma_f64_16x16x4_f64: {f64:.1f} TFLOP/s   v_mfma_f32_16x16x4_f32: {f32:.1f} TFLOP/s")
+    assert 20 < f64 < 200 and 40 < f32 < 400
+
+
+@pytest.mark.parametrize("name", sorted(_cases.kernel_zoo(kernels)))
+def test_kernel_matrix_matches_oracle(name, golden_dir):
+    """K1: per-entry agreement <= 4 ulp with NumPy (same operation order, ocml vs libm
+    exp/sin/cos/pow) on the 5-D and 1-D fixtures of the reference's kernel tests."""
+    g = np.load(golden_dir / "kernels.npz")
+    x1, x2 = _cases.data_kernels()
+    xs, _, ts = _cases.data_solver()
+    kp, ko = _cases.kernel_zoo(kernels)[name], _cases.kernel_zoo(o)[name]
+    for X1, X2, key in ((x1, x2, "5d"), (xs, ts, "1d")):
+        got = kp(X1, X2)
+        want = ko(X1, X2)
+        assert got.shape == want.shape and got.dtype == want.dtype
+        # cos/sin of large arguments lose relative accuracy near zeros of the function:
+        # bound those by absolute error instead
+        if name in ("cosine", "solver_cos", "expsine2", "sum_ops", "prod_ops"):
+            np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-14)
+        else:
+            assert ulp_diff(got, want) <= 4, (name, key, ulp_diff(got, want))
+        np.testing.assert_allclose(got, g[f"{name}__{key}"], rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(kp(x1), ko(x1), rtol=1e-15)
+    # fp32 path: reference tolerance 5e-4 (test_utils.py:15)
+    got32 = kp(x1.astype(np.float32), x2.astype(np.float32))
+    assert got32.dtype == np.float32
+    np.testing.assert_allclose(got32, ko(x1, x2), rtol=5e-4, atol=5e-4)
+
+
+def test_kernel_matrix_ragged_shapes():
+    """Edge shapes: single point, non-multiples of the 128 tile, D > 4 (dynamic-D path)."""
+    rng = np.random.default_rng(7)
+    k, ko = kernels.Matern52(0.7) * 1.3, o.Matern52(0.7) * 1.3
+    for n1, n2, d in [(1, 1, 1), (1, 300, 2), (129, 127, 3), (257, 1, 4), (130, 140, 7), (5, 9, 16)]:
+        a, b = rng.normal(size=(n1, d)), rng.normal(size=(n2, d))
+        if d < 8:
+            assert ulp_diff(k(a, b), ko(a, b)) <= 4, (n1, n2, d)
+        else:
+            # NumPy sums >= 8 terms pairwise (different rounding of sum|d|), and exp(-a) at
+            # a ~ 60 amplifies one ulp of `a` sixty-fold: bound the relative error instead
+            np.testing.assert_allclose(k(a, b), ko(a, b), rtol=1e-12, atol=0)
+    a = rng.normal(size=(0, 2))
+    assert k(a, rng.normal(size=(3, 2))).shape == (0, 3)
+    with pytest.raises(ValueError):
+        k(rng.normal(size=(4, 17)), rng.normal(size=(4, 17)))
+    with pytest.raises(ValueError):
+        k(rng.normal(size=(4, 2)), rng.normal(size=(4, 3)))
+
+
+def test_kernel_scalar_protocol_and_matmul():
+    x1, x2 = _cases.data_kernels()
+    k, ko = 1.5 * kernels.Matern32(2.5), 1.5 * o.Matern32(2.5)
+    np.testing.assert_allclose(k.evaluate(x1[0], x2[3]), ko(x1[:1], x2[3:4])[0, 0], rtol=1e-14)
+    y = np.random.default_rng(3).normal(size=(50, 3))
+    np.testing.assert_allclose(k.matmul(x1, x2, y), ko(x1, x2) @ y, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(k.matmul(x1, y[:, 0]), ko(x1, x1) @ y[:, 0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(k.matmul(x1, y=y[:, 1]), ko(x1, x1) @ y[:, 1], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 2e-5)])
+def test_gemm_nt_vs_numpy(dtype, tol):
+    """MFMA building block, asymmetric operands (catches operand / C-layout transposes)."""
+    rng = np.random.default_rng(11)
+    for m, n, k, lower in [(128, 128, 16, False), (256, 384, 64, False), (512, 512, 128, True),
+                           (640, 256, 48, True), (384, 384, 512, True)]:
+        A = rng.normal(size=(m, k)).astype(dtype)
+        B = rng.normal(size=(n, k)).astype(dtype)
+        C0 = rng.normal(size=(m, n)).astype(dtype)
+        scale = np.sqrt(k)
+        got = ll.gemm_nt(A, B, C0, -1.0, 1.0, lower)
+        want = C0.astype(np.float64) - A.astype(np.float64) @ B.astype(np.float64).T
+        if lower:  # only 128-tiles with row-tile >= col-tile are touched
+            ti, tj = np.arange(m)[:, None] // 128, np.arange(n)[None, :] // 128
+            mask = ti >= tj
+            np.testing.assert_allclose(got[mask], want[mask], rtol=0, atol=tol * scale * 10)
+            np.testing.assert_array_equal(got[~mask], C0[~mask])
+        else:
+            np.testing.assert_allclose(got, want, rtol=0, atol=tol * scale * 10)
+            got2 = ll.gemm_nt(A, B, C0, 1.0, 0.0, False)
+            np.testing.assert_allclose(got2, A.astype(np.float64) @ B.astype(np.float64).T,
+                                       rtol=0, atol=tol * scale * 10)
+
+
+def _spd(n, dtype, seed=0, cond_diag=0.05):
+    X, _ = _cases.synthetic.make_inputs(n, 1, seed=_cases.synthetic.SEED + seed)
+    K = (1.5**2 * o.ExpSquared(2.5))(X, X) + cond_diag * np.eye(n)
+    return K.astype(dtype)
+
+
+@pytest.mark.parametrize("n", [128, 256, 640, 1024, 2048])
+@pytest.mark.parametrize("lookahead", [0, 1])
+def test_potrf_vs_lapack(n, lookahead):
+    """K4: factor agrees with LAPACK dpotrf to a backward-error bound, and reconstructs K."""
+    K = _spd(n, np.float64)
+    L, info = ll.potrf(K, lookahead=lookahead)
+    assert info == 0
+    Lref = sla.cholesky(K, lower=True)
+    # forward agreement scaled by cond(K) ~ 1e3 for these inputs: stay within 1e-11 relative
+    np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-11 * np.abs(Lref).max())
+    resid = np.abs(L @ L.T - K).max() / np.abs(K).max()
+    assert resid < 50 * n * np.finfo(np.float64).eps / 8, resid
+    assert np.all(np.triu(L, 1) == 0)
+
+
+@pytest.mark.parametrize("nb_outer", [128, 256, 512, 1024])
+def test_potrf_block_sizes_agree(nb_outer):
+    K = _spd(1536, np.float64, seed=1)
+    L, info = ll.potrf(K, nb_outer=nb_outer)
+    assert info == 0
+    Lref = sla.cholesky(K, lower=True)
+    np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-11 * np.abs(Lref).max())
+
+
+def test_potrf_fp32():
+    K = _spd(1024, np.float32, cond_diag=0.5)
+    L, info = ll.potrf(K)
+    assert info == 0
+    Lref = sla.cholesky(K.astype(np.float64), lower=True)
+    np.testing.assert_allclose(L, Lref, rtol=5e-4, atol=5e-4)
+
+
+def test_potrf_not_positive_definite_reports_pivot():
+    K = _spd(512, np.float64)
+    K[300, 300] = -1.0
+    L, info = ll.potrf(K)
+    assert info == 301  # LAPACK convention: 1-based index of the failing pivot
+    assert np.isnan(L[300, 300]) and np.all(np.isfinite(L[:300, :300]))
+
+
+@pytest.mark.parametrize("transpose", [False, True])
+def test_trsv_vs_lapack(transpose):
+    for n in (128, 384, 1280):
+        K = _spd(n, np.float64, seed=2)
+        L = sla.cholesky(K, lower=True)
+        y = np.random.default_rng(n).normal(size=n)
+        got = ll.trsv(L, y, transpose)
+        want = sla.solve_triangular(L, y, lower=True, trans=1 if transpose else 0)
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-10 * np.abs(want).max())
+
+
+def test_trsm_right_lt_vs_lapack():
+    for m, n in [(128, 128), (256, 640), (384, 1152)]:
+        K = _spd(n, np.float64, seed=3)
+        L = sla.cholesky(K, lower=True)
+        B = np.random.default_rng(m + n).normal(size=(m, n))
+        got = ll.trsm_right_lt(L, B)
+        want = sla.solve_triangular(L, B.T, lower=True).T
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-10 * np.abs(want).max())

@@ -25,7 +25,7 @@ TILE = 128
 E_ARG = -1
 
 _LIB_NAME = "libtgp_hip.so"
-_lock = threading.Lock()
+_lock = threading.RLock()
 _lib = None
 _default_ctx = None
 
@@ -75,6 +75,7 @@ SIGNATURES = {
     "tgp_sum_log_diag": [_vp, _int, _i64, _vp, _i64, _pdbl],
     "tgp_sum_squares": [_vp, _int, _i64, _vp, _pdbl],
     "tgp_ubench_mfma": [_vp, _int, _pdbl],
+    "tgp_ubench": [_vp, _int, _int, _pdbl, _pdbl],
     "tgp_solver_create": [_vp, _int, _i64, _i32, _vp, _vp, _pvp],
     "tgp_solver_destroy": [_vp],
     "tgp_solver_factor": [_vp, _pkop, _int, _vp, _pi32],

@@ -315,6 +315,13 @@ int tgp_ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops_out) {
   return ubench_mfma(ctx, dtype, tflops_out);
 }
 
+int tgp_ubench(tgp_ctx* ctx, int kind, int blocks_per_cu, double* tflops_out,
+               double* cycles_per_op_out) {
+  CTX_GUARD(ctx);
+  TGP_ARG_CHECK(tflops_out != nullptr, "null output pointer");
+  return ubench(ctx, kind, blocks_per_cu, tflops_out, cycles_per_op_out);
+}
+
 // ---- solver handle ----------------------------------------------------------------------
 static int solver_scratch(tgp_solver* s, size_t bytes) {
   return tgp::grow(&s->scratch, &s->scratch_bytes, bytes);

@@ -39,6 +39,33 @@ template <> struct Mfma<float> {
   static __device__ __forceinline__ int drow(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
+// 1/x and 1/sqrt(x) from the hardware seed + two Newton steps (<= 1 ulp-class; no IEEE
+// division sequence on the factorisation's critical path)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  float e = __builtin_fmaf(-x, r, 1.0f);
+  return __builtin_fmaf(r, e, r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = __builtin_fma(-x * y, y, 1.0);
+  y = __builtin_fma(0.5 * y, e, y);
+  e = __builtin_fma(-x * y, y, 1.0);
+  return __builtin_fma(0.5 * y, e, y);
+}
+__device__ __forceinline__ float fast_rsqrt(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  float e = __builtin_fmaf(-x * y, y, 1.0f);
+  return __builtin_fmaf(0.5f * y, e, y);
+}
+
 // ---------------------------------------------------------------------------------------
 // potf2: 128x128 diagonal block, one workgroup of 256 threads.
 // thread (tr = tid & 15, tc = tid >> 4) owns A[tr + 16 a][tc + 16 b], a, b in 0..7.
@@ -57,6 +84,10 @@ __global__ __launch_bounds__(256, 1) void potf2_kernel(T* __restrict__ A, int64_
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) a[ai][bi] = A[int64_t(tc + 16 * bi) * ld + tr + 16 * ai];
 
+  // Right-looking, one barrier per column.  The trailing update uses the UNSCALED column
+  // (A[i][c] -= col_i * col_c / d) so only a reciprocal sits on the critical path; the
+  // 1/sqrt(d) scaling of the finished column is done by its owners off that path.
+  __builtin_amdgcn_s_setprio(3);
   int p = 0;
   for (int j = 0; j < 128; ++j) {
     const int bj = j >> 4, cj = j & 15;
@@ -71,32 +102,32 @@ __global__ __launch_bounds__(256, 1) void potf2_kernel(T* __restrict__ A, int64_
     __syncthreads();
     const T d = colbuf[p][j];
     if (tid == 0 && !(d > T(0))) atomicCAS(info, 0, pivot_base + j + 1);
-    const T dj = sqrt(d);
-    const T r = T(1) / dj;
-    T lr[8], lc[8];
+    const T rinv = fast_rcp(d);
+    T cr[8], cc[8];
 #pragma unroll
-    for (int ai = 0; ai < 8; ++ai) lr[ai] = colbuf[p][tr + 16 * ai] * r;
+    for (int ai = 0; ai < 8; ++ai) cr[ai] = colbuf[p][tr + 16 * ai];
 #pragma unroll
     for (int bi = 0; bi < 8; ++bi) {
       const int c = tc + 16 * bi;
-      lc[bi] = (c > j) ? colbuf[p][c] * r : T(0);
+      cc[bi] = (c > j) ? colbuf[p][c] * rinv : T(0);
     }
 #pragma unroll
     for (int bi = 0; bi < 8; ++bi) {
       if (16 * bi + 15 > j) {  // uniform: skip finished block columns
 #pragma unroll
-        for (int ai = 0; ai < 8; ++ai) a[ai][bi] -= lr[ai] * lc[bi];
+        for (int ai = 0; ai < 8; ++ai) a[ai][bi] -= cr[ai] * cc[bi];
       }
     }
     if (tc == cj) {
+      const T rs = fast_rsqrt(d);  // NaN for d < 0: the factor is poisoned from here on
 #pragma unroll
       for (int bi = 0; bi < 8; ++bi)
         if (bi == bj) {
 #pragma unroll
           for (int ai = 0; ai < 8; ++ai) {
             const int i = tr + 16 * ai;
-            if (i > j) a[ai][bi] = lr[ai];
-            else if (i == j) a[ai][bi] = dj;
+            if (i > j) a[ai][bi] = cr[ai] * rs;
+            else if (i == j) a[ai][bi] = d * rs;
           }
         }
     }
@@ -160,6 +191,7 @@ __global__ __launch_bounds__(256) void trsm_kernel(int64_t m, const T* __restric
                                                    int64_t ldb) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
+  __builtin_amdgcn_s_setprio(2);  // panel work outranks the concurrent trailing update
   const int lane = threadIdx.x & 63;
   const int64_t r0 = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16;
   if (r0 >= m) return;

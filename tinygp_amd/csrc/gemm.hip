@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
   __shared__ __attribute__((aligned(16))) T sA[2][BK * LDS_LD];
   __shared__ __attribute__((aligned(16))) T sB[2][BK * LDS_LD];
 
+  if (ROLE == 1) __builtin_amdgcn_s_setprio(1);  // in-panel update: on the critical path
   // XCD-aware remap: hardware places workgroup b on XCD b % 8; give every XCD a contiguous
   // run of tile ids so neighbouring tiles (shared panels) meet in one L2.  Bijective form.
   int bid = blockIdx.x;
@@ -128,71 +129,160 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     }
   };
 
-  acc_t acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
-
   const int nkt = g.k / BK;
-  load_global(0);
-  store_lds(0);
-  __syncthreads();
-
   const int lrow = lane & 15, lk = lane >> 4;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_global(kt + 1);
-    const T* pa = &sB[buf][lk * LDS_LD + wc * 64 + lrow];  // MFMA A operand <- B rows (C col)
-    const T* pb = &sA[buf][lk * LDS_LD + wr * 64 + lrow];  // MFMA B operand <- A rows (C row)
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      T aop[4], bop[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        aop[t] = pa[ks * 4 * LDS_LD + t * 16];
-        bop[t] = pb[ks * 4 * LDS_LD + t * 16];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = M::mma(aop[a], bop[b], acc[a][b]);
-    }
-    if (kt + 1 < nkt) store_lds(buf ^ 1);
-    __syncthreads();
-  }
+  T* Cb = g.C + (j0 + wc * 64) * g.ldc + i0 + wr * 64;
 
-  // epilogue: C[i0 + wr*64 + b*16 + lrow, j0 + wc*64 + a*16 + drow(lane, r)]
-  T* Cb = g.C + (j0 + wc * 64) * g.ldc + i0 + wr * 64 + lrow;
+  if constexpr (sizeof(T) == 8) {
+    // fp64: v_mfma_f64_4x4x4_4b_f64 (16 cycles, measured 73-76 TFLOP/s) instead of
+    // v_mfma_f64_16x16x4_f64 (measured 46-49 TFLOP/s on MI355X).  One instruction is four
+    // independent 4x4x4 products: lane (k = l>>4, q = (l>>2)&3, e = l&3) supplies A_q[e][k]
+    // and B_q[k][e]; lane (i = l>>4, q, j = l&3) receives D_q[i][j].  Four instructions with
+    // the B operand's 4-row groups rotated by t = 0..3 (a rotated LDS read, no VALU) cover
+    // the full 16x16 outer product: acc[a][b][t] holds, in lane (i, q, j),
+    //   C[row = b*16 + 4((q+t)&3) + j][col = a*16 + 4q + i]   (within the wave's 64x64).
+    const int lq = (lane >> 2) & 3, lj = lane & 3;
+    double acc[4][4][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      T* col = Cb + int64_t(a * 16 + M::drow(lane, r)) * g.ldc;
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (g.mode == 0) col[b * 16] -= acc[a][b][r];
-        else col[b * 16] = acc[a][b][r];
+        for (int t = 0; t < 4; ++t) acc[a][b][t] = 0.0;
+    int rot[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) rot[t] = 4 * ((lq + t) & 3) + lj;
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nkt) load_global(kt + 1);
+      const T* pa = &sB[buf][lk * LDS_LD + wc * 64 + lrow];
+      const T* pb = &sA[buf][lk * LDS_LD + wr * 64];
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        double aop[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * LDS_LD + a * 16];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          double bop[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bop[t] = pb[ks * 4 * LDS_LD + b * 16 + rot[t]];
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc[a][b][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aop[a], bop[t], acc[a][b][t], 0, 0, 0);
+        }
       }
+      if (kt + 1 < nkt) store_lds(buf ^ 1);
+      __syncthreads();
     }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      T* col = Cb + int64_t(a * 16 + 4 * lq + lk) * g.ldc;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (g.mode == 0) col[b * 16 + rot[t]] -= acc[a][b][t];
+          else col[b * 16 + rot[t]] = acc[a][b][t];
+        }
+    }
+  } else {
+    acc_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nkt) load_global(kt + 1);
+      const T* pa = &sB[buf][lk * LDS_LD + wc * 64 + lrow];  // MFMA A operand <- B rows (C col)
+      const T* pb = &sA[buf][lk * LDS_LD + wr * 64 + lrow];  // MFMA B operand <- A rows (C row)
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        T aop[4], bop[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          aop[t] = pa[ks * 4 * LDS_LD + t * 16];
+          bop[t] = pb[ks * 4 * LDS_LD + t * 16];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = M::mma(aop[a], bop[b], acc[a][b]);
+      }
+      if (kt + 1 < nkt) store_lds(buf ^ 1);
+      __syncthreads();
+    }
+    // epilogue: C[i0 + wr*64 + b*16 + lrow, j0 + wc*64 + a*16 + drow(lane, r)]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T* col = Cb + lrow + int64_t(a * 16 + M::drow(lane, r)) * g.ldc;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (g.mode == 0) col[b * 16] -= acc[a][b][r];
+          else col[b * 16] = acc[a][b][r];
+        }
+      }
+  }
 }
 
-// ---- MFMA issue-rate microbenchmark ---------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void ubench_kernel(T* out, int iters) {
-  using M = Mfma<T>;
-  typename M::acc_t acc[8];
+// ---- issue-rate microbenchmarks ---------------------------------------------------------
+// kind 0: v_mfma_f64_16x16x4_f64   1: v_mfma_f32_16x16x4_f32   2: v_fma_f64 (VALU)
+//      3: MFMA f64 + VALU f64 FMA interleaved in one wave (1 MFMA : 4 FMA)
+//      4: v_mfma_f64_4x4x4_4b_f64
+// cyc[blockIdx] = shader cycles (s_memtime) spent by wave 0 of the block in the loop.
+template <int KIND>
+__global__ __launch_bounds__(256) void ubench_kernel(double* out, long long* cyc, int iters) {
+  d4 acc[8];
+  f4 accf[8];
+  double v[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = typename M::acc_t{0, 0, 0, 0};
-  T a = T(threadIdx.x) * T(1e-3), b = T(blockIdx.x + 1) * T(1e-3);
+  for (int i = 0; i < 8; ++i) {
+    acc[i] = d4{0, 0, 0, 0};
+    accf[i] = f4{0, 0, 0, 0};
+    v[i] = 1e-3 * i;
+  }
+  const double a = double(threadIdx.x) * 1e-3, b = double(blockIdx.x + 1) * 1e-3;
+  const float af = float(a), bf = float(b);
+  const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = M::mma(a, b, acc[i]);
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (KIND == 0) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+      if constexpr (KIND == 1) accf[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, accf[i], 0, 0, 0);
+      if constexpr (KIND == 2) v[i] = __builtin_fma(v[i], a, b);
+      if constexpr (KIND == 3) {
+        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        v[i] = __builtin_fma(v[i], a, b);
+        v[(i + 1) & 7] = __builtin_fma(v[(i + 1) & 7], a, b);
+        v[(i + 2) & 7] = __builtin_fma(v[(i + 2) & 7], a, b);
+        v[(i + 3) & 7] = __builtin_fma(v[(i + 3) & 7], a, b);
+      }
+      if constexpr (KIND == 4) {
+        double r = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i][0], 0, 0, 0);
+        acc[i][0] = r;
+      }
+    }
   }
-  T s = 0;
+  const long long t1 = __builtin_readcyclecounter();
+  double s = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  if (s == T(-1)) out[0] = s;  // never true; keeps the chain live
+  for (int i = 0; i < 8; ++i)
+    s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + double(accf[i][0] + accf[i][3]) + v[i];
+  if (s == -1.2345) out[0] = s;  // never true; keeps the chains live
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
 }  // namespace
@@ -225,20 +315,27 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   return TGP_OK;
 }
 
-int ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops) {
-  const int iters = 4096, blocks = ctx->cus * 4;
+int ubench(tgp_ctx* ctx, int kind, int blocks_per_cu, double* tflops, double* cycles_per_op) {
+  TGP_ARG_CHECK(kind >= 0 && kind <= 4 && blocks_per_cu >= 1 && blocks_per_cu <= 8, "ubench: bad kind");
+  const int iters = 2048, blocks = ctx->cus * blocks_per_cu;
+  TGP_TRY(ensure_work(ctx, size_t(blocks) * sizeof(long long)));
+  long long* cyc = static_cast<long long*>(ctx->d_work);
   hipEvent_t e0, e1;
   TGP_HIP_TRY(hipEventCreate(&e0));
   TGP_HIP_TRY(hipEventCreate(&e1));
   float best = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     TGP_HIP_TRY(hipEventRecord(e0, ctx->stream));
-    if (dtype == TGP_F64)
-      hipLaunchKernelGGL((ubench_kernel<double>), dim3(blocks), dim3(256), 0, ctx->stream,
-                         reinterpret_cast<double*>(ctx->d_scal), iters);
-    else
-      hipLaunchKernelGGL((ubench_kernel<float>), dim3(blocks), dim3(256), 0, ctx->stream,
-                         reinterpret_cast<float*>(ctx->d_scal), iters);
+#define TGP_UB(K) hipLaunchKernelGGL((ubench_kernel<K>), dim3(blocks), dim3(256), 0, ctx->stream, \
+                                     ctx->d_scal, cyc, iters)
+    switch (kind) {
+      case 0: TGP_UB(0); break;
+      case 1: TGP_UB(1); break;
+      case 2: TGP_UB(2); break;
+      case 3: TGP_UB(3); break;
+      default: TGP_UB(4); break;
+    }
+#undef TGP_UB
     TGP_HIP_TRY(hipEventRecord(e1, ctx->stream));
     TGP_HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
@@ -247,9 +344,18 @@ int ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops) {
   }
   hipEventDestroy(e0);
   hipEventDestroy(e1);
-  const double flops = double(blocks) * 4.0 /*waves*/ * iters * 8.0 * 2048.0;
+  long long c0 = 0;
+  TGP_HIP_TRY(hipMemcpy(&c0, cyc, sizeof(long long), hipMemcpyDeviceToHost));
+  // flops per wave-iteration of the unrolled-by-8 body
+  const double per_op[5] = {2048.0, 2048.0, 128.0, 2048.0 + 4 * 128.0, 512.0};
+  const double flops = double(blocks) * 4.0 /*waves*/ * iters * 8.0 * per_op[kind];
   *tflops = flops / (double(best) * 1e-3) / 1e12;
+  if (cycles_per_op) *cycles_per_op = double(c0) / (double(iters) * 8.0);
   return TGP_OK;
+}
+
+int ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops) {
+  return ubench(ctx, dtype == TGP_F64 ? 0 : 1, 4, tflops, nullptr);
 }
 
 #define TGP_INST(T)                                                                              \

@@ -143,5 +143,6 @@ template <typename T>
 int launch_add_diag(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, const T* diag);
 
 int ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops);
+int ubench(tgp_ctx* ctx, int kind, int blocks_per_cu, double* tflops, double* cycles_per_op);
 
 }  // namespace tgp
