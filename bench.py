@@ -46,6 +46,7 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-profile", action="store_true", help="disable per-launch HIP-event timing")
     p.add_argument("--stages", action="store_true", help="also print per-stage times to stderr")
+    p.add_argument("--unfused", action="store_true", help="separate factor and solve passes")
     return p.parse_args()
 
 
@@ -155,16 +156,19 @@ def main():
     solver = DirectSolver(kernel_at(-1), X, noise.Diagonal(np.full(n, spec["diag"], dtype=dt)), ctx=ctx)
     import ctypes as C
 
-    _ffi.check(_ffi.lib().tgp_solver_set_resid(solver._handle, _ffi.ptr(np.ascontiguousarray(y))),
-               "tgp_solver_set_resid")
+    solver.set_residual(y)
 
     def one_step(step):
-        info = solver.refactor(kernel_at(step))
-        out = C.c_double()
-        _ffi.check(_ffi.lib().tgp_solver_logprob(solver._handle, None, C.byref(out)), "tgp_solver_logprob")
-        if info != 0 or not np.isfinite(out.value):
-            raise SystemExit(f"numerical failure in the bench step (info={info}, ll={out.value})")
-        return out.value
+        if args.unfused:  # factor, then a separate triangular-solve pass
+            solver.refactor(kernel_at(step))
+            out = C.c_double()
+            _ffi.check(_ffi.lib().tgp_solver_logprob(solver._handle, None, C.byref(out)), "tgp_solver_logprob")
+            ll = out.value
+        else:  # one fused device pass (what GaussianProcess.log_probability runs)
+            ll = solver.factor_log_probability(None, kernel_at(step))
+        if solver.info != 0 or not np.isfinite(ll):
+            raise SystemExit(f"numerical failure in the bench step (info={solver.info}, ll={ll})")
+        return ll
 
     def barrier():
         torch.cuda.synchronize()

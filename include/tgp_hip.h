@@ -175,6 +175,13 @@ int tgp_solver_destroy(tgp_solver* s);
  * optimiser loop of SURVEY 3.4.  *info = potrf info. */
 int tgp_solver_factor(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
                       int32_t* info);
+/* tgp_solver_factor + the whole of GaussianProcess.log_probability (gp.py:126-138) in one
+ * call: the forward substitution alpha = L^-1 resid runs block column by block column on a
+ * side stream as soon as each column of L is final, i.e. underneath the factorisation.
+ * resid_host (n,) = y - loc, or NULL to use the residual of tgp_solver_set_resid.
+ * *logprob = -0.5 |alpha|^2 - sum log L_ii - n/2 log(2 pi)  (not clamped: NaN when info>0) */
+int tgp_solver_factor_logprob(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
+                              const void* resid_host, int32_t* info, double* logprob);
 /* replace the noise diagonal (n,) without re-uploading X */
 int tgp_solver_set_noise(tgp_solver* s, const void* noise_diag_host);
 

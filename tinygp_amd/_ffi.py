@@ -79,6 +79,7 @@ SIGNATURES = {
     "tgp_solver_create": [_vp, _int, _i64, _i32, _vp, _vp, _pvp],
     "tgp_solver_destroy": [_vp],
     "tgp_solver_factor": [_vp, _pkop, _int, _vp, _pi32],
+    "tgp_solver_factor_logprob": [_vp, _pkop, _int, _vp, _vp, _pi32, _pdbl],
     "tgp_solver_set_noise": [_vp, _vp],
     "tgp_solver_normalization": [_vp, _pdbl],
     "tgp_solver_solve_tri": [_vp, _int, _i64, _vp, _vp],

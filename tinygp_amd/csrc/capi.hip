@@ -105,6 +105,8 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   int lo = 0, hi = 0;
   TGP_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->panel_stream, hipStreamNonBlocking, hi));
+  TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->solve_stream, hipStreamNonBlocking, hi));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
   TGP_HIP_TRY(hipMalloc(&ctx->d_scal, 16 * sizeof(double)));
@@ -121,6 +123,11 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->panel_stream) hipStreamSynchronize(ctx->panel_stream);
+  if (ctx->solve_stream) {
+    hipStreamSynchronize(ctx->solve_stream);
+    hipStreamDestroy(ctx->solve_stream);
+  }
+  if (ctx->ev_c) hipEventDestroy(ctx->ev_c);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
   if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
@@ -386,9 +393,20 @@ int tgp_solver_set_noise(tgp_solver* s, const void* noise_diag_host) {
   return TGP_OK;
 }
 
-int tgp_solver_factor(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
-                      int32_t* info) {
-  SOLVER_GUARD(s);
+// upload a host vector (n,) into a zero-padded device vector
+static int upload_vec(tgp_solver* s, void* dst, const void* src_host) {
+  const size_t es = esize(s->dtype);
+  TGP_HIP_TRY(hipMemcpyAsync(dst, src_host, size_t(s->n) * es, hipMemcpyHostToDevice, s->ctx->stream));
+  if (s->npad > s->n)
+    TGP_HIP_TRY(hipMemsetAsync((char*)dst + size_t(s->n) * es, 0, size_t(s->npad - s->n) * es,
+                               s->ctx->stream));
+  return TGP_OK;
+}
+
+// fused != 0: also alpha = L^-1 resid (into s->vec) overlapped with the factorisation and
+// *logprob = -0.5 |alpha|^2 - normalization.  resid_host NULL -> the resident residual.
+static int factor_impl(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
+                       int32_t* info, int fused, const void* resid_host, double* logprob) {
   tgp_ctx* ctx = s->ctx;
   if (nops > 0) {
     TGP_TRY(make_kprog(prog, nops, &s->kp));
@@ -420,18 +438,31 @@ int tgp_solver_factor(tgp_solver* s, const tgp_kop* prog, int nops, const void* 
                              KMAT_LOWER | KMAT_PAD_IDENTITY));
     }
     if (prof) TGP_HIP_TRY(hipEventRecord(e1, ctx->stream));
+    if (fused) {
+      if (resid_host) {
+        TGP_TRY(upload_vec(s, s->vec, resid_host));
+      } else {
+        TGP_ARG_CHECK(s->has_resid, "no resident residual: call tgp_solver_set_resid first");
+        TGP_HIP_TRY(hipMemcpyAsync(s->vec, s->resid, size_t(s->npad) * es, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+      }
+    }
     int32_t inf = 0;
-    int st = potrf<T>(ctx, s->npad, A, s->npad, (T*)s->dinv, &inf);
+    int st = potrf<T>(ctx, s->npad, A, s->npad, (T*)s->dinv, &inf, fused ? (T*)s->vec : (T*)nullptr);
     if (st < 0) return st;
     s->info = inf;
     if (prof) TGP_HIP_TRY(hipEventRecord(e2, ctx->stream));
     TGP_TRY(launch_sum_log_diag<T>(ctx, s->n, A, s->npad, 1));
+    if (fused) TGP_TRY(launch_sum_squares<T>(ctx, s->n, (const T*)s->vec, 0));
     return TGP_OK;
   });
   if (status < 0) return status;
-  TGP_HIP_TRY(hipMemcpyAsync(&s->logdet_half, ctx->d_scal + 1, sizeof(double),
-                             hipMemcpyDeviceToHost, ctx->stream));
+  double two[2] = {0, 0};
+  TGP_HIP_TRY(hipMemcpyAsync(two, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  s->logdet_half = two[1];
+  if (fused && logprob)
+    *logprob = -0.5 * two[0] - (s->logdet_half + 0.5 * double(s->n) * std::log(2.0 * M_PI));
   if (prof) {
     float a = 0, b = 0;
     TGP_HIP_TRY(hipEventElapsedTime(&a, e0, e1));
@@ -450,6 +481,19 @@ int tgp_solver_factor(tgp_solver* s, const tgp_kop* prog, int nops, const void* 
   return s->info > 0 ? s->info : TGP_OK;
 }
 
+int tgp_solver_factor(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
+                      int32_t* info) {
+  SOLVER_GUARD(s);
+  return factor_impl(s, prog, nops, cov_host, info, 0, nullptr, nullptr);
+}
+
+int tgp_solver_factor_logprob(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
+                              const void* resid_host, int32_t* info, double* logprob) {
+  SOLVER_GUARD(s);
+  TGP_ARG_CHECK(logprob != nullptr, "null output pointer");
+  return factor_impl(s, prog, nops, cov_host, info, 1, resid_host, logprob);
+}
+
 #define NEED_FACTOR(s) TGP_ARG_CHECK((s)->factored, "solver has not been factored yet")
 
 int tgp_solver_normalization(tgp_solver* s, double* out) {
@@ -457,16 +501,6 @@ int tgp_solver_normalization(tgp_solver* s, double* out) {
   NEED_FACTOR(s);
   TGP_ARG_CHECK(out != nullptr, "null output pointer");
   *out = s->logdet_half + 0.5 * double(s->n) * std::log(2.0 * M_PI);
-  return TGP_OK;
-}
-
-// upload a host vector (n,) into a zero-padded device vector
-static int upload_vec(tgp_solver* s, void* dst, const void* src_host) {
-  const size_t es = esize(s->dtype);
-  TGP_HIP_TRY(hipMemcpyAsync(dst, src_host, size_t(s->n) * es, hipMemcpyHostToDevice, s->ctx->stream));
-  if (s->npad > s->n)
-    TGP_HIP_TRY(hipMemsetAsync((char*)dst + size_t(s->n) * es, 0, size_t(s->npad - s->n) * es,
-                               s->ctx->stream));
   return TGP_OK;
 }
 

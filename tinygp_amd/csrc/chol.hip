@@ -67,97 +67,151 @@ __device__ __forceinline__ float fast_rsqrt(float x) {
 }
 
 // ---------------------------------------------------------------------------------------
-// potf2: 128x128 diagonal block, one workgroup of 256 threads.
-// thread (tr = tid & 15, tc = tid >> 4) owns A[tr + 16 a][tc + 16 b], a, b in 0..7.
+// potf2: 128x128 diagonal block in ONE workgroup (8 waves), matrix resident in LDS.
+//
+// Right-looking over 16-column blocks kb = 0..7:
+//   P1  wave 0 factors the 16x16 diagonal block in registers (lane = row; cross-lane
+//       broadcasts through v_readlane -> SGPR operands) and inverts it (W = L_kk^-1);
+//   P2  the blocks below are solved with MFMAs:  L_ik = A_ik W^T       (one block per wave)
+//   P3  rank-16 trailing update with MFMAs:      A_ij -= L_ik L_jk^T   (block pairs per wave)
+// Every MFMA operand is "16 consecutive rows at fixed k" of the column-major LDS image
+// (leading dimension 144: conflict-free), and every D tile is written back row-contiguous.
+// The eight W blocks are also stored to `dinv` for the trsm / trsv kernels.
 // ---------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 1) void potf2_kernel(T* __restrict__ A, int64_t ld,
-                                                       T* __restrict__ dinv,
-                                                       int32_t* __restrict__ info,
-                                                       int32_t pivot_base) {
-  __shared__ T colbuf[2][128];
-  __shared__ T sD[8][16][16];  // sD[bb][c][i] = element (i, c) of diagonal sub-block bb
-  const int tid = threadIdx.x, tr = tid & 15, tc = tid >> 4;
-  T a[8][8];
-#pragma unroll
-  for (int bi = 0; bi < 8; ++bi)
-#pragma unroll
-    for (int ai = 0; ai < 8; ++ai) a[ai][bi] = A[int64_t(tc + 16 * bi) * ld + tr + 16 * ai];
+__device__ __forceinline__ double readlane(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 
-  // Right-looking, one barrier per column.  The trailing update uses the UNSCALED column
-  // (A[i][c] -= col_i * col_c / d) so only a reciprocal sits on the critical path; the
-  // 1/sqrt(d) scaling of the finished column is done by its owners off that path.
+// LDS image: only the 36 lower 16x16 blocks, each contiguous and column-major
+// (element (r, c) of block (i, j) at blk(i, j) * 256 + c * 16 + r).  72 KiB + W: small
+// enough to share a CU with one 74 KiB GEMM workgroup during look-ahead, and a 32-lane
+// operand read (16 rows x 2 k) is 256 contiguous bytes: conflict-free without padding.
+__device__ __forceinline__ constexpr int blk(int i, int j) { return (i * (i + 1) / 2 + j) * 256; }
+
+template <typename T>
+__global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t ld,
+                                                    T* __restrict__ dinv,
+                                                    int32_t* __restrict__ info,
+                                                    int32_t pivot_base) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  __shared__ __attribute__((aligned(16))) T S[36 * 256];
+  __shared__ __attribute__((aligned(16))) T Wb[16 * 16];  // Wb[k * 16 + c] = W[c][k]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lrow = lane & 15;
   __builtin_amdgcn_s_setprio(3);
-  int p = 0;
-  for (int j = 0; j < 128; ++j) {
-    const int bj = j >> 4, cj = j & 15;
-    if (tc == cj) {
+
+  for (int e = tid; e < 36 * 256; e += 512) {
+    const int b = e >> 8, c = (e >> 4) & 15, r = e & 15;
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= b) ++i;
+    const int j = b - i * (i + 1) / 2;
+    S[e] = A[int64_t(j * 16 + c) * ld + i * 16 + r];
+  }
+  __syncthreads();
+
+  for (int kb = 0; kb < 8; ++kb) {
+    const int k0 = kb * 16;
+    // ---- P1: diagonal block, wave 0 (lanes 16..63 mirror lanes 0..15) ----------------
+    if (w == 0) {
+      const int i = lrow;
+      T* D = &S[blk(kb, kb)];
+      T a[16];
 #pragma unroll
-      for (int bi = 0; bi < 8; ++bi)
-        if (bi == bj) {
+      for (int c = 0; c < 16; ++c) a[c] = D[c * 16 + i];
+      int bad = 0;
 #pragma unroll
-          for (int ai = 0; ai < 8; ++ai) colbuf[p][tr + 16 * ai] = a[ai][bi];
+      for (int j = 0; j < 16; ++j) {
+        const T d = readlane(a[j], j);
+        if (!(d > T(0)) && bad == 0) bad = j + 1;
+        const T v = a[j] * fast_rcp(d);
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) a[c] -= v * readlane(a[j], c);
+      }
+      if (bad != 0 && lane == 0) atomicCAS(info, 0, pivot_base + k0 + bad);
+      T dd = a[0];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) dd = (i == j) ? a[j] : dd;
+      const T rs = fast_rsqrt(dd);  // 1 / L_ii; NaN poisons the factor when d <= 0
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const T rsj = readlane(rs, j);
+        a[j] = (i >= j) ? a[j] * rsj : T(0);
+      }
+      // W = L^-1, lane c owns column c: x_i = (delta_ic - sum_{k<i} L_ik x_k) / L_ii
+      T x[16];
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) {
+        T s0 = (ii == i) ? T(1) : T(0), s1 = T(0);
+#pragma unroll
+        for (int k = 0; k < ii; ++k) {
+          const T lik = readlane(a[k], ii);
+          if (k & 1) s1 -= lik * x[k];
+          else s0 -= lik * x[k];
+        }
+        x[ii] = (s0 + s1) * readlane(rs, ii);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          D[c * 16 + i] = a[c];
+          Wb[i * 16 + c] = x[c];               // row k = i of Wb holds W[:, k]
+          dinv[kb * 256 + i * 16 + c] = x[c];  // element (row c, col i) of W at i*16 + c
+        }
+      }
+    }
+    __syncthreads();
+    // ---- P2: L_ik = A_ik W^T for the blocks below (block i -> wave (i-kb-1)) ----------
+    {
+      const int ib = kb + 1 + w;
+      if (ib < 8) {
+        T* X = &S[blk(ib, kb)];
+        acc_t acc = acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int kk = M::drow(lane, s);
+          acc = M::mma(Wb[kk * 16 + lrow] /* W[c=lrow][kk] */, X[kk * 16 + lrow] /* A_ik[r=lrow][kk] */, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[M::drow(lane, r) * 16 + lrow] = acc[r];
+      }
+    }
+    __syncthreads();
+    // ---- P3: A_ij -= L_ik L_jk^T for kb < j <= i ----------------------------------------
+    {
+      int cnt = 0;
+      for (int jb = kb + 1; jb < 8; ++jb)
+        for (int ib = jb; ib < 8; ++ib, ++cnt) {
+          if ((cnt & 7) != w) continue;
+          T* Cij = &S[blk(ib, jb)];
+          const T* Xi = &S[blk(ib, kb)];
+          const T* Xj = &S[blk(jb, kb)];
+          acc_t acc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = Cij[M::drow(lane, r) * 16 + lrow];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int kk = M::drow(lane, s);
+            acc = M::mma(-Xj[kk * 16 + lrow], Xi[kk * 16 + lrow], acc);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] = acc[r];
         }
     }
     __syncthreads();
-    const T d = colbuf[p][j];
-    if (tid == 0 && !(d > T(0))) atomicCAS(info, 0, pivot_base + j + 1);
-    const T rinv = fast_rcp(d);
-    T cr[8], cc[8];
-#pragma unroll
-    for (int ai = 0; ai < 8; ++ai) cr[ai] = colbuf[p][tr + 16 * ai];
-#pragma unroll
-    for (int bi = 0; bi < 8; ++bi) {
-      const int c = tc + 16 * bi;
-      cc[bi] = (c > j) ? colbuf[p][c] * rinv : T(0);
-    }
-#pragma unroll
-    for (int bi = 0; bi < 8; ++bi) {
-      if (16 * bi + 15 > j) {  // uniform: skip finished block columns
-#pragma unroll
-        for (int ai = 0; ai < 8; ++ai) a[ai][bi] -= cr[ai] * cc[bi];
-      }
-    }
-    if (tc == cj) {
-      const T rs = fast_rsqrt(d);  // NaN for d < 0: the factor is poisoned from here on
-#pragma unroll
-      for (int bi = 0; bi < 8; ++bi)
-        if (bi == bj) {
-#pragma unroll
-          for (int ai = 0; ai < 8; ++ai) {
-            const int i = tr + 16 * ai;
-            if (i > j) a[ai][bi] = cr[ai] * rs;
-            else if (i == j) a[ai][bi] = d * rs;
-          }
-        }
-    }
-    p ^= 1;
   }
 
-  // write L (zeros above the diagonal: diagonal tiles of the factor are clean)
-#pragma unroll
-  for (int bi = 0; bi < 8; ++bi)
-#pragma unroll
-    for (int ai = 0; ai < 8; ++ai) {
-      const int i = tr + 16 * ai, c = tc + 16 * bi;
-      A[int64_t(c) * ld + i] = (i >= c) ? a[ai][bi] : T(0);
-    }
-  // inverses of the eight 16x16 diagonal sub-blocks
-#pragma unroll
-  for (int bb = 0; bb < 8; ++bb) sD[bb][tc][tr] = (tr >= tc) ? a[bb][bb] : T(0);
-  __syncthreads();
-  if (tid < 128) {
-    const int bb = tid >> 4, c = tid & 15;
-    T x[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      T s = (i == c) ? T(1) : T(0);
-#pragma unroll
-      for (int k = 0; k < i; ++k) s -= sD[bb][k][i] * x[k];
-      x[i] = s / sD[bb][i][i];
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dinv[bb * 256 + c * 16 + i] = x[i];
+  // write L; everything above the diagonal of the tile is zero (clean diagonal tiles)
+  for (int e = tid; e < 128 * 128; e += 512) {
+    const int c = e >> 7, r = e & 127;
+    const int i = r >> 4, j = c >> 4;
+    A[int64_t(c) * ld + r] = (r >= c) ? S[blk(i, j) + (c & 15) * 16 + (r & 15)] : T(0);
   }
 }
 
@@ -364,7 +418,7 @@ template <typename T>
 int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_t* info,
                  int32_t pivot_base) {
   (void)ctx;
-  hipLaunchKernelGGL((potf2_kernel<T>), dim3(1), dim3(256), 0, st, A, ld, dinv, info, pivot_base);
+  hipLaunchKernelGGL((potf2_kernel<T>), dim3(1), dim3(512), 0, st, A, ld, dinv, info, pivot_base);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -390,6 +444,18 @@ int compute_dinv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* dinv) {
   return TGP_OK;
 }
 
+// one forward-substitution step: y[0:128] <- L_jj^-1 y[0:128]; y[128:128+m] -= L[below] y[0:128]
+template <typename T>
+int launch_trsv_fwd_step(hipStream_t st, int64_t m_below, const T* Ljj, int64_t ld, const T* dj,
+                         T* yj) {
+  hipLaunchKernelGGL((trsv_diag_fwd_kernel<T>), dim3(1), dim3(128), 0, st, Ljj, ld, dj, yj);
+  if (m_below > 0)
+    hipLaunchKernelGGL((trsv_update_fwd_kernel<T>), dim3((unsigned)((m_below + 255) / 256)),
+                       dim3(256), 0, st, m_below, Ljj + TILE, ld, yj, yj + TILE);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
 namespace {
 struct ProfSpan {
   hipEvent_t e0, e1;
@@ -407,12 +473,20 @@ int prof_event(tgp_ctx* ctx, hipEvent_t* out) {
 }
 }  // namespace
 
+// y != nullptr: also overwrite y (n, zero padded) with L^-1 y.  Block column j of L is final
+// once its trsm has run, so the forward substitution step j (diagonal solve + update of the
+// rows below) is issued on a third stream right behind it and hides under the
+// factorisation -- log_probability needs no separate triangular-solve pass.
 template <typename T>
-int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host) {
+int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host, T* y) {
   TGP_ARG_CHECK(n % TILE == 0 && ld >= n, "potrf: n must be a multiple of %d and ld >= n", TILE);
   if (info_host) *info_host = 0;
   if (n == 0) return TGP_OK;
-  hipStream_t S0 = ctx->stream, S1 = ctx->panel_stream;
+  hipStream_t S0 = ctx->stream, S1 = ctx->panel_stream, S2 = ctx->solve_stream;
+  if (y != nullptr) {  // S2 must see y (uploaded on S0)
+    TGP_HIP_TRY(hipEventRecord(ctx->ev_c, S0));
+    TGP_HIP_TRY(hipStreamWaitEvent(S2, ctx->ev_c, 0));
+  }
   int64_t NB = ctx->nb_outer;
   if (NB < TILE) NB = TILE;
   NB = NB / TILE * TILE;
@@ -428,6 +502,11 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       TGP_TRY(launch_potf2<T>(ctx, st, Ljj, ld, dj, ctx->d_info, (int32_t)j0));
       const int64_t mb = n - (j0 + TILE);
       if (mb > 0) TGP_TRY(launch_trsm<T>(ctx, st, mb, Ljj, ld, dj, Ljj + TILE, ld));
+      if (y != nullptr) {
+        TGP_HIP_TRY(hipEventRecord(ctx->ev_c, st));
+        TGP_HIP_TRY(hipStreamWaitEvent(S2, ctx->ev_c, 0));
+        TGP_TRY(launch_trsv_fwd_step<T>(S2, mb, Ljj, ld, dj, y + j0));
+      }
       const int64_t nc = (k0 + kb) - (j0 + TILE);
       if (mb > 0 && nc > 0)
         TGP_TRY(launch_gemm_nt<T>(ctx, st, mb, nc, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
@@ -435,14 +514,14 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     }
     return TGP_OK;
   };
-  auto trailing = [&](int64_t m, int64_t nn, int64_t kb, const T* P, T* C) -> int {
+  auto trailing = [&](int64_t m, int64_t nn, int64_t kb, const T* P, T* C, int role) -> int {
     ProfSpan sp{};
     if (prof) {
       TGP_TRY(prof_event(ctx, &sp.e0));
       TGP_TRY(prof_event(ctx, &sp.e1));
       TGP_HIP_TRY(hipEventRecord(sp.e0, S0));
     }
-    TGP_TRY(launch_gemm_nt<T>(ctx, S0, m, nn, kb, P, ld, P, ld, C, ld, 1, 0, 0));
+    TGP_TRY(launch_gemm_nt<T>(ctx, S0, m, nn, kb, P, ld, P, ld, C, ld, 1, 0, role));
     if (prof) {
       TGP_HIP_TRY(hipEventRecord(sp.e1, S0));
       // algorithmic flops of the lower-trapezoid update: entries (i >= j) x 2 kb
@@ -459,7 +538,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
       TGP_TRY(panel(S0, k0, kb));
       const int64_t next = k0 + kb, mt = n - next;
-      if (mt > 0) TGP_TRY(trailing(mt, mt, kb, A + k0 * ld + next, A + next * ld + next));
+      if (mt > 0) TGP_TRY(trailing(mt, mt, kb, A + k0 * ld + next, A + next * ld + next, 0));
     }
   } else {
     TGP_TRY(panel(S0, 0, (n < NB) ? n : NB));
@@ -470,7 +549,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       const int64_t kbn = (mt < NB) ? mt : NB;
       const T* P = A + k0 * ld + next;
       // 1. block column of the next panel first ...
-      TGP_TRY(trailing(mt, kbn, kb, P, A + next * ld + next));
+      TGP_TRY(trailing(mt, kbn, kb, P, A + next * ld + next, 0));
       TGP_HIP_TRY(hipEventRecord(ctx->ev_a, S0));
       TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
       // 2. ... factor it on the side stream ...
@@ -479,9 +558,13 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       // 3. ... while the main stream updates the rest
       const int64_t m2 = mt - kbn;
       if (m2 > 0)
-        TGP_TRY(trailing(m2, m2, kb, P + kbn, A + (next + kbn) * ld + next + kbn));
+        TGP_TRY(trailing(m2, m2, kb, P + kbn, A + (next + kbn) * ld + next + kbn, ctx->lookahead >= 2 ? 2 : 0));
       TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_b, 0));
     }
+  }
+  if (y != nullptr) {
+    TGP_HIP_TRY(hipEventRecord(ctx->ev_c, S2));
+    TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_c, 0));
   }
   int32_t info = 0;
   TGP_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, S0));
@@ -509,12 +592,8 @@ int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int tra
   if (!transpose) {
     for (int64_t kb = 0; kb < nb; ++kb) {
       const int64_t j0 = kb * TILE;
-      hipLaunchKernelGGL((trsv_diag_fwd_kernel<T>), dim3(1), dim3(128), 0, st, L + j0 * ld + j0, ld,
-                         dinv + kb * 2048, y + j0);
-      const int64_t m = n - (j0 + TILE);
-      if (m > 0)
-        hipLaunchKernelGGL((trsv_update_fwd_kernel<T>), dim3((unsigned)((m + 255) / 256)),
-                           dim3(256), 0, st, m, L + j0 * ld + j0 + TILE, ld, y + j0, y + j0 + TILE);
+      TGP_TRY(launch_trsv_fwd_step<T>(st, n - (j0 + TILE), L + j0 * ld + j0, ld, dinv + kb * 2048,
+                                      y + j0));
     }
   } else {
     for (int64_t kb = nb - 1; kb >= 0; --kb) {
@@ -563,7 +642,7 @@ int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, c
   template int launch_trsm<T>(tgp_ctx*, hipStream_t, int64_t, const T*, int64_t, const T*, T*,   \
                               int64_t);                                                          \
   template int compute_dinv<T>(tgp_ctx*, int64_t, const T*, int64_t, T*);                        \
-  template int potrf<T>(tgp_ctx*, int64_t, T*, int64_t, T*, int32_t*);                           \
+  template int potrf<T>(tgp_ctx*, int64_t, T*, int64_t, T*, int32_t*, T*);                           \
   template int trsv<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, int, T*);                 \
   template int trsm_right_lt<T>(tgp_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*,     \
                                 int64_t);

@@ -62,7 +62,8 @@ struct tgp_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t panel_stream = nullptr;  // look-ahead panel factorisation
-  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  hipStream_t solve_stream = nullptr;  // forward substitution overlapped with the factorisation
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
   int64_t nb_outer = 512;
   int64_t lookahead = 1;
   int64_t profile = 0;
@@ -115,7 +116,7 @@ int launch_trsm(tgp_ctx* ctx, hipStream_t st, int64_t m, const T* L, int64_t ldl
                 T* B, int64_t ldb);
 
 template <typename T>
-int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host);
+int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host, T* y = nullptr);
 template <typename T>
 int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int transpose, T* y);
 template <typename T>

@@ -81,33 +81,77 @@ class DirectSolver(Solver):
                                          _ffi.ptr(P), _ffi.ptr(self._noise_diag), C.byref(h)),
                    "tgp_solver_create")
         self._handle = h
-        self.info = 0
-        self.refactor(kernel, covariance=self._covariance_value)
+        # The factorisation is deferred to the first use: when that first use is
+        # log_probability (the optimiser / MCMC loop) assembly, Cholesky and the forward
+        # solve run as ONE fused device pass.  Results are identical either way.
+        self._info = 0
+        self._factored = False
 
     # -- factorisation -------------------------------------------------------------
-    def refactor(self, kernel=None, *, covariance=None) -> int:
-        """Re-assemble and re-factor in place with new hyper-parameters (same X / noise):
-        the optimiser / MCMC step of SURVEY 3.4 without re-uploading anything."""
+    def _set_kernel(self, kernel):
         if kernel is not None:
             self.kernel = kernel
             try:
                 self._prog = kernel.program()
             except NotImplementedError:
                 self._prog = None
+            self._covariance_value = None if self._prog is not None else self._covariance_value
+
+    def refactor(self, kernel=None, *, covariance=None) -> int:
+        """(Re-)assemble and (re-)factor in place with new hyper-parameters (same X / noise):
+        the optimiser / MCMC step of SURVEY 3.4 without re-uploading anything."""
+        self._set_kernel(kernel)
+        if covariance is None:
+            covariance = self._covariance_value
         kp, nops = _ffi.as_kprog(self._prog or [])
         info = C.c_int32(0)
         _ffi.check(_ffi.lib().tgp_solver_factor(self._handle, kp, nops if self._prog else 0,
                                                 _ffi.ptr(covariance), C.byref(info)),
                    "tgp_solver_factor")
-        self.info = int(info.value)
+        self._info = int(info.value)
+        self._factored = True
         self._scale_tril = None
-        return self.info
+        return self._info
+
+    def factor_log_probability(self, resid=None, kernel=None) -> float:
+        """Fused step: assemble + factor + forward solve + reductions in one device pass
+        (``tgp_solver_factor_logprob``).  ``resid=None`` re-uses the residual made resident
+        by :meth:`set_residual`.  Returns the raw log-probability (NaN if not PD)."""
+        self._set_kernel(kernel)
+        kp, nops = _ffi.as_kprog(self._prog or [])
+        r = None
+        if resid is not None:
+            r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
+        info, out = C.c_int32(0), C.c_double()
+        _ffi.check(_ffi.lib().tgp_solver_factor_logprob(
+            self._handle, kp, nops if self._prog else 0, _ffi.ptr(self._covariance_value),
+            _ffi.ptr(r), C.byref(info), C.byref(out)), "tgp_solver_factor_logprob")
+        self._info = int(info.value)
+        self._factored = True
+        self._scale_tril = None
+        return out.value
+
+    def set_residual(self, resid):
+        """Make ``y - loc`` resident on the device for repeated fused evaluations."""
+        r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
+        _ffi.check(_ffi.lib().tgp_solver_set_resid(self._handle, _ffi.ptr(r)), "tgp_solver_set_resid")
+
+    def _ensure_factor(self):
+        if not self._factored:
+            self.refactor()
+
+    @property
+    def info(self) -> int:
+        """LAPACK-style potrf info: 0, or the 1-based index of the first non-positive pivot."""
+        self._ensure_factor()
+        return self._info
 
     # -- Solver protocol -------------------------------------------------------------
     def variance(self):
         """Reference ``direct.py:49,55-56``: ``kernel(X) + noise.diagonal()``."""
         if self._prog is None:
             return self.kernel(self.X) + self._noise_diag
+        self._ensure_factor()
         out = np.empty(self.n, dtype=self.dtype)
         _ffi.check(_ffi.lib().tgp_solver_variance(self._handle, _ffi.ptr(out)), "tgp_solver_variance")
         return out
@@ -116,6 +160,7 @@ class DirectSolver(Solver):
         """Reference ``direct.py:58-59``.  Recomputed: the factor overwrote K on the device."""
         if self._covariance_value is not None:
             return self._covariance_value
+        self._ensure_factor()
         out = np.empty((self.n, self.n), dtype=self.dtype)
         _ffi.check(_ffi.lib().tgp_solver_covariance(self._handle, _ffi.ptr(out)),
                    "tgp_solver_covariance")
@@ -132,6 +177,7 @@ class DirectSolver(Solver):
     @property
     def scale_tril(self):
         """The lower Cholesky factor as an (N, N) host array, upper triangle zero."""
+        self._ensure_factor()
         if self._scale_tril is None:
             out = np.empty((self.n, self.n), dtype=self.dtype)
             _ffi.check(_ffi.lib().tgp_solver_get_factor(self._handle, _ffi.ptr(out)),
@@ -143,6 +189,7 @@ class DirectSolver(Solver):
 
     def normalization(self):
         """Reference ``direct.py:61-64``."""
+        self._ensure_factor()
         out = C.c_double()
         _ffi.check(_ffi.lib().tgp_solver_normalization(self._handle, C.byref(out)),
                    "tgp_solver_normalization")
@@ -150,6 +197,7 @@ class DirectSolver(Solver):
 
     def solve_triangular(self, y, *, transpose: bool = False):
         """Reference ``direct.py:66-70``: ``L x = y`` or ``L^T x = y``; y (N,) or (N, R)."""
+        self._ensure_factor()
         y = np.asarray(y)
         if y.ndim not in (1, 2) or y.shape[0] != self.n:
             raise ValueError(f"y must have shape ({self.n},) or ({self.n}, R); got {y.shape}")
@@ -167,6 +215,7 @@ class DirectSolver(Solver):
 
     def dot_triangular(self, y):
         """Reference ``direct.py:72-73``: ``einsum('ij,j...->i...', L, y)``."""
+        self._ensure_factor()
         y = np.asarray(y)
         if y.ndim < 1 or y.shape[0] != self.n:
             raise ValueError(f"y must have leading dimension {self.n}")
@@ -180,6 +229,7 @@ class DirectSolver(Solver):
         return out.reshape(y.shape)
 
     def _cond(self, kernel, X_test, noise_diag, var_only: bool):
+        self._ensure_factor()
         prog = kernel.program()
         kp, nops = _ffi.as_kprog(prog)
         if X_test is None:
@@ -219,17 +269,21 @@ class DirectSolver(Solver):
     def log_probability(self, resid):
         """``-0.5 |L^-1 r|^2 - normalization`` fused on the device (reference
         ``gp.py:313-320``); non-finite -> ``-inf`` (``gp.py:316``)."""
-        r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
-        out = C.c_double()
-        _ffi.check(_ffi.lib().tgp_solver_logprob(self._handle, _ffi.ptr(r), C.byref(out)),
-                   "tgp_solver_logprob")
-        v = out.value
+        if not self._factored:
+            v = self.factor_log_probability(resid)  # first use: one fused device pass
+        else:
+            r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
+            out = C.c_double()
+            _ffi.check(_ffi.lib().tgp_solver_logprob(self._handle, _ffi.ptr(r), C.byref(out)),
+                       "tgp_solver_logprob")
+            v = out.value
         if self.info or not np.isfinite(v):
             v = -np.inf
         return self.dtype.type(v)
 
     def alpha(self, resid):
         """``(K^-1 r, log_probability)`` -- the two solves of reference ``gp.py:330-334``."""
+        self._ensure_factor()
         r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
         a = np.empty(self.n, dtype=self.dtype)
         out = C.c_double()
