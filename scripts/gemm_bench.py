@@ -15,19 +15,21 @@ dt = np.float64 if len(sys.argv) < 2 or sys.argv[1] == "f64" else np.float32
 es = np.dtype(dt).itemsize
 code = _ffi.dtype_code(dt)
 M = 8192
-for lower in (1, 0):
-    for K in (128, 256, 512, 1024, 2048):
+for mode in ((-1.0, 1.0), (1.0, 0.0)):
+  lower = 0
+  for K in (16, 128, 512, 2048):
+    if True:
         rng = np.random.default_rng(0)
         dA = ctx.upload(rng.normal(size=M * K).astype(dt))
         dC = ctx.upload(rng.normal(size=M * M).astype(dt))
         def run(reps):
             for _ in range(reps):
-                _ffi.check(lib.tgp_gemm_nt(ctx.handle, code, M, M, K, -1.0, C.c_void_p(dA), M, C.c_void_p(dA), M,
-                                           1.0, C.c_void_p(dC), M, lower), "gemm")
+                _ffi.check(lib.tgp_gemm_nt(ctx.handle, code, M, M, K, mode[0], C.c_void_p(dA), M, C.c_void_p(dA), M,
+                                           mode[1], C.c_void_p(dC), M, lower), "gemm")
             ctx.sync()
         run(2)
         t0 = time.perf_counter(); reps = 8; run(reps); dtm = (time.perf_counter() - t0) / reps
         tiles = (M // 128) * (M // 128 + 1) // 2 if lower else (M // 128) ** 2
         flops = tiles * 128 * 128 * K * 2.0
-        print(f"{np.dtype(dt).name} lower={lower} M={M} K={K:5d}: {dtm*1e3:8.3f} ms  {flops/dtm/1e12:7.2f} TFLOP/s", flush=True)
+        print(f"mode={mode} {np.dtype(dt).name} lower={lower} M={M} K={K:5d}: {dtm*1e3:8.3f} ms  {flops/dtm/1e12:7.2f} TFLOP/s", flush=True)
         ctx.free(dA); ctx.free(dC)
