@@ -35,6 +35,18 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet: FP64 matrix = FP64 vector 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
 
 
+def emit(obj):
+    """Print the ONE JSON line last: flush C stdio first (RCCL's banner sits in libc's buffer)."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(obj), flush=True)
+
+
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -47,6 +59,10 @@ def parse_args():
     p.add_argument("--no-profile", action="store_true", help="disable per-launch HIP-event timing")
     p.add_argument("--stages", action="store_true", help="also print per-stage times to stderr")
     p.add_argument("--unfused", action="store_true", help="separate factor and solve passes")
+    p.add_argument("--distributed", action="store_true",
+                   help="ONE matrix, 1-D block-cyclic columns over the N GPUs with RCCL panel "
+                        "broadcast (strong scaling; BASELINE config 4) instead of replicas")
+    p.add_argument("--nb-dist", type=int, default=1024, help="block-column width of --distributed")
     return p.parse_args()
 
 
@@ -106,8 +122,70 @@ def cpu_baseline(spec, rank):
     }
 
 
+def run_distributed(args, spec, X, y, rank, local_rank, world, dist, torch):
+    """Strong scaling: one log_probability of ONE N x N matrix spread over all ranks."""
+    import torch.distributed as tdist
+
+    from tinygp_amd import kernels, synthetic
+    from tinygp_amd.distributed import BlockCyclicCholesky, HipBlockOps
+
+    if dist is None:  # single rank still goes through RCCL (self-broadcast)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    n = spec["n"]
+    dt = np.dtype(spec["dtype"])
+    kern = synthetic.config_kernel(kernels, spec["kernel"])
+    solver = BlockCyclicCholesky(kern, X, np.full(n, spec["diag"], dtype=dt), nb=args.nb_dist,
+                                 ops=HipBlockOps(local_rank), dist=tdist)
+
+    def one_step(step):
+        u = ((step * 7) % 11 - 5) / 5.0
+        solver.assemble(synthetic.config_kernel(kernels, spec["kernel"], amp=1.5 * (1 + 0.02 * u),
+                                                scale=2.5 * (1 + 0.03 * u)))
+        solver.factor()
+        ll = solver.log_probability(y)
+        if not np.isfinite(ll):
+            raise SystemExit(f"numerical failure in the distributed bench step (info={solver.info})")
+        return ll
+
+    def barrier():
+        torch.cuda.synchronize(); tdist.barrier(); torch.cuda.synchronize()
+
+    for s_ in range(args.warmup):
+        one_step(s_)
+    barrier()
+    t0 = time.perf_counter()
+    for s_ in range(args.steps):
+        one_step(args.warmup + s_)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    result = None
+    if rank == 0:
+        flops = n**3 / 3.0
+        result = ({
+            "metric": "GP log_probability evals/sec + Cholesky TFLOP/s (fp64), N=16,384",
+            "value": args.steps / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64" if dt == np.float64 else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{spec['name']}: {spec['kernel']} kernel, {spec['d']}-D X, N={n}, "
+                                   "1-D block-cyclic column Cholesky, RCCL panel broadcast",
+                       "n": n, "nb": args.nb_dist, "parallelism": f"block-cyclic columns x{world}"},
+            "aggregate_cholesky_tflops": flops * args.steps / elapsed / 1e12,
+            "roofline": None, "cpu_baseline": None})
+    tdist.barrier()
+    tdist.destroy_process_group()
+    if result is not None:
+        emit(result)
+
+
 def main():
     args = parse_args()
+    os.environ.setdefault("NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,6 +222,9 @@ def main():
     ctx.set_option("nb_outer", nb_used)
 
     X, y = synthetic.make_inputs(n, d, spec["dtype"])
+
+    if args.distributed:
+        return run_distributed(args, spec, X, y, rank, local_rank, world, dist, torch)
 
     def kernel_at(step):
         # a different hyper-parameter point per step and per rank (replicas), like an
@@ -240,10 +321,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spec, rank)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        emit(out)
 
 
 if __name__ == "__main__":

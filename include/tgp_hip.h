@@ -148,6 +148,11 @@ int tgp_gemm_nt(tgp_ctx* ctx, int dtype, int64_t m, int64_t n, int64_t k, double
                 const void* A, int64_t lda, const void* B, int64_t ldb, double beta, void* C,
                 int64_t ldc, int lower);
 
+/* y (m) -= P (m x k, column-major) x (k), k % TGP_TILE == 0: the update half of a blocked
+ * forward substitution (used by the multi-GPU forward solve, one block column at a time) */
+int tgp_gemv_sub(tgp_ctx* ctx, int dtype, int64_t m, int64_t k, const void* P, int64_t ld,
+                 const void* x, void* y);
+
 /* K7/K8 reductions: *out_host = sum log L[i,i] over i < n   /   sum y[i]^2 over i < n */
 int tgp_sum_log_diag(tgp_ctx* ctx, int dtype, int64_t n, const void* L, int64_t ld,
                      double* out_host);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "tgp_trsv": [_vp, _int, _i64, _vp, _i64, _int, _vp],
     "tgp_trsm_right_lt": [_vp, _int, _i64, _i64, _vp, _i64, _vp, _i64],
     "tgp_gemm_nt": [_vp, _int, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64, _int],
+    "tgp_gemv_sub": [_vp, _int, _i64, _i64, _vp, _i64, _vp, _vp],
     "tgp_sum_log_diag": [_vp, _int, _i64, _vp, _i64, _pdbl],
     "tgp_sum_squares": [_vp, _int, _i64, _vp, _pdbl],
     "tgp_ubench_mfma": [_vp, _int, _pdbl],

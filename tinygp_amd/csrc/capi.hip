@@ -276,6 +276,15 @@ int tgp_trsm_right_lt(tgp_ctx* ctx, int dtype, int64_t m, int64_t n, const void*
   });
 }
 
+int tgp_gemv_sub(tgp_ctx* ctx, int dtype, int64_t m, int64_t k, const void* P, int64_t ld,
+                 const void* x, void* y) {
+  CTX_GUARD(ctx);
+  return dispatch(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return gemv_sub<T>(ctx, m, k, (const T*)P, ld, (const T*)x, (T*)y);
+  });
+}
+
 int tgp_gemm_nt(tgp_ctx* ctx, int dtype, int64_t m, int64_t n, int64_t k, double alpha,
                 const void* A, int64_t lda, const void* B, int64_t ldb, double beta, void* C,
                 int64_t ldc, int lower) {

@@ -609,6 +609,18 @@ int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int tra
   return TGP_OK;
 }
 
+// y (m) -= P (m x k, column-major) x (k); k a multiple of 128.  Thread per row, coalesced.
+template <typename T>
+int gemv_sub(tgp_ctx* ctx, int64_t m, int64_t k, const T* P, int64_t ld, const T* x, T* y) {
+  TGP_ARG_CHECK(k % TILE == 0, "gemv_sub: k must be a multiple of %d", TILE);
+  if (m == 0) return TGP_OK;
+  for (int64_t c0 = 0; c0 < k; c0 += TILE)
+    hipLaunchKernelGGL((trsv_update_fwd_kernel<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0,
+                       ctx->stream, m, P + c0 * ld, ld, x + c0, y);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
 template <typename T>
 int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, const T* dinv, T* B,
                   int64_t ldb) {
@@ -644,6 +656,7 @@ int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, c
   template int compute_dinv<T>(tgp_ctx*, int64_t, const T*, int64_t, T*);                        \
   template int potrf<T>(tgp_ctx*, int64_t, T*, int64_t, T*, int32_t*, T*);                           \
   template int trsv<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, int, T*);                 \
+  template int gemv_sub<T>(tgp_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*);                          \
   template int trsm_right_lt<T>(tgp_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*,     \
                                 int64_t);
 TGP_INST(float)

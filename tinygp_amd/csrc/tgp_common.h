@@ -123,6 +123,8 @@ template <typename T>
 int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, const T* dinv,
                   T* B, int64_t ldb);
 template <typename T>
+int gemv_sub(tgp_ctx* ctx, int64_t m, int64_t k, const T* P, int64_t ld, const T* x, T* y);
+template <typename T>
 int compute_dinv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* dinv);
 
 // reductions into ctx->d_scal[slot] (device), deterministic order
