@@ -276,3 +276,30 @@ def test_matern52_3d_n8192_properties():
     gp = GaussianProcess(k, X, diag=0.01)
     assert gp.solver.info == 0 and np.isfinite(gp.log_probability(y))
     _factor_property_checks(gp, X, k, 0.01, 2)
+
+
+def test_sample_shapes_and_moments_like_test_gp():
+    # reference tests/test_gp.py:24-38 (100k samples, mean / covariance within 0.015)
+    rng = np.random.default_rng(1058390)
+    X = rng.uniform(-3, 3, (50, 5))
+    gp = GaussianProcess(kernels.Matern32(1.5), X, diag=0.01, mean=np.sum)
+    assert gp.sample(543).shape == (50,)
+    assert gp.sample(543, shape=(7, 3)).shape == (7, 3, 50)
+    y = gp.sample(543, shape=(100_000,))
+    assert y.shape == (100_000, 50)
+    np.testing.assert_allclose(y.mean(axis=0), X.sum(axis=1), atol=0.015)
+    np.testing.assert_allclose(np.cov(y, rowvar=False), gp.covariance, atol=0.015)
+
+
+def test_config3_n65536_full_size_properties():
+    """BASELINE config 3 at full size (Matern-5/2, 3-D, N = 65 536, fp64; 34 GB factor): no
+    CPU oracle finishes in seconds here, so the factor is checked through the properties that
+    define it -- L^-T L^-1 (K z) = z with K z from the fused kernel mat-vec (never touches the
+    factor) -- plus finiteness of the fused log-probability."""
+    X, y, c = _cases.data_config("c3")
+    k = _cases.synthetic.config_kernel(kernels, c["kernel"])
+    gp = GaussianProcess(k, X, diag=c["diag"])
+    ll = float(gp.log_probability(y))
+    assert gp.solver.info == 0 and np.isfinite(ll)
+    _factor_property_checks(gp, X, k, c["diag"], 3)
+    assert abs(float(gp.solver.log_probability(y)) - ll) <= 1e-9 * abs(ll)  # fused == unfused

@@ -565,6 +565,25 @@ int tgp_solver_dot_tri(tgp_solver* s, int64_t nrhs, const void* y_host, void* ou
   const size_t es = esize(s->dtype);
   return dispatch(s->dtype, [&](auto tag) {
     using T = decltype(tag);
+    if (nrhs >= 8) {
+      // (L Z)^T = Z^T L^T as one MFMA GEMM: the host (n, R) row-major array IS the
+      // column-major (R x n) operand, and so is the result; the k-loop stops at the
+      // diagonal tile (TRMM), so the never-written upper tiles of L are not touched.
+      const int64_t mpad = round_up(nrhs, TILE);
+      const size_t bytes = size_t(mpad) * s->npad * es;
+      TGP_TRY(solver_scratch(s, 2 * bytes));
+      char* Zt = (char*)s->scratch;
+      char* Ct = Zt + bytes;
+      TGP_HIP_TRY(hipMemsetAsync(Zt, 0, bytes, ctx->stream));
+      TGP_HIP_TRY(hipMemcpy2DAsync(Zt, size_t(mpad) * es, y_host, size_t(nrhs) * es, size_t(nrhs) * es,
+                                   size_t(s->n), hipMemcpyHostToDevice, ctx->stream));
+      TGP_TRY(launch_gemm_nt<T>(ctx, ctx->stream, mpad, s->npad, s->npad, (const T*)Zt, mpad,
+                                (const T*)s->A, s->npad, (T*)Ct, mpad, 0, 3, 1));
+      TGP_HIP_TRY(hipMemcpy2DAsync(out_host, size_t(nrhs) * es, Ct, size_t(mpad) * es, size_t(nrhs) * es,
+                                   size_t(s->n), hipMemcpyDeviceToHost, ctx->stream));
+      TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+      return TGP_OK;
+    }
     for (int64_t r = 0; r < nrhs; ++r) {
       TGP_HIP_TRY(hipMemcpy2DAsync(s->vec, es, (const char*)y_host + r * es, size_t(nrhs) * es, es,
                                    size_t(s->n), hipMemcpyHostToDevice, ctx->stream));

@@ -58,7 +58,7 @@ struct GemmArgs {
   int tm, tn;  // tiles in m / n
   int k;
   int lower;   // only tiles with ti >= tj
-  int mode;    // 0: C -= A B^T, 1: C = A B^T
+  int mode;    // 0: C -= A B^T, 1: C = A B^T, 3: C = A B^T with B lower-triangular (k <= col)
   int nblk;    // total workgroups
 };
 
@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     }
   };
 
-  const int nkt = g.k / BK;
+  // mode 3 (TRMM): B = L is lower triangular, so column tile tj only needs k < (tj+1)*BN
+  const int nkt = (g.mode & 2) ? ((g.k < (tj + 1) * BN ? g.k : (tj + 1) * BN) / BK) : g.k / BK;
   const int lrow = lane & 15, lk = lane >> 4;
   T* Cb = g.C + (j0 + wc * 64) * g.ldc + i0 + wr * 64;
 

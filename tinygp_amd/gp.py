@@ -10,7 +10,9 @@ runs it on the MI355X.  Two deliberate departures, both invisible in the results
   reference computes them eagerly (``gp.py:201-221``) and relies on XLA dead-code
   elimination when the caller only reads ``.loc``.
 
-``sample`` / ``numpyro_dist`` are adjacent to the hot path and not provided.
+``sample`` draws its standard normals with NumPy on the host (JAX's threefry stream cannot be
+reproduced bit for bit; moments match) and multiplies by L on the device;
+``numpyro_dist`` is adjacent to the hot path and not provided.
 """
 
 from __future__ import annotations
@@ -114,6 +116,20 @@ class GaussianProcess:
             self._solver_args = (cov, self._solver_args[1])
             return cov
         return self.solver.covariance()
+
+    # -- reference gp.py:273-311 ---------------------------------------------------------
+    def sample(self, key, shape=None):
+        """Draw samples from the prior: ``mean + L z`` (reference ``gp.py:273-311``).
+
+        ``key``: an ``int`` seed or a ``numpy.random.Generator`` (the reference takes a JAX
+        PRNG key; the random stream necessarily differs, the distribution does not).
+        Returns shape ``shape + (N,)`` like the reference.
+        """
+        rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+        full = (self.num_data,) if shape is None else (self.num_data,) + tuple(shape)
+        z = rng.standard_normal(full).astype(self.dtype, copy=False)
+        out = self.solver.dot_triangular(z)
+        return self.mean + np.moveaxis(out, 0, -1)
 
     # -- reference gp.py:126-138, 313-320 ---------------------------------------------
     def log_probability(self, y):
