@@ -33,6 +33,12 @@ sys.path.insert(0, str(ROOT))
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet: FP64 matrix = FP64 vector = 78.6 TFLOP/s
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
+# HBM bytes per trailing-update launch for workload c2 / nb_outer 512, from the committed PMC
+# passes (profiles/r01_e_pmc_hbm_traffic.md: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+# separate runs, KB units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM" for wide coalesced
+# reads): (2 x 81.010 GB + 33.157 GB) / 183 launches.  PMC collection serialises kernels, so it
+# cannot run inside the timed region; other workloads report null.
+PMC_TRAFFIC_BYTES_PER_LAUNCH_C2 = (2 * 81.010e9 + 33.157e9) / 183
 
 
 def emit(obj):
@@ -290,7 +296,11 @@ def main():
             roofline = {
                 "kernel": f"gemm_nt_kernel<{'double' if dt == np.float64 else 'float'}, 0> (Cholesky trailing update)",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": None,
+                "frac": achieved / peak,
+                "traffic": (PMC_TRAFFIC_BYTES_PER_LAUNCH_C2
+                            if (args.workload == "c2" and nb_used == 512 and world == 1) else None),
+                "traffic_unit": "bytes/launch (PMC, profiles/r01_e_pmc_hbm_traffic.md)",
+                "algorithmic_bytes_per_launch": None,
                 "avg_launch_ms": acc["syrk_ms"] / launches,
                 "flops_per_launch": acc["syrk_flops"] / launches,
                 "launches_per_step": launches / args.steps,

@@ -28,14 +28,46 @@ template <> struct MathC<float> {
   static constexpr float TWO_PI = 6.283185307179586f;
 };
 
+// One leaf of the program (a stationary kernel or a constant) at the pair's distances.
+template <typename T>
+__device__ __forceinline__ T leaf_value(const KProg& kp, int i, T r1, T r2, T l2dist, T l1sq) {
+  const int op = kp.op[i];
+  const bool l2 = kp.metric[i] == TGP_METRIC_L2;
+  const T dist = l2 ? l2dist : r1;
+  const T sq = l2 ? r2 : l1sq;
+  const T p0 = T(kp.p0[i]);
+  const T p1 = T(kp.p1[i]);
+  switch (op) {
+    case TGP_K_CONST: return p0;
+    case TGP_K_EXP: return exp(-dist / p0);
+    case TGP_K_EXPSQ: return exp(T(-0.5) * (sq / (p0 * p0)));
+    case TGP_K_M32: { const T a = MathC<T>::SQRT3 * (dist / p0); return (T(1) + a) * exp(-a); }
+    case TGP_K_M52: { const T a = MathC<T>::SQRT5 * (dist / p0);
+                      return (T(1) + a + (a * a) / T(3)) * exp(-a); }
+    case TGP_K_COS: return cos(MathC<T>::TWO_PI * (dist / p0));
+    case TGP_K_ESS: { const T s = sin(MathC<T>::PI * (dist / p0)); return exp(-p1 * (s * s)); }
+    case TGP_K_RQ: return pow(T(1) + T(0.5) * (sq / (p0 * p0)) / p1, -p1);
+    default: return T(0);
+  }
+}
+
 // Evaluate the postfix program for one pair given r1 = sum|d| and r2 = sum d^2.
-// The evaluation stack lives in 8 named registers (no runtime-indexed array -> no scratch).
+// Programs of one leaf, or of two leaves and one operator (e.g. `amp**2 * ExpSquared(l)`),
+// take a direct path; anything else runs the general stack machine, whose evaluation stack
+// lives in 8 named registers (no runtime-indexed array -> no scratch).  All branches are
+// wave-uniform (the program sits in kernarg / SGPRs).
 template <typename T>
 __device__ __forceinline__ T eval_kprog(const KProg& kp, T r1, T r2) {
-  T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
   // distance.py:51-56: zero-safe sqrt; distance.py:30-38: L1 "squared" = distance^2
   const T l2dist = (r2 == T(0)) ? r1 : sqrt(r2);
   const T l1sq = r1 * r1;
+  if (kp.n == 1) return leaf_value<T>(kp, 0, r1, r2, l2dist, l1sq);
+  if (kp.n == 3 && kp.op[0] < TGP_K_ADD && kp.op[1] < TGP_K_ADD) {
+    const T a = leaf_value<T>(kp, 0, r1, r2, l2dist, l1sq);
+    const T b = leaf_value<T>(kp, 1, r1, r2, l2dist, l1sq);
+    return (kp.op[2] == TGP_K_ADD) ? (a + b) : (a * b);
+  }
+  T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
   for (int i = 0; i < kp.n; ++i) {
     const int op = kp.op[i];
     if (op >= TGP_K_ADD) {
@@ -43,24 +75,7 @@ __device__ __forceinline__ T eval_kprog(const KProg& kp, T r1, T r2) {
       s0 = r; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
       continue;
     }
-    const bool l2 = kp.metric[i] == TGP_METRIC_L2;
-    const T dist = l2 ? l2dist : r1;
-    const T sq = l2 ? r2 : l1sq;
-    const T p0 = T(kp.p0[i]);
-    const T p1 = T(kp.p1[i]);
-    T v;
-    switch (op) {
-      case TGP_K_CONST: v = p0; break;
-      case TGP_K_EXP: v = exp(-dist / p0); break;
-      case TGP_K_EXPSQ: v = exp(T(-0.5) * (sq / (p0 * p0))); break;
-      case TGP_K_M32: { const T a = MathC<T>::SQRT3 * (dist / p0); v = (T(1) + a) * exp(-a); } break;
-      case TGP_K_M52: { const T a = MathC<T>::SQRT5 * (dist / p0);
-                        v = (T(1) + a + (a * a) / T(3)) * exp(-a); } break;
-      case TGP_K_COS: v = cos(MathC<T>::TWO_PI * (dist / p0)); break;
-      case TGP_K_ESS: { const T s = sin(MathC<T>::PI * (dist / p0)); v = exp(-p1 * (s * s)); } break;
-      case TGP_K_RQ: v = pow(T(1) + T(0.5) * (sq / (p0 * p0)) / p1, -p1); break;
-      default: v = T(0);
-    }
+    const T v = leaf_value<T>(kp, i, r1, r2, l2dist, l1sq);
     s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
   }
   return s0;
