@@ -141,8 +141,8 @@ int tgp_trsm_right_lt(tgp_ctx* ctx, int dtype, int64_t m, int64_t n, const void*
                       void* B, int64_t ldb);
 
 /* C (m x n) <- beta*C + alpha * A (m x k) * B(n x k)^T, all column-major; m,n % TGP_TILE == 0,
- * k % 16 == 0; alpha,beta in {(-1,1),(1,0)}.  lower != 0: only tiles with row >= col
- * (same origin for A and B rows).  The fp64/fp32 MFMA building block (K4 trailing update,
+* k % 16 == 0; alpha,beta in {(-1,1),(1,0)}.  lower != 0: only tiles on/below the diagonal are
+ * computed (same origin for A and B rows; entries strictly above the diagonal are unspecified).  The fp64/fp32 MFMA building block (K4 trailing update,
  * K10 = A^T A at solvers/direct.py:95). */
 int tgp_gemm_nt(tgp_ctx* ctx, int dtype, int64_t m, int64_t n, int64_t k, double alpha,
                 const void* A, int64_t lda, const void* B, int64_t ldb, double beta, void* C,

@@ -88,11 +88,17 @@ def test_gemm_nt_vs_numpy(dtype, tol):
         scale = np.sqrt(k)
         got = ll.gemm_nt(A, B, C0, -1.0, 1.0, lower)
         want = C0.astype(np.float64) - A.astype(np.float64) @ B.astype(np.float64).T
-        if lower:  # only 128-tiles with row-tile >= col-tile are touched
-            ti, tj = np.arange(m)[:, None] // 128, np.arange(n)[None, :] // 128
-            mask = ti >= tj
-            np.testing.assert_allclose(got[mask], want[mask], rtol=0, atol=tol * scale * 10)
-            np.testing.assert_array_equal(got[~mask], C0[~mask])
+        if lower:
+            # tiles on/below the diagonal are updated (tile size is an implementation detail:
+            # 64 for short K, 128 otherwise); everything on/below the diagonal must be right,
+            # anything above it is either updated or untouched
+            tri = np.arange(m)[:, None] >= np.arange(n)[None, :]
+            np.testing.assert_allclose(got[tri], want[tri], rtol=0, atol=tol * scale * 10)
+            up = ~tri
+            ok = np.isclose(got[up], want[up], rtol=0, atol=tol * scale * 10) | (got[up] == C0[up])
+            assert ok.all()
+            far = (np.arange(m)[:, None] // 128) < (np.arange(n)[None, :] // 128)
+            np.testing.assert_array_equal(got[far], C0[far])
         else:
             np.testing.assert_allclose(got, want, rtol=0, atol=tol * scale * 10)
             got2 = ll.gemm_nt(A, B, C0, 1.0, 0.0, False)

@@ -94,6 +94,13 @@ __device__ __forceinline__ float readlane(float v, int lane) {
 // operand read (16 rows x 2 k) is 256 contiguous bytes: conflict-free without padding.
 __device__ __forceinline__ constexpr int blk(int i, int j) { return (i * (i + 1) / 2 + j) * 256; }
 
+#ifdef TGP_POTF2_STAMPS
+__device__ long long g_potf2_stamps[64];
+#define POTF2_STAMP(i) do { if (threadIdx.x == 0) g_potf2_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define POTF2_STAMP(i) do {} while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t ld,
                                                     T* __restrict__ dinv,
@@ -103,21 +110,28 @@ __global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t l
   using acc_t = typename M::acc_t;
   __shared__ __attribute__((aligned(16))) T S[36 * 256];
   __shared__ __attribute__((aligned(16))) T Wb[16 * 16];  // Wb[k * 16 + c] = W[c][k]
+  __shared__ T Rs[16];                                     // 1 / L_ii of the current block
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lrow = lane & 15;
   __builtin_amdgcn_s_setprio(3);
 
-  for (int e = tid; e < 36 * 256; e += 512) {
-    const int b = e >> 8, c = (e >> 4) & 15, r = e & 15;
+  POTF2_STAMP(0);
+  for (int b = w; b < 36; b += 8) {  // one 16x16 block per wave per trip, 4 elements per lane
     int i = 0;
     while ((i + 1) * (i + 2) / 2 <= b) ++i;
     const int j = b - i * (i + 1) / 2;
-    S[e] = A[int64_t(j * 16 + c) * ld + i * 16 + r];
+    const T* src = A + int64_t(j * 16) * ld + i * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = q * 64 + lane, c = e >> 4, r = e & 15;
+      S[b * 256 + e] = src[int64_t(c) * ld + r];
+    }
   }
   __syncthreads();
 
   for (int kb = 0; kb < 8; ++kb) {
     const int k0 = kb * 16;
+    POTF2_STAMP(1 + 4 * kb);
     // ---- P1: diagonal block, wave 0 (lanes 16..63 mirror lanes 0..15) ----------------
     if (w == 0) {
       const int i = lrow;
@@ -144,45 +158,55 @@ __global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t l
         const T rsj = readlane(rs, j);
         a[j] = (i >= j) ? a[j] * rsj : T(0);
       }
-      // W = L^-1, lane c owns column c: x_i = (delta_ic - sum_{k<i} L_ik x_k) / L_ii
-      T x[16];
+      // L block (zeros above the diagonal) and 1/L_ii to LDS: the inversion below reads them
+      // back as same-address broadcasts (no SGPR traffic: hoisted v_readlane results spilled)
+      if (lane < 16) {
 #pragma unroll
-      for (int ii = 0; ii < 16; ++ii) {
-        T s0 = (ii == i) ? T(1) : T(0), s1 = T(0);
+        for (int c = 0; c < 16; ++c) D[c * 16 + i] = a[c];
+        Rs[i] = rs;
+      }
+      // W = L^-1, lane c owns column c, outer-product order (short dependency chain):
+      //   x_k = s_k / L_kk ;  s_i -= L_ik x_k  (i > k)
+      T sv[16], x[16];
 #pragma unroll
-        for (int k = 0; k < ii; ++k) {
-          const T lik = readlane(a[k], ii);
-          if (k & 1) s1 -= lik * x[k];
-          else s0 -= lik * x[k];
-        }
-        x[ii] = (s0 + s1) * readlane(rs, ii);
+      for (int ii = 0; ii < 16; ++ii) sv[ii] = (ii == i) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        x[k] = sv[k] * Rs[k];
+#pragma unroll
+        for (int ii = k + 1; ii < 16; ++ii) sv[ii] -= D[k * 16 + ii] * x[k];
       }
       if (lane < 16) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          D[c * 16 + i] = a[c];
           Wb[i * 16 + c] = x[c];               // row k = i of Wb holds W[:, k]
           dinv[kb * 256 + i * 16 + c] = x[c];  // element (row c, col i) of W at i*16 + c
         }
       }
     }
+    POTF2_STAMP(2 + 4 * kb);
     __syncthreads();
+    POTF2_STAMP(3 + 4 * kb);
     // ---- P2: L_ik = A_ik W^T for the blocks below (block i -> wave (i-kb-1)) ----------
     {
       const int ib = kb + 1 + w;
       if (ib < 8) {
         T* X = &S[blk(ib, kb)];
-        acc_t acc = acc_t{0, 0, 0, 0};
+        acc_t acc = acc_t{0, 0, 0, 0}, acc2 = acc_t{0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int kk = M::drow(lane, s);
-          acc = M::mma(Wb[kk * 16 + lrow] /* W[c=lrow][kk] */, X[kk * 16 + lrow] /* A_ik[r=lrow][kk] */, acc);
+          const T wv = Wb[kk * 16 + lrow] /* W[c=lrow][kk] */, xv = X[kk * 16 + lrow] /* A_ik[r=lrow][kk] */;
+          if (s & 1) acc2 = M::mma(wv, xv, acc2);
+          else acc = M::mma(wv, xv, acc);
         }
+        acc += acc2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) X[M::drow(lane, r) * 16 + lrow] = acc[r];
       }
     }
     __syncthreads();
+    POTF2_STAMP(4 + 4 * kb);
     // ---- P3: A_ij -= L_ik L_jk^T for kb < j <= i ----------------------------------------
     {
       int cnt = 0;
@@ -192,14 +216,17 @@ __global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t l
           T* Cij = &S[blk(ib, jb)];
           const T* Xi = &S[blk(ib, kb)];
           const T* Xj = &S[blk(jb, kb)];
-          acc_t acc;
+          acc_t acc, acc2 = acc_t{0, 0, 0, 0};
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[r] = Cij[M::drow(lane, r) * 16 + lrow];
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int kk = M::drow(lane, s);
-            acc = M::mma(-Xj[kk * 16 + lrow], Xi[kk * 16 + lrow], acc);
+            const T xj = -Xj[kk * 16 + lrow], xi = Xi[kk * 16 + lrow];
+            if (s & 1) acc2 = M::mma(xj, xi, acc2);
+            else acc = M::mma(xj, xi, acc);
           }
+          acc += acc2;
 #pragma unroll
           for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] = acc[r];
         }
@@ -207,12 +234,14 @@ __global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t l
     __syncthreads();
   }
 
+  POTF2_STAMP(33);
   // write L; everything above the diagonal of the tile is zero (clean diagonal tiles)
   for (int e = tid; e < 128 * 128; e += 512) {
     const int c = e >> 7, r = e & 127;
     const int i = r >> 4, j = c >> 4;
     A[int64_t(c) * ld + r] = (r >= c) ? S[blk(i, j) + (c & 15) * 16 + (r & 15)] : T(0);
   }
+  POTF2_STAMP(34);
 }
 
 // dinv for an existing factor: one thread per (16-block, column)
@@ -253,7 +282,7 @@ __global__ __launch_bounds__(256) void trsm_kernel(int64_t m, const T* __restric
   acc_t Z[8];
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
-    acc_t acc;
+    acc_t acc, acc2 = acc_t{0, 0, 0, 0};  // two chains: MFMA latency overlaps
     T* bp = B + r0 + lrow + int64_t(jb * 16) * ldb;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = bp[int64_t(M::drow(lane, r)) * ldb];
@@ -262,15 +291,19 @@ __global__ __launch_bounds__(256) void trsm_kernel(int64_t m, const T* __restric
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const T a = L[int64_t(kb * 16 + M::drow(lane, s)) * ldl + jb * 16 + lrow];
-        acc = M::mma(a, Z[kb][s], acc);
+        if (s & 1) acc2 = M::mma(a, Z[kb][s], acc2);
+        else acc = M::mma(a, Z[kb][s], acc);
       }
     }
-    acc_t y = acc_t{0, 0, 0, 0};
+    acc += acc2;
+    acc_t y = acc_t{0, 0, 0, 0}, y2 = acc_t{0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const T a = dinv[jb * 256 + M::drow(lane, s) * 16 + lrow];
-      y = M::mma(a, acc[s], y);
+      if (s & 1) y2 = M::mma(a, acc[s], y2);
+      else y = M::mma(a, acc[s], y);
     }
+    y += y2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) bp[int64_t(M::drow(lane, r)) * ldb] = y[r];
     Z[jb] = -y;

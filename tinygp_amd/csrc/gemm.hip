@@ -239,6 +239,146 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
   }
 }
 
+// ---- small-tile variant -----------------------------------------------------------------
+// 64 x 64 x 16 tiles, 4 waves of 32 x 32.  For the short-K updates on the factorisation's
+// critical path (in-panel updates, K = 128): a 128 x 128 tile there is ONE long serial
+// k-loop per workgroup (36 us measured) however few tiles exist; quarter-size tiles spread
+// the same flops over 4x the workgroups and finish in a fraction of that.
+constexpr int SM = 64, S_LD = 80;  // 80 mod 32 == 16: conflict-free operand reads
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmArgs<T> g) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  using v2_t = typename M::v2_t;
+  __shared__ __attribute__((aligned(16))) T sA[2][BK * S_LD];
+  __shared__ __attribute__((aligned(16))) T sB[2][BK * S_LD];
+  __builtin_amdgcn_s_setprio(1);
+  int ti, tj;
+  decode_tile(blockIdx.x, g.tm, g.tn, g.lower, ti, tj);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int64_t i0 = int64_t(ti) * SM, j0 = int64_t(tj) * SM;
+  // staging: 32 lanes x 2 rows cover one 64-row k-line; thread t loads k-lines t/32 and t/32+8
+  const int l32 = tid & 31, kq = tid >> 5;
+  const T* Ag = g.A + i0 + l32 * 2;
+  const T* Bg = g.B + j0 + l32 * 2;
+  v2_t ra[2], rb[2];
+  auto load_global = [&](int kt) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int64_t kk = int64_t(kt) * BK + kq + 8 * r;
+      ra[r] = *reinterpret_cast<const v2_t*>(Ag + kk * g.lda);
+      rb[r] = *reinterpret_cast<const v2_t*>(Bg + kk * g.ldb);
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int kk = kq + 8 * r;
+      *reinterpret_cast<v2_t*>(&sA[buf][kk * S_LD + l32 * 2]) = ra[r];
+      *reinterpret_cast<v2_t*>(&sB[buf][kk * S_LD + l32 * 2]) = rb[r];
+    }
+  };
+  const int nkt = g.k / BK;
+  const int lrow = lane & 15, lk = lane >> 4;
+  T* Cb = g.C + (j0 + wc * 32) * g.ldc + i0 + wr * 32;
+
+  if constexpr (sizeof(T) == 8) {
+    const int lq = (lane >> 2) & 3, lj = lane & 3;
+    double acc[2][2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[a][b][t] = 0.0;
+    int rot[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) rot[t] = 4 * ((lq + t) & 3) + lj;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nkt) load_global(kt + 1);
+      const T* pa = &sB[buf][lk * S_LD + wc * 32 + lrow];
+      const T* pb = &sA[buf][lk * S_LD + wr * 32];
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        double aop[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) aop[a] = pa[ks * 4 * S_LD + a * 16];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          double bop[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bop[t] = pb[ks * 4 * S_LD + b * 16 + rot[t]];
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc[a][b][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aop[a], bop[t], acc[a][b][t], 0, 0, 0);
+        }
+      }
+      if (kt + 1 < nkt) store_lds(buf ^ 1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      T* col = Cb + int64_t(a * 16 + 4 * lq + lk) * g.ldc;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (g.mode == 0) col[b * 16 + rot[t]] -= acc[a][b][t];
+          else col[b * 16 + rot[t]] = acc[a][b][t];
+        }
+    }
+  } else {
+    acc_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nkt) load_global(kt + 1);
+      const T* pa = &sB[buf][lk * S_LD + wc * 32 + lrow];
+      const T* pb = &sA[buf][lk * S_LD + wr * 32 + lrow];
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        T aop[2], bop[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          aop[t] = pa[ks * 4 * S_LD + t * 16];
+          bop[t] = pb[ks * 4 * S_LD + t * 16];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = M::mma(aop[a], bop[b], acc[a][b]);
+      }
+      if (kt + 1 < nkt) store_lds(buf ^ 1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T* col = Cb + lrow + int64_t(a * 16 + M::drow(lane, r)) * g.ldc;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (g.mode == 0) col[b * 16] -= acc[a][b][r];
+          else col[b * 16] = acc[a][b][r];
+        }
+      }
+  }
+}
+
 // ---- issue-rate microbenchmarks ---------------------------------------------------------
 // kind 0: v_mfma_f64_16x16x4_f64   1: v_mfma_f32_16x16x4_f32   2: v_fma_f64 (VALU)
 //      3: MFMA f64 + VALU f64 FMA interleaved in one wave (1 MFMA : 4 FMA)
@@ -298,6 +438,21 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
                 (long long)m, (long long)n, (long long)k);
   if (m == 0 || n == 0) return TGP_OK;
   GemmArgs<T> g;
+  if (role == 1 && k <= 256 && (mode == 0 || mode == 1)) {  // short-K critical-path update
+    g.A = A; g.B = B; g.C = C;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.tm = int(m / SM); g.tn = int(n / SM);
+    g.k = int(k); g.lower = lower; g.mode = mode;
+    if (lower) {
+      if (g.tn > g.tm) g.tn = g.tm;
+      g.nblk = g.tn * g.tm - (g.tn * (g.tn - 1)) / 2;
+    } else {
+      g.nblk = g.tm * g.tn;
+    }
+    hipLaunchKernelGGL((gemm_nt_small_kernel<T>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
+    TGP_HIP_TRY(hipGetLastError());
+    return TGP_OK;
+  }
   g.A = A; g.B = B; g.C = C;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.tm = int(m / BM); g.tn = int(n / BN);
