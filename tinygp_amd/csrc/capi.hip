@@ -106,6 +106,9 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->panel_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->solve_stream, hipStreamNonBlocking, hi));
+  TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->update_stream, hipStreamNonBlocking, hi));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_e, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
@@ -128,6 +131,12 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
     hipStreamDestroy(ctx->solve_stream);
   }
   if (ctx->ev_c) hipEventDestroy(ctx->ev_c);
+  if (ctx->update_stream) {
+    hipStreamSynchronize(ctx->update_stream);
+    hipStreamDestroy(ctx->update_stream);
+  }
+  if (ctx->ev_d) hipEventDestroy(ctx->ev_d);
+  if (ctx->ev_e) hipEventDestroy(ctx->ev_e);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
   if (ctx->ev_b) hipEventDestroy(ctx->ev_b);

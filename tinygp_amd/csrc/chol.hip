@@ -105,7 +105,8 @@ template <typename T>
 __global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t ld,
                                                     T* __restrict__ dinv,
                                                     int32_t* __restrict__ info,
-                                                    int32_t pivot_base) {
+                                                    int32_t pivot_base,
+                                                    const T* __restrict__ Xp, int64_t ldx) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   __shared__ __attribute__((aligned(16))) T S[36 * 256];
@@ -125,6 +126,37 @@ __global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t l
     for (int q = 0; q < 4; ++q) {
       const int e = q * 64 + lane, c = e >> 4, r = e & 15;
       S[b * 256 + e] = src[int64_t(c) * ld + r];
+    }
+  }
+  if (Xp != nullptr) {
+    // Pending in-panel update of THIS tile, folded in so that it is not a separate kernel on
+    // the critical path:  A_tile -= Xp Xp^T  with Xp = the previous block column's 128 rows
+    // of this tile (128 x 128, column-major, ld = ldx).  One 16x16 block per wave per trip,
+    // operands straight from L2 (16 consecutive rows at fixed k = 128 contiguous bytes).
+    __syncthreads();
+    for (int b = w; b < 36; b += 8) {
+      int ib = 0;
+      while ((ib + 1) * (ib + 2) / 2 <= b) ++ib;
+      const int jb = b - ib * (ib + 1) / 2;
+      T* Cij = &S[b * 256];
+      acc_t acc, acc2 = acc_t{0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = Cij[M::drow(lane, r) * 16 + lrow];
+      const T* xj = Xp + jb * 16 + lrow;
+      const T* xi = Xp + ib * 16 + lrow;
+#pragma unroll 4
+      for (int k16 = 0; k16 < 8; ++k16) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          const int64_t kk = k16 * 16 + M::drow(lane, s2);
+          const T av = -xj[kk * ldx], bv = xi[kk * ldx];
+          if (s2 & 1) acc2 = M::mma(av, bv, acc2);
+          else acc = M::mma(av, bv, acc);
+        }
+      }
+      acc += acc2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] = acc[r];
     }
   }
   __syncthreads();
@@ -449,9 +481,10 @@ __global__ __launch_bounds__(256) void trsv_update_bwd_kernel(int64_t ncols,
 // ---------------------------------------------------------------------------------------
 template <typename T>
 int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_t* info,
-                 int32_t pivot_base) {
+                 int32_t pivot_base, const T* Xp, int64_t ldx) {
   (void)ctx;
-  hipLaunchKernelGGL((potf2_kernel<T>), dim3(1), dim3(512), 0, st, A, ld, dinv, info, pivot_base);
+  hipLaunchKernelGGL((potf2_kernel<T>), dim3(1), dim3(512), 0, st, A, ld, dinv, info, pivot_base,
+                     Xp, ldx);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -528,11 +561,18 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   std::vector<ProfSpan> spans;
   ctx->ev_used = 0;
 
+  // Panel = 128-column blocks.  Per block the critical path is potf2 -> trsm; the in-panel
+  // update of the columns to the right runs on its own stream (S3) beside the NEXT block's
+  // potf2, which folds the update of its own diagonal tile in (role 3 skips that tile).
+  hipStream_t S3 = ctx->update_stream;
   auto panel = [&](hipStream_t st, int64_t k0, int64_t kb) -> int {
     for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
       T* Ljj = A + j0 * ld + j0;
       T* dj = dinv + (j0 / TILE) * 2048;
-      TGP_TRY(launch_potf2<T>(ctx, st, Ljj, ld, dj, ctx->d_info, (int32_t)j0));
+      const bool pend = j0 > k0;  // in-panel update from block column j0-128 still in flight
+      TGP_TRY(launch_potf2<T>(ctx, st, Ljj, ld, dj, ctx->d_info, (int32_t)j0,
+                              pend ? (const T*)(A + (j0 - TILE) * ld + j0) : (const T*)nullptr, ld));
+      if (pend) TGP_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_e, 0));  // rest of that update
       const int64_t mb = n - (j0 + TILE);
       if (mb > 0) TGP_TRY(launch_trsm<T>(ctx, st, mb, Ljj, ld, dj, Ljj + TILE, ld));
       if (y != nullptr) {
@@ -541,9 +581,13 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
         TGP_TRY(launch_trsv_fwd_step<T>(S2, mb, Ljj, ld, dj, y + j0));
       }
       const int64_t nc = (k0 + kb) - (j0 + TILE);
-      if (mb > 0 && nc > 0)
-        TGP_TRY(launch_gemm_nt<T>(ctx, st, mb, nc, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
-                                  A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, 1));
+      if (mb > 0 && nc > 0) {
+        TGP_HIP_TRY(hipEventRecord(ctx->ev_d, st));
+        TGP_HIP_TRY(hipStreamWaitEvent(S3, ctx->ev_d, 0));
+        TGP_TRY(launch_gemm_nt<T>(ctx, S3, mb, nc, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
+                                  A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, 3));
+        TGP_HIP_TRY(hipEventRecord(ctx->ev_e, S3));
+      }
     }
     return TGP_OK;
   };
@@ -683,7 +727,8 @@ int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, c
 }
 
 #define TGP_INST(T)                                                                              \
-  template int launch_potf2<T>(tgp_ctx*, hipStream_t, T*, int64_t, T*, int32_t*, int32_t);       \
+  template int launch_potf2<T>(tgp_ctx*, hipStream_t, T*, int64_t, T*, int32_t*, int32_t,       \
+                               const T*, int64_t);       \
   template int launch_trsm<T>(tgp_ctx*, hipStream_t, int64_t, const T*, int64_t, const T*, T*,   \
                               int64_t);                                                          \
   template int compute_dinv<T>(tgp_ctx*, int64_t, const T*, int64_t, T*);                        \

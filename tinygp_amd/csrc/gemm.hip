@@ -60,6 +60,7 @@ struct GemmArgs {
   int lower;   // only tiles with ti >= tj
   int mode;    // 0: C -= A B^T, 1: C = A B^T, 3: C = A B^T with B lower-triangular (k <= col)
   int nblk;    // total workgroups
+  int skip00;  // small kernel: skip the 2x2 tiles of the first 128x128 diagonal block
 };
 
 // Linear workgroup id -> (ti, tj).  Tiles are enumerated column by column (tj major) so
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmArgs<T> g) {
   __builtin_amdgcn_s_setprio(1);
   int ti, tj;
   decode_tile(blockIdx.x, g.tm, g.tn, g.lower, ti, tj);
+  if (g.skip00 && ti < 2 && tj < 2) return;  // that tile is updated inside the next potf2
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1;
   const int64_t i0 = int64_t(ti) * SM, j0 = int64_t(tj) * SM;
@@ -438,7 +440,10 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
                 (long long)m, (long long)n, (long long)k);
   if (m == 0 || n == 0) return TGP_OK;
   GemmArgs<T> g;
-  if (role == 1 && k <= 256 && (mode == 0 || mode == 1)) {  // short-K critical-path update
+  g.skip00 = 0;
+  TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");
+  if ((role == 1 || role == 3) && k <= 256 && (mode == 0 || mode == 1)) {  // short-K update
+    g.skip00 = (role == 3);
     g.A = A; g.B = B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.tm = int(m / SM); g.tn = int(n / SM);

@@ -63,8 +63,9 @@ struct tgp_ctx {
   bool own_stream = false;
   hipStream_t panel_stream = nullptr;  // look-ahead panel factorisation
   hipStream_t solve_stream = nullptr;  // forward substitution overlapped with the factorisation
-  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
-  int64_t nb_outer = 512;
+  hipStream_t update_stream = nullptr;  // in-panel updates beside the next potf2
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_e = nullptr;
+  int64_t nb_outer = 1024;  // measured best for N = 4k .. 32k (profiles/r01_f_nb_sweep.txt)
   int64_t lookahead = 1;
   int64_t profile = 0;
   // small device scratch: scal[0..15] doubles, info int
@@ -102,7 +103,8 @@ int launch_kmat_gemv(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int 
                      const T* X2, const T* v, T* out);
 
 // C (m x n) = beta*C + alpha*A*B^T ; mode 0: C -= A B^T ; mode 1: C = A B^T.
-// role: 0 = trailing update (profiled as the dominant kernel), 1 = everything else.
+// role: 0 = trailing update (profiled as the dominant kernel), 1 = everything else,
+// 3 = in-panel update that skips the first 128x128 diagonal tile (potf2 folds it in).
 template <typename T>
 int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k, const T* A,
                    int64_t lda, const T* B, int64_t ldb, T* C, int64_t ldc, int lower, int mode,
@@ -110,7 +112,7 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
 
 template <typename T>
 int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_t* info,
-                 int32_t pivot_base);
+                 int32_t pivot_base, const T* Xp = nullptr, int64_t ldx = 0);
 template <typename T>
 int launch_trsm(tgp_ctx* ctx, hipStream_t st, int64_t m, const T* L, int64_t ldl, const T* dinv,
                 T* B, int64_t ldb);
