@@ -81,12 +81,15 @@ def workload_spec(name: str):
         return c
     if name.startswith("n"):
         body = name[1:]
+        dtype = "float64"
+        if body.endswith("f32"):
+            body, dtype = body[:-3], "float32"
         d = 1
         if "d" in body:
             body, ds = body.split("d")
             d = int(ds)
-        return dict(name=name, n=int(body), d=d, dtype="float64", diag=0.01,
-                    kernel="expsq" if d == 1 else "matern52")
+        return dict(name=name, n=int(body), d=d, dtype=dtype, diag=0.01 if dtype == "float64" else 0.1,
+                    kernel=("expsq" if d == 1 else "matern52") if dtype == "float64" else "sum")
     raise SystemExit(f"unknown workload {name}")
 
 

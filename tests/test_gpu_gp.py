@@ -303,3 +303,28 @@ def test_config3_n65536_full_size_properties():
     assert gp.solver.info == 0 and np.isfinite(ll)
     _factor_property_checks(gp, X, k, c["diag"], 3)
     assert abs(float(gp.solver.log_probability(y)) - ll) <= 1e-9 * abs(ll)  # fused == unfused
+
+
+def test_transforms_like_test_transforms():
+    # reference tests/test_transforms.py:10-49
+    from tinygp_amd import transforms
+
+    k0 = kernels.Matern32(4.5)
+    np.testing.assert_allclose(k0.evaluate(0.5, 0.1), transforms.Linear(1 / 4.5, kernels.Matern32()).evaluate(0.5, 0.1), **TOL)
+    np.testing.assert_allclose(k0.evaluate(0.5, 0.1), transforms.Cholesky(4.5, kernels.Matern32()).evaluate(0.5, 0.1), **TOL)
+    a, b = np.full(3, 0.5), np.full(3, 0.1)
+    np.testing.assert_allclose(k0.evaluate(a, b), transforms.Linear(np.full(3, 1 / 4.5), kernels.Matern32()).evaluate(a, b), **TOL)
+    np.testing.assert_allclose(k0.evaluate(a, b), transforms.Cholesky(np.full(3, 4.5), kernels.Matern32()).evaluate(a, b), **TOL)
+    ks = transforms.Subspace(1, kernels.Matern32())
+    np.testing.assert_allclose(ks.evaluate(np.array([0.5, 0.1]), np.array([-0.4, 0.7])),
+                               ks.evaluate(np.array([100.5, 0.1]), np.array([-70.4, 0.7])), **TOL)
+    # a whole GP through an anisotropic Linear transform == the oracle on pre-scaled inputs
+    rng = np.random.default_rng(4)
+    X = rng.uniform(-3, 3, (60, 2)); y = np.sin(X[:, 0]) + 0.2 * X[:, 1]; t = rng.uniform(-3, 3, (9, 2))
+    scale = np.array([0.5, 2.0])
+    gp = GaussianProcess(1.3 * transforms.Linear(scale, kernels.ExpSquared()), X, diag=0.05)
+    ref = o.GaussianProcess(1.3 * o.ExpSquared(), X * scale, diag=0.05)
+    np.testing.assert_allclose(gp.log_probability(y), ref.log_probability(y), rtol=LL_RTOL)
+    c, r = gp.condition(y, t), ref.condition(y, t * scale)
+    np.testing.assert_allclose(c.gp.loc, r.gp.loc, **TOL)
+    np.testing.assert_allclose(c.gp.variance, r.gp.variance, **TOL)

@@ -114,3 +114,43 @@ def test_synthetic_inputs_are_reproducible():
     assert np.all(np.diff(X) >= 0) and X.max() <= 10.24
     X3, _ = _cases.synthetic.make_inputs(4096, 3)
     assert X3.shape == (4096, 3) and X3.max() <= (40.96) ** (1 / 3)
+
+
+def test_transforms_fold_into_coordinates():
+    """transforms.* are host-side pre-transforms (reference transforms.py:23-162): the device
+    program is the inner kernel's, the coordinates are mapped."""
+    from tinygp_amd import transforms
+
+    x = np.array([0.5, 0.1, -2.0])
+    prog, P = transforms.Linear(1 / 4.5, kernels.Matern32())._lower(x)
+    assert prog == kernels.Matern32().program()
+    np.testing.assert_allclose(P.ravel(), x / 4.5)
+    prog, P = transforms.Cholesky(4.5, kernels.Matern32())._lower(x)
+    np.testing.assert_allclose(P.ravel(), x / 4.5)
+    X = np.arange(12.0).reshape(4, 3)
+    _, P = transforms.Linear(np.array([1.0, 2.0, 3.0]), kernels.Exp())._lower(X)
+    np.testing.assert_allclose(P, X * [1.0, 2.0, 3.0])
+    A = np.array([[1.0, 0.5, 0.0], [0.0, 2.0, 1.0]])
+    _, P = transforms.Linear(A, kernels.Exp())._lower(X)
+    np.testing.assert_allclose(P, X @ A.T)
+    Lf = np.array([[2.0, 0.0, 0.0], [0.3, 1.5, 0.0], [0.1, -0.2, 0.7]])
+    _, P = transforms.Cholesky(Lf, kernels.Exp())._lower(X)
+    np.testing.assert_allclose(P, np.linalg.solve(Lf, X.T).T)
+    _, P = transforms.Subspace(1, kernels.Exp())._lower(X)
+    np.testing.assert_allclose(P.ravel(), X[:, 1])
+    _, P = transforms.Subspace((0, 2), kernels.Exp())._lower(X)
+    np.testing.assert_allclose(P, X[:, [0, 2]])
+    _, P = transforms.Transform(lambda v: v**2, kernels.Exp())._lower(x)
+    np.testing.assert_allclose(P.ravel(), x**2)
+    c = transforms.Cholesky.from_parameters(np.array([2.0, 1.5]), np.array([0.3]), kernels.Exp())
+    np.testing.assert_allclose(c.factor, [[2.0, 0.0], [0.3, 1.5]])
+    with pytest.raises(ValueError):
+        transforms.Cholesky.from_parameters(np.ones(3), np.ones(2), kernels.Exp())
+    with pytest.raises(ValueError):
+        transforms.Linear(np.ones((2, 2, 2)), kernels.Exp())._lower(X)
+    # algebra around a transform keeps one coordinate set; mixing transforms is refused loudly
+    prog, P = (1.5 * transforms.Subspace(1, kernels.Matern32()) + kernels.Constant(0.2))._lower(X)
+    assert [o[0] for o in prog] == [base.K_CONST, base.K_M32, base.K_MUL, base.K_CONST, base.K_ADD]
+    np.testing.assert_allclose(P.ravel(), X[:, 1])
+    with pytest.raises(NotImplementedError):
+        (transforms.Linear(2.0, kernels.Exp()) + kernels.Exp())._lower(x)

@@ -10,6 +10,7 @@ from tinygp_amd import kernels as kernels
 from tinygp_amd import means as means
 from tinygp_amd import noise as noise
 from tinygp_amd import solvers as solvers
+from tinygp_amd import transforms as transforms
 from tinygp_amd.gp import ConditionResult as ConditionResult
 from tinygp_amd.gp import GaussianProcess as GaussianProcess
 

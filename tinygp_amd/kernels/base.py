@@ -52,6 +52,11 @@ class Kernel:
             raise ValueError(f"kernel expression too deep: stack {peak} > {KSTACK_MAX}")
         return ops
 
+    def _lower(self, X):
+        """``(program, coordinates)`` for evaluation at ``X``.  Plain kernels pass ``X``
+        through; :mod:`tinygp_amd.transforms` fold their input map into the coordinates."""
+        return self.program(), X
+
     # -- reference protocol ----------------------------------------------------
     def evaluate(self, X1, X2):
         """k(x1, x2) for ONE pair of points (reference ``base.py:38-57``).  Runs the same
@@ -61,8 +66,7 @@ class Kernel:
             raise ValueError("Kernel.evaluate takes single data points; call the kernel "
                              "instance to evaluate on arrays of points")
         dt = _device.common_dtype(x1, x2)
-        return _device.kmat(self.program(), x1.reshape(1, -1).astype(dt),
-                            x2.reshape(1, -1).astype(dt))[0, 0]
+        return self(x1.reshape(1, -1).astype(dt), x2.reshape(1, -1).astype(dt))[0, 0]
 
     def evaluate_diag(self, X):
         """Reference ``base.py:59-66``."""
@@ -77,14 +81,17 @@ class Kernel:
             X2 = None
         if X2 is None:
             X2 = X1
-        return _device.kmat_gemv(self.program(), X1, X2, y)
+        prog, P1 = self._lower(X1)
+        _, P2 = self._lower(X2)
+        return _device.kmat_gemv(prog, P1, P2, y)
 
     def __call__(self, X1, X2=None):
         """Reference ``base.py:84-103``: diagonal (N,) when ``X2`` is None, else (N1, N2)."""
-        prog = self.program()
+        prog, P1 = self._lower(X1)
         if X2 is None:
-            return _device.kdiag(prog, X1)
-        return _device.kmat(prog, X1, X2)
+            return _device.kdiag(prog, P1)
+        _, P2 = self._lower(X2)
+        return _device.kmat(prog, P1, P2)
 
     # -- algebra (reference base.py:105-126) -------------------------------------
     def __add__(self, other: Any) -> "Kernel":
@@ -111,6 +118,23 @@ class Kernel:
         return Product(Constant(other), self)
 
 
+def _lower_binary(node, op, X):
+    """Both operands must see the same device coordinates (one X per kernel matrix)."""
+    p1, X1 = node.kernel1._lower(X)
+    p2, X2 = node.kernel2._lower(X)
+    const1 = all(o[0] in (K_CONST, K_ADD, K_MUL) for o in p1)
+    const2 = all(o[0] in (K_CONST, K_ADD, K_MUL) for o in p2)
+    if not (X1 is X2 or const1 or const2 or
+            (np.shape(X1) == np.shape(X2) and np.array_equal(X1, X2))):
+        raise NotImplementedError(
+            "a Sum/Product whose operands use different input transforms cannot be evaluated "
+            "in one device pass; evaluate on the host and pass covariance_value=")
+    ops = p1 + p2 + [(op, 0, 0.0, 0.0)]
+    if len(ops) > KPROG_MAX:
+        raise ValueError(f"kernel expression too large: {len(ops)} ops > {KPROG_MAX}")
+    return ops, (X2 if const1 and not const2 else X1)
+
+
 class Sum(Kernel):
     """k1 + k2 (reference ``base.py:170-177``)."""
 
@@ -121,6 +145,9 @@ class Sum(Kernel):
         self.kernel1._emit(ops)
         self.kernel2._emit(ops)
         ops.append((K_ADD, 0, 0.0, 0.0))
+
+    def _lower(self, X):
+        return _lower_binary(self, K_ADD, X)
 
     def __repr__(self):
         return f"Sum({self.kernel1!r}, {self.kernel2!r})"
@@ -136,6 +163,9 @@ class Product(Kernel):
         self.kernel1._emit(ops)
         self.kernel2._emit(ops)
         ops.append((K_MUL, 0, 0.0, 0.0))
+
+    def _lower(self, X):
+        return _lower_binary(self, K_MUL, X)
 
     def __repr__(self):
         return f"Product({self.kernel1!r}, {self.kernel2!r})"

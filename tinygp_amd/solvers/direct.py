@@ -50,8 +50,12 @@ class DirectSolver(Solver):
         noise_diag = np.asarray(noise.diagonal())
         if covariance is not None:
             covariance = np.asarray(covariance)
+        try:  # transforms fold their input map into the coordinates the device sees
+            self._prog, Xdev = kernel._lower(X)
+        except NotImplementedError:
+            self._prog, Xdev = None, X  # e.g. kernels.Conditioned: needs covariance=
         dt = _device.common_dtype(np.asarray(X), noise_diag, covariance)
-        P = _device.points(X, dt)
+        P = _device.points(Xdev, dt)
         self.dtype = dt
         self._P = P
         self.n, self.d = P.shape
@@ -59,10 +63,6 @@ class DirectSolver(Solver):
             raise ValueError("the noise model must have one entry per data point")
         self._noise_diag = np.ascontiguousarray(noise_diag, dtype=dt)
 
-        try:
-            self._prog = kernel.program()
-        except NotImplementedError:
-            self._prog = None  # e.g. kernels.Conditioned: host-evaluated, needs covariance=
         if covariance is None and not isinstance(noise, Diagonal):
             # e.g. noise.Dense: add on the host, ship through the covariance channel
             covariance = kernel(X, X) + noise
@@ -92,7 +92,10 @@ class DirectSolver(Solver):
         if kernel is not None:
             self.kernel = kernel
             try:
-                self._prog = kernel.program()
+                self._prog, Xdev = kernel._lower(self.X)
+                if not np.array_equal(_device.points(Xdev, self.dtype), self._P):
+                    raise ValueError("refactor() cannot change the kernel's input transform: the "
+                                     "transformed coordinates are resident on the device")
             except NotImplementedError:
                 self._prog = None
             self._covariance_value = None if self._prog is not None else self._covariance_value
@@ -230,12 +233,12 @@ class DirectSolver(Solver):
 
     def _cond(self, kernel, X_test, noise_diag, var_only: bool):
         self._ensure_factor()
-        prog = kernel.program()
+        prog = self._lower_like_resident(kernel)
         kp, nops = _ffi.as_kprog(prog)
         if X_test is None:
             Pt, m = None, self.n
         else:
-            Pt = _device.points(X_test, self.dtype)
+            Pt = _device.points(kernel._lower(X_test)[1], self.dtype)
             if Pt.shape[1] != self.d:
                 raise ValueError("X_test must have the same number of input dimensions as X")
             m = Pt.shape[0]
@@ -251,6 +254,15 @@ class DirectSolver(Solver):
         if self.info:
             out[:] = np.nan
         return out
+
+    def _lower_like_resident(self, kernel):
+        """Program of ``kernel`` provided its input transform maps X onto the resident points."""
+        prog, Xdev = kernel._lower(self.X)
+        if Xdev is not self.X and not np.array_equal(_device.points(Xdev, self.dtype), self._P):
+            raise NotImplementedError(
+                "conditioning with a kernel whose input transform differs from the GP's kernel "
+                "needs a host-evaluated covariance")
+        return prog
 
     def condition(self, kernel, X_test, noise):
         """Reference ``direct.py:75-95``: ``Kss + noise - A^T A`` with ``A = L^-1 Ks``.
@@ -298,10 +310,10 @@ class DirectSolver(Solver):
 
     def conditional_mean(self, kernel, X_test, alpha):
         """``K(X_test, X) @ alpha`` fused (reference ``gp.py:357`` via ``base.py:68-82``)."""
-        Pt = _device.points(X_test, self.dtype)
+        Pt = _device.points(kernel._lower(X_test)[1], self.dtype)
         if Pt.shape[1] != self.d:
             raise ValueError("X_test must have the same number of input dimensions as X")
-        kp, nops = _ffi.as_kprog(kernel.program())
+        kp, nops = _ffi.as_kprog(self._lower_like_resident(kernel))
         a = np.ascontiguousarray(alpha, dtype=self.dtype)
         out = np.empty(Pt.shape[0], dtype=self.dtype)
         if Pt.shape[0]:
