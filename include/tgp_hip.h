@@ -204,6 +204,14 @@ int tgp_solver_set_resid(tgp_solver* s, const void* resid_host);
 int tgp_solver_logprob(tgp_solver* s, const void* resid_host, double* out);
 /* GaussianProcess._condition (gp.py:330-334): alpha = K^-1 resid (host, (n,)) and log-prob */
 int tgp_solver_alpha(tgp_solver* s, const void* resid_host, void* alpha_host, double* logprob);
+/* Gradient of log_probability (what the reference's callers obtain with jax.value_and_grad,
+ * docs/tutorials/quickstart.ipynb cell 4):  1/2 tr((alpha alpha^T - K^-1) dK/dtheta).
+ * grad_params: 2*nops doubles, [2*i + q] = d ll / d (p0 if q==0 else p1) of program op i (0 for
+ * ADD/MUL and unused p1); grad_noise_host (n,) = d ll / d noise_i = 1/2 (alpha_i^2 - K^-1_ii), or
+ * NULL; alpha_host (n,) = K^-1 resid = d ll / d mean_i, or NULL.  Needs tgp_solver_factor first;
+ * allocates two more n_pad^2 buffers (L^-T and K^-1) on first use. */
+int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, double* grad_params,
+                    void* grad_noise_host, void* alpha_host);
 /* mean = K(Xt, X) alpha (gp.py:353-357; K9 fused). Xt host (m,d) row-major */
 int tgp_solver_cond_mean(tgp_solver* s, const tgp_kop* prog, int nops, int64_t m,
                          const void* Xt_host, const void* alpha_host, void* mean_host);

@@ -1,0 +1,46 @@
+"""TEST INFRASTRUCTURE: gradient of the GP log-probability in NumPy.
+
+The reference has no explicit gradient code -- its users differentiate ``log_probability``
+with JAX autodiff (docs/tutorials/quickstart.ipynb cell 4) -- so this oracle states the
+textbook identity
+    d ll / d theta = 1/2 alpha^T (dK/dtheta) alpha - 1/2 tr(K^-1 dK/dtheta),  alpha = K^-1 r,
+with dK/dtheta taken by central differences of the ORACLE's own kernel matrix, and
+cross-checks it against central differences of the oracle's log-likelihood itself.
+"""
+import numpy as np
+
+from oracle import tinygp_np as o
+
+
+def log_probability_and_grad(build, theta, X, diag, y, *, rel_step=1e-6):
+    """build(theta) -> oracle kernel.  Returns (ll, grad_theta, grad_noise_diag, grad_mean)."""
+    theta = np.asarray(theta, dtype=np.float64)
+    diag = np.broadcast_to(np.asarray(diag, dtype=np.float64), (len(y),))
+    K = build(theta)(X, X) + np.diag(diag)
+    Kinv = np.linalg.inv(K)
+    alpha = Kinv @ y
+    ll = float(o.GaussianProcess(build(theta), X, diag=diag).log_probability(y))
+    G = np.outer(alpha, alpha) - Kinv
+    g = np.empty_like(theta)
+    for p in range(len(theta)):
+        h = rel_step * max(1.0, abs(theta[p]))
+        tp, tm = theta.copy(), theta.copy()
+        tp[p] += h
+        tm[p] -= h
+        dK = (build(tp)(X, X) - build(tm)(X, X)) / (2 * h)
+        g[p] = 0.5 * np.sum(G * dK)
+    return ll, g, 0.5 * np.diag(G), alpha
+
+
+def finite_difference_grad(build, theta, X, diag, y, *, rel_step=1e-5):
+    theta = np.asarray(theta, dtype=np.float64)
+    g = np.empty_like(theta)
+    for p in range(len(theta)):
+        h = rel_step * max(1.0, abs(theta[p]))
+        tp, tm = theta.copy(), theta.copy()
+        tp[p] += h
+        tm[p] -= h
+        lp = float(o.GaussianProcess(build(tp), X, diag=diag).log_probability(y))
+        lm = float(o.GaussianProcess(build(tm), X, diag=diag).log_probability(y))
+        g[p] = (lp - lm) / (2 * h)
+    return g

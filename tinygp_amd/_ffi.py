@@ -88,6 +88,7 @@ SIGNATURES = {
     "tgp_solver_set_resid": [_vp, _vp],
     "tgp_solver_logprob": [_vp, _vp, _pdbl],
     "tgp_solver_alpha": [_vp, _vp, _vp, _pdbl],
+    "tgp_solver_grad": [_vp, _vp, _pdbl, _pdbl, _vp, _vp],
     "tgp_solver_cond_mean": [_vp, _pkop, _int, _i64, _vp, _vp, _vp],
     "tgp_solver_condition_cov": [_vp, _pkop, _int, _i64, _vp, _vp, _int, _vp],
     "tgp_solver_covariance": [_vp, _vp],

@@ -58,6 +58,8 @@ struct tgp_solver {
   void* vec2 = nullptr;
   void* resid = nullptr;  // resident residual (tgp_solver_set_resid)
   void* scratch = nullptr;  // per-solver workspace (multi-RHS / conditional products)
+  void* Minv = nullptr;     // L^-T (gradient path), npad x npad, allocated on first use
+  void* Kinv = nullptr;     // K^-1 lower tiles (gradient path)
   size_t scratch_bytes = 0;
   KProg kp{};
   bool has_prog = false, factored = false, has_resid = false;
@@ -395,7 +397,7 @@ int tgp_solver_destroy(tgp_solver* s) {
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
   }
-  void* bufs[] = {s->X, s->diag, s->A, s->dinv, s->vec, s->vec2, s->resid, s->scratch};
+  void* bufs[] = {s->X, s->diag, s->A, s->dinv, s->vec, s->vec2, s->resid, s->scratch, s->Minv, s->Kinv};
   for (void* b : bufs)
     if (b) hipFree(b);
   delete s;
@@ -672,6 +674,55 @@ int tgp_solver_alpha(tgp_solver* s, const void* resid_host, void* alpha_host, do
   TGP_HIP_TRY(hipMemcpyAsync(alpha_host, s->vec, size_t(s->n) * esize(s->dtype),
                              hipMemcpyDeviceToHost, ctx->stream));
   TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TGP_OK;
+}
+
+// Gradient of the log-probability (the reference gets it from JAX autodiff through
+// cholesky):  d ll / d theta = 1/2 sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij / d theta.
+int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, double* grad_params,
+                    void* grad_noise_host, void* alpha_host) {
+  SOLVER_GUARD(s);
+  NEED_FACTOR(s);
+  TGP_ARG_CHECK(s->has_prog, "gradients need a kernel program (not a host covariance)");
+  TGP_ARG_CHECK(logprob && grad_params, "null output pointer");
+  tgp_ctx* ctx = s->ctx;
+  const size_t es = esize(s->dtype);
+  const size_t mat = size_t(s->npad) * s->npad * es;
+  if (!s->Minv) TGP_HIP_TRY(hipMalloc(&s->Minv, mat));
+  if (!s->Kinv) TGP_HIP_TRY(hipMalloc(&s->Kinv, mat));
+  TGP_TRY(logprob_device(s, resid_host, logprob));  // s->vec = L^-1 r
+  std::vector<double> g(size_t(2 * s->kp.n), 0.0);
+  TGP_TRY(dispatch(s->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const T* L = (const T*)s->A;
+    T* alpha = (T*)s->vec;
+    TGP_TRY(trsv<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, 1, alpha));  // alpha = K^-1 r
+    TGP_TRY(tri_inverse_t<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, (T*)s->Minv, s->npad));
+    // K^-1 = L^-T L^-1 = M M^T, lower tiles, k-loop from the row tile (M upper triangular)
+    TGP_TRY(launch_gemm_nt<T>(ctx, ctx->stream, s->npad, s->npad, s->npad, (const T*)s->Minv, s->npad,
+                              (const T*)s->Minv, s->npad, (T*)s->Kinv, s->npad, 1, 5, 1));
+    for (int i = 0; i < s->kp.n; ++i) {
+      const int op = s->kp.op[i];
+      if (op >= TGP_K_ADD) continue;
+      const int nparam = (op == TGP_K_ESS || op == TGP_K_RQ) ? 2 : 1;
+      for (int q = 0; q < nparam; ++q) {
+        TGP_TRY(launch_kgrad<T>(ctx, s->kp, i, q, s->n, s->d, (const T*)s->X, (const T*)alpha,
+                                (const T*)s->Kinv, s->npad, ctx->d_scal + 2));
+        TGP_HIP_TRY(hipMemcpyAsync(&g[size_t(2 * i + q)], ctx->d_scal + 2, sizeof(double),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+      }
+    }
+    if (grad_noise_host) {
+      TGP_TRY(launch_noise_grad<T>(ctx, s->n, (const T*)alpha, (const T*)s->Kinv, s->npad, (T*)s->vec2));
+      TGP_HIP_TRY(hipMemcpyAsync(grad_noise_host, s->vec2, size_t(s->n) * es, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    }
+    if (alpha_host)
+      TGP_HIP_TRY(hipMemcpyAsync(alpha_host, alpha, size_t(s->n) * es, hipMemcpyDeviceToHost, ctx->stream));
+    return TGP_OK;
+  }));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < g.size(); ++i) grad_params[i] = g[i];
   return TGP_OK;
 }
 

@@ -726,7 +726,49 @@ int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, c
   return TGP_OK;
 }
 
+// M (n x n, column-major, zero-initialised by the caller) <- L^-T (upper triangular).
+// Same right-sided sweep as trsm_right_lt applied to B = I, with the row range clipped:
+// column block j of L^-T is non-zero only in rows < (j+1)*128, so every solve / update
+// touches just the rows that can be non-zero -> n^3/3 flops instead of n^3.
+template <typename T>
+__global__ __launch_bounds__(256) void set_identity_kernel(int64_t n, T* __restrict__ M, int64_t ld) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) M[i * ld + i] = T(1);
+}
+
+template <typename T>
+int tri_inverse_t(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* dinv, T* M,
+                  int64_t ldm) {
+  TGP_ARG_CHECK(n % TILE == 0, "tri_inverse_t: n must be a multiple of %d", TILE);
+  hipStream_t st = ctx->stream;
+  TGP_HIP_TRY(hipMemsetAsync(M, 0, size_t(ldm) * size_t(n) * sizeof(T), st));
+  hipLaunchKernelGGL((set_identity_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                     n, M, ldm);
+  int64_t NB = ctx->nb_outer;
+  if (NB < TILE) NB = TILE;
+  NB = NB / TILE * TILE;
+  for (int64_t k0 = 0; k0 < n; k0 += NB) {
+    const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
+    for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
+      const int64_t mr = j0 + TILE;  // rows that can be non-zero in column block j0
+      TGP_TRY(launch_trsm<T>(ctx, st, mr, L + j0 * ldl + j0, ldl, dinv + (j0 / TILE) * 2048,
+                             M + j0 * ldm, ldm));
+      const int64_t nc = (k0 + kb) - (j0 + TILE);
+      if (nc > 0)
+        TGP_TRY(launch_gemm_nt<T>(ctx, st, mr, nc, TILE, M + j0 * ldm, ldm,
+                                  L + j0 * ldl + j0 + TILE, ldl, M + (j0 + TILE) * ldm, ldm, 0, 0, 1));
+    }
+    const int64_t next = k0 + kb, nr = n - next;
+    if (nr > 0)
+      TGP_TRY(launch_gemm_nt<T>(ctx, st, next, nr, kb, M + k0 * ldm, ldm, L + k0 * ldl + next, ldl,
+                                M + next * ldm, ldm, 0, 0, 1));
+  }
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
 #define TGP_INST(T)                                                                              \
+  template int tri_inverse_t<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, T*, int64_t);    \
   template int launch_potf2<T>(tgp_ctx*, hipStream_t, T*, int64_t, T*, int32_t*, int32_t,       \
                                const T*, int64_t);       \
   template int launch_trsm<T>(tgp_ctx*, hipStream_t, int64_t, const T*, int64_t, const T*, T*,   \

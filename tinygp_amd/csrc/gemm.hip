@@ -58,7 +58,8 @@ struct GemmArgs {
   int tm, tn;  // tiles in m / n
   int k;
   int lower;   // only tiles with ti >= tj
-  int mode;    // 0: C -= A B^T, 1: C = A B^T, 3: C = A B^T with B lower-triangular (k <= col)
+  int mode;    // bit0: 0 = C -= A B^T, 1 = C = A B^T; bit1 (TRMM): B lower-triangular, k < end of
+               // the column tile; bit2: A, B upper-triangular (M M^T), k starts at the ROW tile
   int nblk;    // total workgroups
   int skip00;  // small kernel: skip the 2x2 tiles of the first 128x128 diagonal block
 };
@@ -132,6 +133,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 
   // mode 3 (TRMM): B = L is lower triangular, so column tile tj only needs k < (tj+1)*BN
   const int nkt = (g.mode & 2) ? ((g.k < (tj + 1) * BN ? g.k : (tj + 1) * BN) / BK) : g.k / BK;
+  // mode bit 2: rows of an upper-triangular operand are zero left of the diagonal, so a
+  // lower tile (ti >= tj) of M M^T only needs k >= ti*BM
+  const int kt0 = (g.mode & 4) ? (ti * BM) / BK : 0;
   const int lrow = lane & 15, lk = lane >> 4;
   T* Cb = g.C + (j0 + wc * 64) * g.ldc + i0 + wr * 64;
 
@@ -155,10 +159,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) rot[t] = 4 * ((lq + t) & 3) + lj;
 
-    load_global(0);
-    store_lds(0);
+    load_global(kt0);
+    store_lds(kt0 & 1);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt0; kt < nkt; ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < nkt) load_global(kt + 1);
       const T* pa = &sB[buf][lk * LDS_LD + wc * 64 + lrow];
@@ -201,10 +205,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
 
-    load_global(0);
-    store_lds(0);
+    load_global(kt0);
+    store_lds(kt0 & 1);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt0; kt < nkt; ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < nkt) load_global(kt + 1);
       const T* pa = &sB[buf][lk * LDS_LD + wc * 64 + lrow];  // MFMA A operand <- B rows (C col)

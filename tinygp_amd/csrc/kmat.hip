@@ -81,6 +81,63 @@ __device__ __forceinline__ T eval_kprog(const KProg& kp, T r1, T r2) {
   return s0;
 }
 
+// d(leaf)/d(param) at the pair's distances: param 0 = p0 (scale or constant), 1 = p1
+// (gamma / alpha).  Derived from the forms of kernels/stationary.py:76-235.
+template <typename T>
+__device__ __forceinline__ T leaf_deriv(const KProg& kp, int i, int param, T r1, T r2, T l2dist,
+                                        T l1sq) {
+  const int op = kp.op[i];
+  const bool l2 = kp.metric[i] == TGP_METRIC_L2;
+  const T dist = l2 ? l2dist : r1;
+  const T sq = l2 ? r2 : l1sq;
+  const T p0 = T(kp.p0[i]);
+  const T p1 = T(kp.p1[i]);
+  switch (op) {
+    case TGP_K_CONST: return param == 0 ? T(1) : T(0);
+    case TGP_K_EXP: return param == 0 ? exp(-dist / p0) * dist / (p0 * p0) : T(0);
+    case TGP_K_EXPSQ: return param == 0 ? exp(T(-0.5) * (sq / (p0 * p0))) * sq / (p0 * p0 * p0) : T(0);
+    case TGP_K_M32: { const T a = MathC<T>::SQRT3 * (dist / p0);
+                      return param == 0 ? a * a * exp(-a) / p0 : T(0); }
+    case TGP_K_M52: { const T a = MathC<T>::SQRT5 * (dist / p0);
+                      return param == 0 ? (a * a / T(3)) * (T(1) + a) * exp(-a) / p0 : T(0); }
+    case TGP_K_COS: { const T u = MathC<T>::TWO_PI * (dist / p0);
+                      return param == 0 ? sin(u) * u / p0 : T(0); }
+    case TGP_K_ESS: { const T u = MathC<T>::PI * (dist / p0);
+                      const T sn = sin(u), v = exp(-p1 * (sn * sn));
+                      return param == 0 ? v * p1 * T(2) * sn * cos(u) * u / p0 : -(sn * sn) * v; }
+    case TGP_K_RQ: { const T q = T(0.5) * (sq / (p0 * p0)) / p1;  // r^2 / (2 alpha l^2)
+                     const T u = T(1) + q, v = pow(u, -p1);
+                     return param == 0 ? v / u * sq / (p0 * p0 * p0) : v * (q / u - log(u)); }
+    default: return T(0);
+  }
+}
+
+// Forward-mode derivative of the whole program with respect to ONE leaf parameter: the stack
+// carries (value, derivative) pairs; only leaf `which_op` seeds a non-zero derivative.
+template <typename T>
+__device__ __forceinline__ T eval_kprog_deriv(const KProg& kp, int which_op, int which_param, T r1,
+                                              T r2) {
+  const T l2dist = (r2 == T(0)) ? r1 : sqrt(r2);
+  const T l1sq = r1 * r1;
+  T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+  T d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, d6 = 0, d7 = 0;
+  for (int i = 0; i < kp.n; ++i) {
+    const int op = kp.op[i];
+    if (op >= TGP_K_ADD) {
+      const T v = (op == TGP_K_ADD) ? (s1 + s0) : (s1 * s0);
+      const T dv = (op == TGP_K_ADD) ? (d1 + d0) : (d1 * s0 + s1 * d0);
+      s0 = v; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
+      d0 = dv; d1 = d2; d2 = d3; d3 = d4; d4 = d5; d5 = d6; d6 = d7;
+      continue;
+    }
+    const T v = leaf_value<T>(kp, i, r1, r2, l2dist, l1sq);
+    const T dv = (i == which_op) ? leaf_deriv<T>(kp, i, which_param, r1, r2, l2dist, l1sq) : T(0);
+    s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
+    d7 = d6; d6 = d5; d5 = d4; d4 = d3; d3 = d2; d2 = d1; d1 = d0; d0 = dv;
+  }
+  return d0;
+}
+
 constexpr int KT = 128;  // tile edge
 
 // D = 0: dynamic dimension (coordinates re-read from LDS); D > 0: row point in registers.
@@ -142,6 +199,84 @@ __global__ __launch_bounds__(256) void kmat_kernel(KProg kp, int64_t n1, int64_t
     }
     out[gj * ld + gi] = v;
   }
+}
+
+// One lower 128x128 tile: sum of w_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta, w = 1/2 on the
+// diagonal, 1 strictly below it, 0 above (the 1/2 of 1/2 tr(G dK) folded with symmetry).
+// partial[tile] gets the tile's sum; fixed LDS tree -> deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void kgrad_kernel(KProg kp, int which_op, int which_param,
+                                                    int64_t n, int d, const T* __restrict__ X,
+                                                    const T* __restrict__ alpha,
+                                                    const T* __restrict__ Kinv, int64_t ld,
+                                                    double* __restrict__ partial) {
+  const int tr = blockIdx.x, tc = blockIdx.y;
+  const int tile_id = tr * gridDim.y + tc;
+  if (tr < tc) {
+    if (threadIdx.x == 0) partial[tile_id] = 0.0;
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* s1 = reinterpret_cast<T*>(smem);  // [KT][d]
+  T* s2 = s1 + KT * d;                 // [KT][d]
+  __shared__ double red[256];
+  const int64_t r0 = int64_t(tr) * KT, c0 = int64_t(tc) * KT;
+  for (int t = threadIdx.x; t < KT * d; t += 256) {
+    const int64_t gi = r0 + t / d, gj = c0 + t / d;
+    s1[t] = (gi < n) ? X[gi * d + t % d] : T(0);
+    s2[t] = (gj < n) ? X[gj * d + t % d] : T(0);
+  }
+  __syncthreads();
+  const int il = threadIdx.x & (KT - 1), g = threadIdx.x >> 7;
+  const int64_t gi = r0 + il;
+  const T ai = (gi < n) ? alpha[gi] : T(0);
+  double acc = 0.0;
+  if (gi < n) {
+    for (int c = 0; c < KT / 2; ++c) {
+      const int jl = g * (KT / 2) + c;
+      const int64_t gj = c0 + jl;
+      if (gj >= n || gj > gi) continue;
+      T r1 = 0, r2 = 0;
+      for (int t = 0; t < d; ++t) {
+        const T dx = s1[il * d + t] - s2[jl * d + t];
+        r1 += fabs(dx);
+        r2 += dx * dx;
+      }
+      const T dk = eval_kprog_deriv<T>(kp, which_op, which_param, r1, r2);
+      const T gij = ai * alpha[gj] - Kinv[gj * ld + gi];
+      acc += double(gij) * double(dk) * (gi == gj ? 0.5 : 1.0);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[tile_id] = red[0];
+}
+
+__global__ __launch_bounds__(1024) void sum_partials_kernel(int64_t count, const double* __restrict__ partial,
+                                                            double* __restrict__ out) {
+  __shared__ double red[1024];
+  double acc = 0;
+  for (int64_t i = threadIdx.x; i < count; i += 1024) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = 512; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0];
+}
+
+// d loglik / d noise_i = 1/2 (alpha_i^2 - Kinv_ii)
+template <typename T>
+__global__ __launch_bounds__(256) void noise_grad_kernel(int64_t n, const T* __restrict__ alpha,
+                                                         const T* __restrict__ Kinv, int64_t ld,
+                                                         T* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) out[i] = T(0.5) * (alpha[i] * alpha[i] - Kinv[i * ld + i]);
 }
 
 template <typename T>
@@ -298,7 +433,34 @@ int launch_kmat_gemv(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int 
   return TGP_OK;
 }
 
+template <typename T>
+int launch_kgrad(tgp_ctx* ctx, const KProg& kp, int which_op, int which_param, int64_t n, int d,
+                 const T* X, const T* alpha, const T* Kinv, int64_t ld, double* out_dev) {
+  const int64_t tiles = (n + KT - 1) / KT;
+  TGP_ARG_CHECK(tiles <= 65535, "kgrad: too many tiles");
+  TGP_TRY(ensure_work(ctx, size_t(tiles) * tiles * sizeof(double)));
+  double* partial = static_cast<double*>(ctx->d_work);
+  const size_t shmem = 2 * size_t(KT) * d * sizeof(T);
+  hipLaunchKernelGGL((kgrad_kernel<T>), dim3((unsigned)tiles, (unsigned)tiles), dim3(256), shmem,
+                     ctx->stream, kp, which_op, which_param, n, d, X, alpha, Kinv, ld, partial);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream, tiles * tiles, partial,
+                     out_dev);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+template <typename T>
+int launch_noise_grad(tgp_ctx* ctx, int64_t n, const T* alpha, const T* Kinv, int64_t ld, T* out) {
+  hipLaunchKernelGGL((noise_grad_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     ctx->stream, n, alpha, Kinv, ld, out);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
 #define TGP_INST(T)                                                                               \
+  template int launch_kgrad<T>(tgp_ctx*, const KProg&, int, int, int64_t, int, const T*, const T*, \
+                               const T*, int64_t, double*);                                       \
+  template int launch_noise_grad<T>(tgp_ctx*, int64_t, const T*, const T*, int64_t, T*);          \
   template int launch_kmat<T>(tgp_ctx*, const KProg&, int64_t, int64_t, int, const T*, const T*,  \
                               const T*, T*, int64_t, int64_t, int64_t, int);                      \
   template int launch_kdiag<T>(tgp_ctx*, const KProg&, int64_t, int, const T*, const T*, T*);     \

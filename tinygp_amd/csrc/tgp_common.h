@@ -127,6 +127,8 @@ int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, c
 template <typename T>
 int gemv_sub(tgp_ctx* ctx, int64_t m, int64_t k, const T* P, int64_t ld, const T* x, T* y);
 template <typename T>
+int tri_inverse_t(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* dinv, T* M, int64_t ldm);
+template <typename T>
 int compute_dinv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* dinv);
 
 // reductions into ctx->d_scal[slot] (device), deterministic order
@@ -146,6 +148,14 @@ int launch_set_lower_from_rowmajor(tgp_ctx* ctx, int64_t n, int64_t npad, const 
                                    int64_t ld);
 template <typename T>
 int launch_add_diag(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, const T* diag);
+
+// gradient of the log-probability (row 8f-1): partial[pass][block] sums of
+//   w_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta over the lower triangle, w = 1/2 on the diagonal
+template <typename T>
+int launch_kgrad(tgp_ctx* ctx, const KProg& kp, int which_op, int which_param, int64_t n, int d,
+                 const T* X, const T* alpha, const T* Kinv, int64_t ld, double* out_dev);
+template <typename T>
+int launch_noise_grad(tgp_ctx* ctx, int64_t n, const T* alpha, const T* Kinv, int64_t ld, T* out);
 
 int ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops);
 int ubench(tgp_ctx* ctx, int kind, int blocks_per_cu, double* tflops, double* cycles_per_op);

@@ -140,6 +140,11 @@ class GaussianProcess:
             return fused(resid)
         return self._compute_log_prob(self.solver.solve_triangular(resid))
 
+    def log_probability_and_grad(self, y):
+        """``(log_probability, grads)``; see :meth:`solvers.DirectSolver.log_probability_and_grad`.
+        ``grads["kernel"]`` follows ``self.kernel.parameters()``."""
+        return self.solver.log_probability_and_grad(self._residual(y))
+
     def _residual(self, y):
         y = np.asarray(y)
         try:

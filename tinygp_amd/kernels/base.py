@@ -52,6 +52,18 @@ class Kernel:
             raise ValueError(f"kernel expression too deep: stack {peak} > {KSTACK_MAX}")
         return ops
 
+    def _slots(self, out: list) -> None:
+        """Append, per program op, ``[(obj, attr) | None, (obj, attr) | None]`` naming the
+        Python attributes behind the op's ``p0`` / ``p1`` (same order as :meth:`_emit`)."""
+        raise NotImplementedError(f"{type(self).__name__} has no differentiable parameters")
+
+    def parameters(self) -> list[tuple[Any, str]]:
+        """The kernel's scalar hyper-parameters as ``(object, attribute)`` pairs, in program
+        order -- the order of the ``"kernel"`` entry of ``log_probability_and_grad``."""
+        slots: list = []
+        self._slots(slots)
+        return [s for pair in slots for s in pair if s is not None]
+
     def _lower(self, X):
         """``(program, coordinates)`` for evaluation at ``X``.  Plain kernels pass ``X``
         through; :mod:`tinygp_amd.transforms` fold their input map into the coordinates."""
@@ -149,6 +161,11 @@ class Sum(Kernel):
     def _lower(self, X):
         return _lower_binary(self, K_ADD, X)
 
+    def _slots(self, out):
+        self.kernel1._slots(out)
+        self.kernel2._slots(out)
+        out.append([None, None])
+
     def __repr__(self):
         return f"Sum({self.kernel1!r}, {self.kernel2!r})"
 
@@ -167,6 +184,11 @@ class Product(Kernel):
     def _lower(self, X):
         return _lower_binary(self, K_MUL, X)
 
+    def _slots(self, out):
+        self.kernel1._slots(out)
+        self.kernel2._slots(out)
+        out.append([None, None])
+
     def __repr__(self):
         return f"Product({self.kernel1!r}, {self.kernel2!r})"
 
@@ -182,6 +204,9 @@ class Constant(Kernel):
         if np.ndim(self.value) != 0:
             raise ValueError("The value of a constant kernel must be a scalar")
         ops.append((K_CONST, 0, float(self.value), 0.0))
+
+    def _slots(self, out):
+        out.append([(self, "value"), None])
 
     def __repr__(self):
         return f"Constant({self.value!r})"

@@ -34,8 +34,13 @@ class Stationary(base.Kernel):
         self.scale = scale
         self.distance = self._default_distance() if distance is None else distance
 
+    _extra_name: str | None = None
+
     def _extra(self) -> float:
         return 0.0
+
+    def _slots(self, out):
+        out.append([(self, "scale"), (self, self._extra_name) if self._extra_name else None])
 
     def _emit(self, ops):
         if np.ndim(self.scale) != 0:
@@ -88,6 +93,7 @@ class ExpSineSquared(Stationary):
     """exp(-Gamma sin^2(pi r)), reference ``stationary.py:178-205``; ``gamma`` is required."""
 
     _op = base.K_ESS
+    _extra_name = "gamma"
 
     def __init__(self, scale=1.0, distance: Distance | None = None, gamma=None):
         super().__init__(scale, distance)
@@ -105,6 +111,7 @@ class RationalQuadratic(Stationary):
     """(1 + r^2 / 2 alpha)^-alpha, reference ``stationary.py:208-235``; ``alpha`` is required."""
 
     _op = base.K_RQ
+    _extra_name = "alpha"
 
     def __init__(self, scale=1.0, distance: Distance | None = None, alpha=None):
         super().__init__(scale, distance)

@@ -293,6 +293,36 @@ class DirectSolver(Solver):
             v = -np.inf
         return self.dtype.type(v)
 
+    def log_probability_and_grad(self, resid):
+        """``(log_probability, grads)`` with ``grads = {"kernel": [...], "noise_diag": (N,),
+        "mean": (N,)}``: derivatives with respect to ``kernel.parameters()`` (same order), to
+        every noise variance, and to every entry of the mean vector (= K^-1 r).  The
+        reference's users get this from ``jax.value_and_grad`` around ``log_probability``
+        (docs/tutorials/quickstart.ipynb); here it is
+        ``1/2 tr((alpha alpha^T - K^-1) dK/dtheta)`` with ``K^-1 = L^-T L^-1`` formed by a
+        clipped triangular sweep + one MFMA GEMM, and dK/dtheta evaluated tile by tile."""
+        self._ensure_factor()
+        if self._prog is None:
+            raise NotImplementedError("gradients need an on-device kernel program")
+        slots: list = []
+        self.kernel._slots(slots)
+        r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
+        nops = len(self._prog)
+        gp_ = (C.c_double * (2 * nops))()
+        gnoise = np.empty(self.n, dtype=self.dtype)
+        alpha = np.empty(self.n, dtype=self.dtype)
+        out = C.c_double()
+        _ffi.check(_ffi.lib().tgp_solver_grad(self._handle, _ffi.ptr(r), C.byref(out), gp_,
+                                              _ffi.ptr(gnoise), _ffi.ptr(alpha)), "tgp_solver_grad")
+        kgrad = [gp_[2 * i + q] for i, pair in enumerate(slots) for q in (0, 1) if pair[q] is not None]
+        ll = out.value
+        if self.info or not np.isfinite(ll):
+            ll = -np.inf
+            kgrad = [np.nan] * len(kgrad)
+            gnoise[:] = np.nan
+            alpha[:] = np.nan
+        return self.dtype.type(ll), {"kernel": kgrad, "noise_diag": gnoise, "mean": alpha}
+
     def alpha(self, resid):
         """``(K^-1 r, log_probability)`` -- the two solves of reference ``gp.py:330-334``."""
         self._ensure_factor()

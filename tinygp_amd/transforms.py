@@ -38,6 +38,9 @@ class _PreTransform(Kernel):
         raise NotImplementedError(
             f"{type(self).__name__} carries an input transform: lower it with _lower(X)")
 
+    def _slots(self, out):  # gradients flow to the inner kernel's parameters only
+        self.kernel._slots(out)
+
 
 class Transform(_PreTransform):
     """Apply ``transform`` (one coordinate -> one coordinate) before ``kernel``
