@@ -161,22 +161,29 @@ __global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t l
   }
   __syncthreads();
 
-  for (int kb = 0; kb < 8; ++kb) {
+  // P1 for diagonal block kb (wave 0 only; lanes 16..63 mirror lanes 0..15)
+  auto factor_diag = [&](int kb) {
     const int k0 = kb * 16;
-    POTF2_STAMP(1 + 4 * kb);
-    // ---- P1: diagonal block, wave 0 (lanes 16..63 mirror lanes 0..15) ----------------
-    if (w == 0) {
       const int i = lrow;
       T* D = &S[blk(kb, kb)];
       T a[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = D[c * 16 + i];
+      // The pivot of column j+1 is predicted from scalars that exist BEFORE the vector update
+      // of step j lands (d_{j+1} = a_{j+1,j+1} - a_{j+1,j}^2 / d_j), so the reciprocal chain
+      // -- the critical path of the 16 sequential columns -- never waits for a VALU -> readlane
+      // round trip; the vector updates run in its shadow.
       int bad = 0;
+      T d = readlane(a[0], 0);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const T d = readlane(a[j], j);
         if (!(d > T(0)) && bad == 0) bad = j + 1;
-        const T v = a[j] * fast_rcp(d);
+        const T rinv = fast_rcp(d);
+        if (j + 1 < 16) {
+          const T t = readlane(a[j], j + 1), u = readlane(a[j + 1], j + 1);
+          d = u - (t * t) * rinv;
+        }
+        const T v = a[j] * rinv;
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) a[c] -= v * readlane(a[j], c);
       }
@@ -215,7 +222,11 @@ __global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t l
           dinv[kb * 256 + i * 16 + c] = x[c];  // element (row c, col i) of W at i*16 + c
         }
       }
-    }
+      };
+
+  if (w == 0) factor_diag(0);
+  for (int kb = 0; kb < 8; ++kb) {
+    POTF2_STAMP(1 + 4 * kb);
     POTF2_STAMP(2 + 4 * kb);
     __syncthreads();
     POTF2_STAMP(3 + 4 * kb);
@@ -239,29 +250,42 @@ __global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t l
     }
     __syncthreads();
     POTF2_STAMP(4 + 4 * kb);
-    // ---- P3: A_ij -= L_ik L_jk^T for kb < j <= i ----------------------------------------
+    // ---- P3: A_ij -= L_ik L_jk^T for kb < j <= i.  Wave 0 takes the next diagonal block first
+    // and factors it straight away (in-kernel look-ahead: P1 of step kb+1 hides under the
+    // other waves' updates); waves 1..7 share the remaining pairs.
     {
-      int cnt = 0;
-      for (int jb = kb + 1; jb < 8; ++jb)
-        for (int ib = jb; ib < 8; ++ib, ++cnt) {
-          if ((cnt & 7) != w) continue;
-          T* Cij = &S[blk(ib, jb)];
-          const T* Xi = &S[blk(ib, kb)];
-          const T* Xj = &S[blk(jb, kb)];
-          acc_t acc, acc2 = acc_t{0, 0, 0, 0};
+      auto update_pair = [&](int ib, int jb) {
+        T* Cij = &S[blk(ib, jb)];
+        const T* Xi = &S[blk(ib, kb)];
+        const T* Xj = &S[blk(jb, kb)];
+        acc_t acc, acc2 = acc_t{0, 0, 0, 0};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = Cij[M::drow(lane, r) * 16 + lrow];
+        for (int r = 0; r < 4; ++r) acc[r] = Cij[M::drow(lane, r) * 16 + lrow];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int kk = M::drow(lane, s);
-            const T xj = -Xj[kk * 16 + lrow], xi = Xi[kk * 16 + lrow];
-            if (s & 1) acc2 = M::mma(xj, xi, acc2);
-            else acc = M::mma(xj, xi, acc);
-          }
-          acc += acc2;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] = acc[r];
+        for (int s = 0; s < 4; ++s) {
+          const int kk = M::drow(lane, s);
+          const T xj = -Xj[kk * 16 + lrow], xi = Xi[kk * 16 + lrow];
+          if (s & 1) acc2 = M::mma(xj, xi, acc2);
+          else acc = M::mma(xj, xi, acc);
         }
+        acc += acc2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] = acc[r];
+      };
+      if (w == 0) {
+        if (kb + 1 < 8) {
+          update_pair(kb + 1, kb + 1);
+          factor_diag(kb + 1);
+        }
+      } else {
+        int cnt = 0;
+        for (int jb = kb + 1; jb < 8; ++jb)
+          for (int ib = jb; ib < 8; ++ib) {
+            if (ib == kb + 1 && jb == kb + 1) continue;
+            if ((cnt++ % 7) + 1 != w) continue;
+            update_pair(ib, jb);
+          }
+      }
     }
     __syncthreads();
   }
