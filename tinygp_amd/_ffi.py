@@ -155,6 +155,10 @@ class Ctx:
         h = C.c_void_p()
         check(lib().tgp_ctx_create(device, C.c_void_p(stream or 0), C.byref(h)), "tgp_ctx_create")
         self.handle = h
+        # tuning overrides, e.g. TGP_HIP_OPTIONS="nb_outer=512,lookahead=0"
+        for item in filter(None, os.environ.get("TGP_HIP_OPTIONS", "").split(",")):
+            key, _, value = item.partition("=")
+            self.set_option(key.strip(), int(value))
 
     def sync(self):
         check(lib().tgp_ctx_sync(self.handle), "tgp_ctx_sync")

@@ -589,28 +589,35 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   // update of the columns to the right runs on its own stream (S3) beside the NEXT block's
   // potf2, which folds the update of its own diagonal tile in (role 3 skips that tile).
   hipStream_t S3 = ctx->update_stream;
-  auto panel = [&](hipStream_t st, int64_t k0, int64_t kb) -> int {
+  // `head_done`: the first block's potf2 was already issued by the caller.
+  auto potf2_at = [&](hipStream_t st, int64_t j0, bool pend) -> int {
+    return launch_potf2<T>(ctx, st, A + j0 * ld + j0, ld, dinv + (j0 / TILE) * 2048, ctx->d_info,
+                           (int32_t)j0, pend ? (const T*)(A + (j0 - TILE) * ld + j0) : (const T*)nullptr,
+                           ld);
+  };
+  auto panel = [&](hipStream_t st, int64_t k0, int64_t kb, bool head_done) -> int {
     for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
       T* Ljj = A + j0 * ld + j0;
       T* dj = dinv + (j0 / TILE) * 2048;
       const bool pend = j0 > k0;  // in-panel update from block column j0-128 still in flight
-      TGP_TRY(launch_potf2<T>(ctx, st, Ljj, ld, dj, ctx->d_info, (int32_t)j0,
-                              pend ? (const T*)(A + (j0 - TILE) * ld + j0) : (const T*)nullptr, ld));
+      if (pend || !head_done) TGP_TRY(potf2_at(st, j0, pend));
       if (pend) TGP_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_e, 0));  // rest of that update
       const int64_t mb = n - (j0 + TILE);
       if (mb > 0) TGP_TRY(launch_trsm<T>(ctx, st, mb, Ljj, ld, dj, Ljj + TILE, ld));
-      if (y != nullptr) {
-        TGP_HIP_TRY(hipEventRecord(ctx->ev_c, st));
-        TGP_HIP_TRY(hipStreamWaitEvent(S2, ctx->ev_c, 0));
-        TGP_TRY(launch_trsv_fwd_step<T>(S2, mb, Ljj, ld, dj, y + j0));
-      }
       const int64_t nc = (k0 + kb) - (j0 + TILE);
-      if (mb > 0 && nc > 0) {
-        TGP_HIP_TRY(hipEventRecord(ctx->ev_d, st));
+      const bool upd = mb > 0 && nc > 0;
+      // one marker behind the trsm serves both side streams (every marker between two
+      // kernels of the chain costs it a few microseconds)
+      if (y != nullptr || upd) TGP_HIP_TRY(hipEventRecord(ctx->ev_d, st));
+      if (upd) {
         TGP_HIP_TRY(hipStreamWaitEvent(S3, ctx->ev_d, 0));
         TGP_TRY(launch_gemm_nt<T>(ctx, S3, mb, nc, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
                                   A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, 3));
         TGP_HIP_TRY(hipEventRecord(ctx->ev_e, S3));
+      }
+      if (y != nullptr) {
+        TGP_HIP_TRY(hipStreamWaitEvent(S2, ctx->ev_d, 0));
+        TGP_TRY(launch_trsv_fwd_step<T>(S2, mb, Ljj, ld, dj, y + j0));
       }
     }
     return TGP_OK;
@@ -637,12 +644,12 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   if (!la) {
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
       const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
-      TGP_TRY(panel(S0, k0, kb));
+      TGP_TRY(panel(S0, k0, kb, false));
       const int64_t next = k0 + kb, mt = n - next;
       if (mt > 0) TGP_TRY(trailing(mt, mt, kb, A + k0 * ld + next, A + next * ld + next, 0));
     }
   } else {
-    TGP_TRY(panel(S0, 0, (n < NB) ? n : NB));
+    TGP_TRY(panel(S0, 0, (n < NB) ? n : NB, false));
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
       const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
       const int64_t next = k0 + kb, mt = n - next;
@@ -651,15 +658,21 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       const T* P = A + k0 * ld + next;
       // 1. block column of the next panel first ...
       TGP_TRY(trailing(mt, kbn, kb, P, A + next * ld + next, 0));
+      // the panel's first potf2 goes in front of the big update on the main stream: issued
+      // beside it, it waits a whole round of tiles (~0.3 ms) for a free CU
+      TGP_TRY(potf2_at(S0, next, false));
       TGP_HIP_TRY(hipEventRecord(ctx->ev_a, S0));
-      TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
-      // 2. ... factor it on the side stream ...
-      TGP_TRY(panel(S1, next, kbn));
-      TGP_HIP_TRY(hipEventRecord(ctx->ev_b, S1));
-      // 3. ... while the main stream updates the rest
+      // 2. ... the main stream updates the rest (enqueued first: the ~90 API calls of a
+      // panel take the host longer than a small update takes the GPU) ...
       const int64_t m2 = mt - kbn;
-      if (m2 > 0)
-        TGP_TRY(trailing(m2, m2, kb, P + kbn, A + (next + kbn) * ld + next + kbn, ctx->lookahead >= 2 ? 2 : 0));
+      if (m2 > 0) {
+        TGP_TRY(trailing(m2, m2, kb, P + kbn, A + (next + kbn) * ld + next + kbn,
+                         ctx->lookahead >= 2 ? 2 : 0));
+      }
+      // 3. ... while the side stream factors the next panel
+      TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
+      TGP_TRY(panel(S1, next, kbn, true));
+      TGP_HIP_TRY(hipEventRecord(ctx->ev_b, S1));
       TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_b, 0));
     }
   }

@@ -187,16 +187,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
       if (kt + 1 < nkt) store_lds(buf ^ 1);
       __syncthreads();
     }
+    // epilogue.  The read-modify-write is batched: 32 independent loads in flight, then 32
+    // stores, twice (element by element it is 64 dependent HBM round trips per lane).
+    if (g.mode == 0) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      T* col = Cb + int64_t(a * 16 + 4 * lq + lk) * g.ldc;
+      for (int ap = 0; ap < 4; ap += 2) {
+        T* col[2];
+        double c[2][4][4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+        for (int a = 0; a < 2; ++a) {
+          col[a] = Cb + int64_t((ap + a) * 16 + 4 * lq + lk) * g.ldc;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (g.mode == 0) col[b * 16 + rot[t]] -= acc[a][b][t];
-          else col[b * 16 + rot[t]] = acc[a][b][t];
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) c[a][b][t] = col[a][b * 16 + rot[t]];
         }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) col[a][b * 16 + rot[t]] = c[a][b][t] - acc[ap + a][b][t];
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        T* col = Cb + int64_t(a * 16 + 4 * lq + lk) * g.ldc;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) col[b * 16 + rot[t]] = acc[a][b][t];
+      }
     }
   } else {
     acc_t acc[4][4];
@@ -231,16 +252,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     }
     // epilogue: C[i0 + wr*64 + b*16 + lrow, j0 + wc*64 + a*16 + drow(lane, r)]
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
+      T* col[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        T* col = Cb + lrow + int64_t(a * 16 + M::drow(lane, r)) * g.ldc;
+      for (int r = 0; r < 4; ++r) col[r] = Cb + lrow + int64_t(a * 16 + M::drow(lane, r)) * g.ldc;
+      if (g.mode == 0) {  // batched read-modify-write: 16 loads in flight
+        T c[4][4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (g.mode == 0) col[b * 16] -= acc[a][b][r];
-          else col[b * 16] = acc[a][b][r];
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) c[r][b] = col[r][b * 16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) col[r][b * 16] = c[r][b] - acc[a][b][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) col[r][b * 16] = acc[a][b][r];
       }
+    }
   }
 }
 
@@ -330,16 +362,32 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmArgs<T> g) {
       if (kt + 1 < nkt) store_lds(buf ^ 1);
       __syncthreads();
     }
+    {
+      T* col[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      T* col = Cb + int64_t(a * 16 + 4 * lq + lk) * g.ldc;
+      for (int a = 0; a < 2; ++a) col[a] = Cb + int64_t(a * 16 + 4 * lq + lk) * g.ldc;
+      if (g.mode == 0) {  // batched read-modify-write: all 16 loads in flight at once
+        double c[2][2][4];
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (g.mode == 0) col[b * 16 + rot[t]] -= acc[a][b][t];
-          else col[b * 16 + rot[t]] = acc[a][b][t];
-        }
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) c[a][b][t] = col[a][b * 16 + rot[t]];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) col[a][b * 16 + rot[t]] = c[a][b][t] - acc[a][b][t];
+      } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) col[a][b * 16 + rot[t]] = acc[a][b][t];
+      }
     }
   } else {
     acc_t acc[2][2];
@@ -371,17 +419,36 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmArgs<T> g) {
       if (kt + 1 < nkt) store_lds(buf ^ 1);
       __syncthreads();
     }
+    {
+      T* col[2][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        T* col = Cb + lrow + int64_t(a * 16 + M::drow(lane, r)) * g.ldc;
+        for (int r = 0; r < 4; ++r)
+          col[a][r] = Cb + lrow + int64_t(a * 16 + M::drow(lane, r)) * g.ldc;
+      if (g.mode == 0) {
+        T c[2][4][2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if (g.mode == 0) col[b * 16] -= acc[a][b][r];
-          else col[b * 16] = acc[a][b][r];
-        }
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) c[a][r][b] = col[a][r][b * 16];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) col[a][r][b * 16] = c[a][r][b] - acc[a][b][r];
+      } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) col[a][r][b * 16] = acc[a][b][r];
       }
+    }
   }
 }
 
