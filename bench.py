@@ -33,12 +33,39 @@ sys.path.insert(0, str(ROOT))
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet: FP64 matrix = FP64 vector = 78.6 TFLOP/s
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
-# HBM bytes per trailing-update launch for workload c2 / nb_outer 512, from the committed PMC
-# passes (profiles/r01_e_pmc_hbm_traffic.md: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
-# separate runs, KB units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM" for wide coalesced
-# reads): (2 x 81.010 GB + 33.157 GB) / 183 launches.  PMC collection serialises kernels, so it
-# cannot run inside the timed region; other workloads report null.
-PMC_TRAFFIC_BYTES_PER_LAUNCH_C2 = (2 * 81.010e9 + 33.157e9) / 183
+# HBM bytes per trailing-update launch for workload c2 at the default nb_outer = 1024, from the
+# committed PMC passes (profiles/r01_h_pmc_hbm_traffic_nb1024.md: rocprofv3 --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE in separate runs, KB units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM"
+# for wide coalesced reads): (2 x 68.075 GB + 15.422 GB) / 87 launches.  PMC collection
+# serialises kernels, so it cannot run inside the timed region; other workloads report null.
+PMC_TRAFFIC_BYTES_PER_LAUNCH_C2 = (2 * 68.075e9 + 15.422e9) / 87
+PMC_TRAFFIC_NB = 1024
+
+
+def trailing_update_bytes(n_pad: int, nb: int, itemsize: int):
+    """(algorithmic bytes, launches) of one factorisation's trailing-update launches.
+
+    Mirrors the launch shapes of csrc/chol.hip (look-ahead: next panel's block column, then
+    the rest).  Per launch: the lower-trapezoid entries of C are read and written once and the
+    panel operand (m x kb) is read once.
+    """
+    total, launches = 0, 0
+    k0 = 0
+    while k0 < n_pad:
+        kb = min(nb, n_pad - k0)
+        nxt = k0 + kb
+        mt = n_pad - nxt
+        if mt <= 0:
+            break
+        kbn = min(nb, mt)
+        for m, nn in ((mt, kbn), (mt - kbn, mt - kbn)):
+            if m <= 0:
+                continue
+            entries = nn * m - nn * (nn - 1) // 2
+            total += itemsize * (2 * entries + m * kb)
+            launches += 1
+        k0 = nxt
+    return total, launches
 
 
 def emit(obj):
@@ -253,6 +280,8 @@ def main():
     ctx.set_option("profile", 0 if args.no_profile else 1)
     nb_used = ctx.set_option("nb_outer", 512)
     ctx.set_option("nb_outer", nb_used)
+    la_used = ctx.set_option("lookahead", 1)
+    ctx.set_option("lookahead", la_used)
 
     X, y = synthetic.make_inputs(n, d, spec["dtype"])
 
@@ -318,6 +347,8 @@ def main():
         roofline = None
         extra = {}
         if not args.no_profile and acc["syrk_ms"] > 0:
+            n_pad = -(-n // 128) * 128
+            alg_bytes, alg_launches = trailing_update_bytes(n_pad, int(nb_used), np.dtype(dt).itemsize)
             achieved = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12
             launches = max(acc["syrk_launches"], 1.0)
             roofline = {
@@ -325,9 +356,10 @@ def main():
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 "traffic": (PMC_TRAFFIC_BYTES_PER_LAUNCH_C2
-                            if (args.workload == "c2" and nb_used == 512 and world == 1) else None),
-                "traffic_unit": "bytes/launch (PMC, profiles/r01_e_pmc_hbm_traffic.md)",
-                "algorithmic_bytes_per_launch": None,
+                            if (args.workload == "c2" and nb_used == PMC_TRAFFIC_NB and world == 1
+                                and la_used == 1) else None),
+                "traffic_unit": "bytes/launch (PMC, profiles/r01_h_pmc_hbm_traffic_nb1024.md)",
+                "algorithmic_bytes_per_launch": alg_bytes / max(alg_launches, 1),
                 "avg_launch_ms": acc["syrk_ms"] / launches,
                 "flops_per_launch": acc["syrk_flops"] / launches,
                 "launches_per_step": launches / args.steps,
