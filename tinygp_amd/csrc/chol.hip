@@ -101,8 +101,10 @@ __device__ long long g_potf2_stamps[64];
 #define POTF2_STAMP(i) do {} while (0)
 #endif
 
-template <typename T>
-__global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t ld,
+// waves_per_eu(4): at most 128 VGPRs, so that two potf2 waves fit on a SIMD beside one wave of the
+// trailing-update GEMM (238 VGPRs) -- otherwise potf2 waits for the whole update to drain.
+template <typename T, bool FOLD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void potf2_kernel(T* __restrict__ A, int64_t ld,
                                                     T* __restrict__ dinv,
                                                     int32_t* __restrict__ info,
                                                     int32_t pivot_base,
@@ -112,51 +114,109 @@ __global__ __launch_bounds__(512) void potf2_kernel(T* __restrict__ A, int64_t l
   __shared__ __attribute__((aligned(16))) T S[36 * 256];
   __shared__ __attribute__((aligned(16))) T Wb[16 * 16];  // Wb[k * 16 + c] = W[c][k]
   __shared__ T Rs[16];                                     // 1 / L_ii of the current block
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar address math
   const int lrow = lane & 15;
   __builtin_amdgcn_s_setprio(3);
 
   POTF2_STAMP(0);
-  for (int b = w; b < 36; b += 8) {  // one 16x16 block per wave per trip, 4 elements per lane
-    int i = 0;
-    while ((i + 1) * (i + 2) / 2 <= b) ++i;
-    const int j = b - i * (i + 1) / 2;
-    const T* src = A + int64_t(j * 16) * ld + i * 16;
+  // the tile: one 16x16 block per wave per trip, 4 elements per lane; with a fold it is fetched
+  // while the fold's second half runs (S is the fold's exchange buffer until then)
+  T tr[5][4];
+  auto load_tile = [&]() {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = q * 64 + lane, c = e >> 4, r = e & 15;
-      S[b * 256 + e] = src[int64_t(c) * ld + r];
-    }
-  }
-  if (Xp != nullptr) {
-    // Pending in-panel update of THIS tile, folded in so that it is not a separate kernel on
-    // the critical path:  A_tile -= Xp Xp^T  with Xp = the previous block column's 128 rows
-    // of this tile (128 x 128, column-major, ld = ldx).  One 16x16 block per wave per trip,
-    // operands straight from L2 (16 consecutive rows at fixed k = 128 contiguous bytes).
-    __syncthreads();
-    for (int b = w; b < 36; b += 8) {
-      int ib = 0;
-      while ((ib + 1) * (ib + 2) / 2 <= b) ++ib;
-      const int jb = b - ib * (ib + 1) / 2;
-      T* Cij = &S[b * 256];
-      acc_t acc, acc2 = acc_t{0, 0, 0, 0};
+    for (int trip = 0; trip < 5; ++trip) {
+      const int b = w + 8 * trip;
+      if (b < 36) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= b) ++i;
+        const int j = b - i * (i + 1) / 2;
+        // uniform base (SGPRs) + one 32-bit lane offset: no per-load address registers
+        const int voff = (lane >> 4) * int(ld) + lrow;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = Cij[M::drow(lane, r) * 16 + lrow];
-      const T* xj = Xp + jb * 16 + lrow;
-      const T* xi = Xp + ib * 16 + lrow;
-#pragma unroll 4
-      for (int k16 = 0; k16 < 8; ++k16) {
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-          const int64_t kk = k16 * 16 + M::drow(lane, s2);
-          const T av = -xj[kk * ldx], bv = xi[kk * ldx];
-          if (s2 & 1) acc2 = M::mma(av, bv, acc2);
-          else acc = M::mma(av, bv, acc);
+        for (int q = 0; q < 4; ++q) {
+          const T* src = A + int64_t(j * 16 + q * 4) * ld + i * 16;
+          tr[trip][q] = src[voff];
         }
       }
-      acc += acc2;
+    }
+  };
+  if constexpr (!FOLD) load_tile();
+  // Pending in-panel update of THIS tile, folded in so that it is not a separate kernel on the
+  // critical path:  A_tile -= Xp Xp^T  with Xp = the previous block column's 128 rows of this
+  // tile (128 x 128, column-major, ld = ldx).  Wave w loads the 16-row slab w of Xp in MFMA
+  // operand layout -- 32 independent loads, ONE round trip to L2 (a version that reads its
+  // operands block by block from global needs ten dependent round trips per wave) -- and the
+  // slabs are exchanged through LDS, 64 k-columns at a time, in the space of S (exactly
+  // 64 x 144 doubles; no LDS beyond the 74 KB that lets potf2 share a CU with a GEMM
+  // workgroup).  Rows p and 7-p hold p + 1 and 8 - p blocks, nine per pair: waves p and p + 4
+  // share pair p (blocks t = 0..4 and t = 5..8 of it).
+  constexpr int XC_LD = 144;  // 144 mod 32 == 16: conflict-free operand reads
+  static_assert(64 * XC_LD <= 36 * 256, "fold exchange buffer must fit in S");
+  T* Xc = S;
+  const int pr = w & 3, i1 = pr, i2 = 7 - pr;
+  const int t0 = (w < 4) ? 0 : 5, nt = (w < 4) ? 5 : 4;
+  acc_t Cf[5];
+  if constexpr (FOLD) {
+    acc_t V[8];
+    const int xoff = M::drow(lane, 0) * int(ldx) + lrow;  // drow(lane, r) = drow(lane, 0) + drow(0, r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] = acc[r];
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T* xs = Xp + int64_t(jb * 16 + M::drow(0, r)) * ldx + w * 16;
+        V[jb][r] = xs[xoff];
+      }
+    const int lk = lane >> 4;
+#pragma unroll
+    for (int tt = 0; tt < 5; ++tt) Cf[tt] = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h) __syncthreads();  // first half fully consumed
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Xc[((jq * 4 + r) * 4 + lk) * XC_LD + w * 16 + lrow] = V[h * 4 + jq][r];
+      if (h) load_tile();  // V is dead: the tile's round trip hides under the second half
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const T* row = &Xc[(ks * 4 + lk) * XC_LD + lrow];
+        const T b1 = row[i1 * 16], b2 = row[i2 * 16];
+#pragma unroll
+        for (int tt = 0; tt < 5; ++tt) {
+          if (tt < nt) {
+            const int t = t0 + tt;
+            const bool first = t <= pr;
+            const int jj = first ? t : t - pr - 1;
+            Cf[tt] = M::mma(row[jj * 16], first ? b1 : b2, Cf[tt]);
+          }
+        }
+      }
+    }
+    __syncthreads();  // exchange buffer dead: S can take the tile
+  }
+#pragma unroll
+  for (int trip = 0; trip < 5; ++trip) {
+    const int b = w + 8 * trip;
+    if (b < 36) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[b * 256 + q * 64 + lane] = tr[trip][q];
+    }
+  }
+  if constexpr (FOLD) {
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 5; ++tt) {
+      if (tt < nt) {
+        const int t = t0 + tt;
+        const bool first = t <= pr;
+        const int ii = first ? i1 : i2, jj = first ? t : t - pr - 1;
+        T* Cij = &S[blk(ii, jj)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] -= Cf[tt][r];
+      }
     }
   }
   __syncthreads();
@@ -325,7 +385,7 @@ __global__ __launch_bounds__(256) void dinv_kernel(int64_t n, const T* __restric
 // trsm: B (m x 128) <- B L^-T, L a 128x128 lower block with its dinv.  Wave per 16 rows.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void trsm_kernel(int64_t m, const T* __restrict__ L, int64_t ldl,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void trsm_kernel(int64_t m, const T* __restrict__ L, int64_t ldl,
                                                    const T* __restrict__ dinv, T* __restrict__ B,
                                                    int64_t ldb) {
   using M = Mfma<T>;
@@ -335,34 +395,56 @@ __global__ __launch_bounds__(256) void trsm_kernel(int64_t m, const T* __restric
   const int64_t r0 = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16;
   if (r0 >= m) return;
   const int lrow = lane & 15;
-  acc_t Z[8];
+  // The recurrence over the eight 16-column steps is serial, so memory latency must not be:
+  // the whole 16 x 128 slab of B is loaded up front, and the L / dinv operands of step j+1
+  // are fetched while step j runs on the MFMAs (one exposed round trip instead of eight).
+  T* bp = B + r0 + lrow;
+  acc_t V[8];  // V[j]: B_j until step j, then Z_j = -Y_j
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) V[jb][r] = bp[int64_t(jb * 16 + M::drow(lane, r)) * ldb];
+  T Dn[4], Ln[7][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) Dn[s] = dinv[M::drow(lane, s) * 16 + lrow];
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
-    acc_t acc, acc2 = acc_t{0, 0, 0, 0};  // two chains: MFMA latency overlaps
-    T* bp = B + r0 + lrow + int64_t(jb * 16) * ldb;
+    T Dc[4], Lc[7][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = bp[int64_t(M::drow(lane, r)) * ldb];
+    for (int s = 0; s < 4; ++s) Dc[s] = Dn[s];
+#pragma unroll
+    for (int kb = 0; kb < jb; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) Lc[kb][s] = Ln[kb][s];
+    if (jb + 1 < 8) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) Dn[s] = dinv[(jb + 1) * 256 + M::drow(lane, s) * 16 + lrow];
+#pragma unroll
+      for (int kb = 0; kb <= jb; ++kb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          Ln[kb][s] = L[int64_t(kb * 16 + M::drow(lane, s)) * ldl + (jb + 1) * 16 + lrow];
+    }
+    acc_t acc = V[jb], acc2 = acc_t{0, 0, 0, 0};  // two chains: MFMA latency overlaps
 #pragma unroll
     for (int kb = 0; kb < jb; ++kb) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const T a = L[int64_t(kb * 16 + M::drow(lane, s)) * ldl + jb * 16 + lrow];
-        if (s & 1) acc2 = M::mma(a, Z[kb][s], acc2);
-        else acc = M::mma(a, Z[kb][s], acc);
+        if (s & 1) acc2 = M::mma(Lc[kb][s], V[kb][s], acc2);
+        else acc = M::mma(Lc[kb][s], V[kb][s], acc);
       }
     }
     acc += acc2;
     acc_t y = acc_t{0, 0, 0, 0}, y2 = acc_t{0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const T a = dinv[jb * 256 + M::drow(lane, s) * 16 + lrow];
-      if (s & 1) y2 = M::mma(a, acc[s], y2);
-      else y = M::mma(a, acc[s], y);
+      if (s & 1) y2 = M::mma(Dc[s], acc[s], y2);
+      else y = M::mma(Dc[s], acc[s], y);
     }
     y += y2;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bp[int64_t(M::drow(lane, r)) * ldb] = y[r];
-    Z[jb] = -y;
+    for (int r = 0; r < 4; ++r) bp[int64_t(jb * 16 + M::drow(lane, r)) * ldb] = y[r];
+    V[jb] = -y;
   }
 }
 
@@ -507,8 +589,12 @@ template <typename T>
 int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_t* info,
                  int32_t pivot_base, const T* Xp, int64_t ldx) {
   (void)ctx;
-  hipLaunchKernelGGL((potf2_kernel<T>), dim3(1), dim3(512), 0, st, A, ld, dinv, info, pivot_base,
-                     Xp, ldx);
+  if (Xp != nullptr)
+    hipLaunchKernelGGL((potf2_kernel<T, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
+                       pivot_base, Xp, ldx);
+  else
+    hipLaunchKernelGGL((potf2_kernel<T, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
+                       pivot_base, Xp, ldx);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
