@@ -42,12 +42,13 @@ PMC_TRAFFIC_BYTES_PER_LAUNCH_C2 = (2 * 68.075e9 + 15.422e9) / 87
 PMC_TRAFFIC_NB = 1024
 
 
-def trailing_update_bytes(n_pad: int, nb: int, itemsize: int):
+def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles: int = 0):
     """(algorithmic bytes, launches) of one factorisation's trailing-update launches.
 
     Mirrors the launch shapes of csrc/chol.hip (look-ahead: next panel's block column, then
     the rest).  Per launch: the lower-trapezoid entries of C are read and written once and the
-    panel operand (m x kb) is read once.
+    panel operand (m x kb) is read once.  Block-column updates of at most `first_small_tiles`
+    128x128 tiles run on the 64x64-tile kernel and are not part of the profiled kernel.
     """
     total, launches = 0, 0
     k0 = 0
@@ -58,8 +59,11 @@ def trailing_update_bytes(n_pad: int, nb: int, itemsize: int):
         if mt <= 0:
             break
         kbn = min(nb, mt)
-        for m, nn in ((mt, kbn), (mt - kbn, mt - kbn)):
+        for which, (m, nn) in enumerate(((mt, kbn), (mt - kbn, mt - kbn))):
             if m <= 0:
+                continue
+            tiles = (m // 128) * (nn // 128) - (nn // 128) * (nn // 128 - 1) // 2
+            if which == 0 and tiles <= first_small_tiles:
                 continue
             entries = nn * m - nn * (nn - 1) // 2
             total += itemsize * (2 * entries + m * kb)
@@ -282,6 +286,8 @@ def main():
     ctx.set_option("nb_outer", nb_used)
     la_used = ctx.set_option("lookahead", 1)
     ctx.set_option("lookahead", la_used)
+    fst_used = ctx.set_option("first_small_tiles", 0)
+    ctx.set_option("first_small_tiles", fst_used)
 
     X, y = synthetic.make_inputs(n, d, spec["dtype"])
 
@@ -348,7 +354,8 @@ def main():
         extra = {}
         if not args.no_profile and acc["syrk_ms"] > 0:
             n_pad = -(-n // 128) * 128
-            alg_bytes, alg_launches = trailing_update_bytes(n_pad, int(nb_used), np.dtype(dt).itemsize)
+            alg_bytes, alg_launches = trailing_update_bytes(n_pad, int(nb_used), np.dtype(dt).itemsize,
+                                                             int(fst_used))
             achieved = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12
             launches = max(acc["syrk_launches"], 1.0)
             roofline = {

@@ -109,6 +109,8 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->panel_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->solve_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->update_stream, hipStreamNonBlocking, hi));
+  TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->asm_stream, hipStreamNonBlocking, lo));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_e, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
@@ -137,6 +139,11 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
     hipStreamSynchronize(ctx->update_stream);
     hipStreamDestroy(ctx->update_stream);
   }
+  if (ctx->asm_stream) {
+    hipStreamSynchronize(ctx->asm_stream);
+    hipStreamDestroy(ctx->asm_stream);
+  }
+  if (ctx->ev_asm) hipEventDestroy(ctx->ev_asm);
   if (ctx->ev_d) hipEventDestroy(ctx->ev_d);
   if (ctx->ev_e) hipEventDestroy(ctx->ev_e);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
@@ -164,6 +171,7 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   if (!strcmp(key, "nb_outer")) slot = &ctx->nb_outer;
   else if (!strcmp(key, "lookahead")) slot = &ctx->lookahead;
   else if (!strcmp(key, "profile")) slot = &ctx->profile;
+  else if (!strcmp(key, "first_small_tiles")) slot = &ctx->first_small_tiles;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)
     TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);
@@ -453,9 +461,31 @@ static int factor_impl(tgp_solver* s, const tgp_kop* prog, int nops, const void*
                                  hipMemcpyHostToDevice, ctx->stream));
       TGP_TRY(launch_set_lower_from_rowmajor<T>(ctx, s->n, s->npad, (const T*)s->scratch, A, s->npad));
     } else {
-      TGP_TRY(launch_kmat<T>(ctx, s->kp, s->n, s->n, s->d, (const T*)s->X, (const T*)s->X,
-                             (const T*)s->diag, A, s->npad, s->npad, s->npad,
-                             KMAT_LOWER | KMAT_PAD_IDENTITY));
+      // Only the first panel's columns gate the factorisation: the rest of K is assembled
+      // on its own stream beside the first panel's potf2/trsm chain (potrf waits for it
+      // before the first trailing update).
+      const int64_t tc = s->npad / 128;
+      int64_t t1 = tc;
+      if (ctx->lookahead != 0 && ctx->asm_stream != nullptr) {
+        int64_t nb = ctx->nb_outer / 128;
+        if (nb < 1) nb = 1;
+        if (nb < tc) t1 = nb;
+      }
+      const int flags = KMAT_LOWER | KMAT_PAD_IDENTITY;
+      if (t1 < tc) {
+        TGP_HIP_TRY(hipEventRecord(ctx->ev_asm, ctx->stream));  // X / noise uploads are on S0
+        TGP_HIP_TRY(hipStreamWaitEvent(ctx->asm_stream, ctx->ev_asm, 0));
+      }
+      TGP_TRY(launch_kmat_cols<T>(ctx, ctx->stream, s->kp, s->n, s->n, s->d, (const T*)s->X,
+                                  (const T*)s->X, (const T*)s->diag, A, s->npad, s->npad, s->npad,
+                                  flags, 0, t1));
+      if (t1 < tc) {
+        TGP_TRY(launch_kmat_cols<T>(ctx, ctx->asm_stream, s->kp, s->n, s->n, s->d, (const T*)s->X,
+                                    (const T*)s->X, (const T*)s->diag, A, s->npad, s->npad,
+                                    s->npad, flags, t1, tc - t1));
+        TGP_HIP_TRY(hipEventRecord(ctx->ev_asm, ctx->asm_stream));
+        ctx->asm_pending = true;
+      }
     }
     if (prof) TGP_HIP_TRY(hipEventRecord(e1, ctx->stream));
     if (fused) {

@@ -667,7 +667,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   if (NB < TILE) NB = TILE;
   NB = NB / TILE * TILE;
   TGP_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int32_t), S0));
-  const bool prof = ctx->profile != 0;
+  const bool prof_on = ctx->profile != 0;
   std::vector<ProfSpan> spans;
   ctx->ev_used = 0;
 
@@ -710,6 +710,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   };
   auto trailing = [&](int64_t m, int64_t nn, int64_t kb, const T* P, T* C, int role) -> int {
     ProfSpan sp{};
+    const bool prof = prof_on && role != 4;  // spans time the 128x128-tile kernel only
     if (prof) {
       TGP_TRY(prof_event(ctx, &sp.e0));
       TGP_TRY(prof_event(ctx, &sp.e1));
@@ -726,8 +727,17 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     return TGP_OK;
   };
 
+  // columns right of the first panel may still be in assembly (capi.hip, factor_impl)
+  auto join_assembly = [&]() -> int {
+    if (ctx->asm_pending) {
+      TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_asm, 0));
+      ctx->asm_pending = false;
+    }
+    return TGP_OK;
+  };
   const bool la = ctx->lookahead != 0 && S1 != nullptr;
   if (!la) {
+    TGP_TRY(join_assembly());
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
       const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
       TGP_TRY(panel(S0, k0, kb, false));
@@ -736,6 +746,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     }
   } else {
     TGP_TRY(panel(S0, 0, (n < NB) ? n : NB, false));
+    TGP_TRY(join_assembly());
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
       const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
       const int64_t next = k0 + kb, mt = n - next;
@@ -743,7 +754,11 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       const int64_t kbn = (mt < NB) ? mt : NB;
       const T* P = A + k0 * ld + next;
       // 1. block column of the next panel first ...
-      TGP_TRY(trailing(mt, kbn, kb, P, A + next * ld + next, 0));
+      // With fewer 128x128 tiles than workgroup slots (512) the update is one round of long
+      // serial k-loops, two per CU on some CUs: 64x64 tiles spread it evenly (role 4).
+      const int64_t first_tiles = (mt / TILE) * (kbn / TILE) - (kbn / TILE) * (kbn / TILE - 1) / 2;
+      TGP_TRY(trailing(mt, kbn, kb, P, A + next * ld + next,
+                       first_tiles <= ctx->first_small_tiles ? 4 : 0));
       // the panel's first potf2 goes in front of the big update on the main stream: issued
       // beside it, it waits a whole round of tiles (~0.3 ms) for a free CU
       TGP_TRY(potf2_at(S0, next, false));
@@ -769,7 +784,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   int32_t info = 0;
   TGP_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, S0));
   TGP_HIP_TRY(hipStreamSynchronize(S0));
-  if (prof) {
+  if (prof_on) {
     ctx->prof_syrk_ms = 0;
     ctx->prof_syrk_flops = 0;
     ctx->prof_syrk_launches = (int64_t)spans.size();

@@ -513,7 +513,8 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   GemmArgs<T> g;
   g.skip00 = 0;
   TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");
-  if ((role == 1 || role == 3) && k <= 256 && (mode == 0 || mode == 1)) {  // short-K update
+  // short-K updates, and (role 4) a latency-bound update with too few big tiles to fill the chip
+  if ((((role == 1 || role == 3) && k <= 256) || role == 4) && (mode == 0 || mode == 1)) {
     g.skip00 = (role == 3);
     g.A = A; g.B = B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;

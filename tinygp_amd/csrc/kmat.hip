@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void kmat_kernel(KProg kp, int64_t n1, int64_t
                                                    const T* __restrict__ X2,
                                                    const T* __restrict__ diag, T* __restrict__ out,
                                                    int64_t ld, int64_t rows_out, int64_t cols_out,
-                                                   int flags) {
-  const int tr = blockIdx.x, tc = blockIdx.y;
+                                                   int flags, int tc0) {
+  const int tr = blockIdx.x, tc = blockIdx.y + tc0;
   if ((flags & KMAT_LOWER) && tr < tc) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* s1 = reinterpret_cast<T*>(smem);  // [KT][d]
@@ -371,19 +371,21 @@ int make_kprog(const tgp_kop* prog, int nops, KProg* out) {
 }
 
 template <typename T>
-int launch_kmat(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
-                const T* X2, const T* diag, T* out, int64_t ld, int64_t rows_out, int64_t cols_out,
-                int flags) {
+int launch_kmat_cols(tgp_ctx* ctx, hipStream_t st, const KProg& kp, int64_t n1, int64_t n2, int d,
+                     const T* X1, const T* X2, const T* diag, T* out, int64_t ld, int64_t rows_out,
+                     int64_t cols_out, int flags, int64_t tc0, int64_t ntc) {
+  (void)ctx;
   TGP_ARG_CHECK(d >= 1 && d <= TGP_MAX_DIM, "input dimension must be 1..%d (got %d)", TGP_MAX_DIM, d);
   TGP_ARG_CHECK(rows_out >= n1 && cols_out >= n2 && ld >= rows_out, "kmat: bad output extents");
-  if (rows_out == 0 || cols_out == 0) return TGP_OK;
+  if (rows_out == 0 || cols_out == 0 || ntc <= 0) return TGP_OK;
   const int64_t tr = (rows_out + KT - 1) / KT, tc = (cols_out + KT - 1) / KT;
-  TGP_ARG_CHECK(tc <= 65535, "kmat: too many column tiles");
-  dim3 grid((unsigned)tr, (unsigned)tc);
+  TGP_ARG_CHECK(tc0 >= 0 && tc0 + ntc <= tc, "kmat: column tile range outside the matrix");
+  TGP_ARG_CHECK(ntc <= 65535, "kmat: too many column tiles");
+  dim3 grid((unsigned)tr, (unsigned)ntc);
   const size_t shmem = 2 * size_t(KT) * d * sizeof(T);
 #define TGP_KMAT_LAUNCH(DD)                                                                      \
-  hipLaunchKernelGGL((kmat_kernel<T, DD>), grid, dim3(256), shmem, ctx->stream, kp, n1, n2, d,   \
-                     X1, X2, diag, out, ld, rows_out, cols_out, flags)
+  hipLaunchKernelGGL((kmat_kernel<T, DD>), grid, dim3(256), shmem, st, kp, n1, n2, d, X1, X2,    \
+                     diag, out, ld, rows_out, cols_out, flags, (int)tc0)
   switch (d) {
     case 1: TGP_KMAT_LAUNCH(1); break;
     case 2: TGP_KMAT_LAUNCH(2); break;
@@ -394,6 +396,14 @@ int launch_kmat(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, co
 #undef TGP_KMAT_LAUNCH
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
+}
+
+template <typename T>
+int launch_kmat(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
+                const T* X2, const T* diag, T* out, int64_t ld, int64_t rows_out, int64_t cols_out,
+                int flags) {
+  return launch_kmat_cols<T>(ctx, ctx->stream, kp, n1, n2, d, X1, X2, diag, out, ld, rows_out,
+                             cols_out, flags, 0, (cols_out + KT - 1) / KT);
 }
 
 template <typename T>
@@ -463,6 +473,9 @@ int launch_noise_grad(tgp_ctx* ctx, int64_t n, const T* alpha, const T* Kinv, in
   template int launch_noise_grad<T>(tgp_ctx*, int64_t, const T*, const T*, int64_t, T*);          \
   template int launch_kmat<T>(tgp_ctx*, const KProg&, int64_t, int64_t, int, const T*, const T*,  \
                               const T*, T*, int64_t, int64_t, int64_t, int);                      \
+  template int launch_kmat_cols<T>(tgp_ctx*, hipStream_t, const KProg&, int64_t, int64_t, int,    \
+                                   const T*, const T*, const T*, T*, int64_t, int64_t, int64_t,   \
+                                   int, int64_t, int64_t);                                        \
   template int launch_kdiag<T>(tgp_ctx*, const KProg&, int64_t, int, const T*, const T*, T*);     \
   template int launch_kmat_gemv<T>(tgp_ctx*, const KProg&, int64_t, int64_t, int, const T*,       \
                                    const T*, const T*, T*);

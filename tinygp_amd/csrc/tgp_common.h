@@ -64,10 +64,14 @@ struct tgp_ctx {
   hipStream_t panel_stream = nullptr;  // look-ahead panel factorisation
   hipStream_t solve_stream = nullptr;  // forward substitution overlapped with the factorisation
   hipStream_t update_stream = nullptr;  // in-panel updates beside the next potf2
+  hipStream_t asm_stream = nullptr;     // assembly of the columns right of the first panel
+  hipEvent_t ev_asm = nullptr;          // ... finished (potrf waits before its first update)
+  bool asm_pending = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_e = nullptr;
   int64_t nb_outer = 1024;  // measured best for N = 4k .. 32k (profiles/r01_f_nb_sweep.txt)
   int64_t lookahead = 1;
   int64_t profile = 0;
+  int64_t first_small_tiles = 1100;  // look-ahead block-column updates up to this many tiles use 64x64 tiles
   // small device scratch: scal[0..15] doubles, info int
   double* d_scal = nullptr;
   int32_t* d_info = nullptr;
@@ -93,6 +97,11 @@ template <typename T>
 int launch_kmat(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
                 const T* X2, const T* diag, T* out, int64_t ld, int64_t rows_out, int64_t cols_out,
                 int flags);
+// column tiles [tc0, tc0 + ntc) of the same matrix (128 columns each) on stream `st`
+template <typename T>
+int launch_kmat_cols(tgp_ctx* ctx, hipStream_t st, const KProg& kp, int64_t n1, int64_t n2, int d,
+                     const T* X1, const T* X2, const T* diag, T* out, int64_t ld, int64_t rows_out,
+                     int64_t cols_out, int flags, int64_t tc0, int64_t ntc);
 constexpr int KMAT_LOWER = 1;         // only tiles on/below the diagonal
 constexpr int KMAT_PAD_IDENTITY = 2;  // padding = identity (else zeros)
 
