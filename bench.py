@@ -36,9 +36,10 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
 # HBM bytes per trailing-update launch for workload c2 at the default nb_outer = 1024, from the
 # committed PMC passes (profiles/r01_h_pmc_hbm_traffic_nb1024.md: rocprofv3 --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE in separate runs, KB units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM"
-# for wide coalesced reads): (2 x 68.075 GB + 15.422 GB) / 87 launches.  PMC collection
-# serialises kernels, so it cannot run inside the timed region; other workloads report null.
-PMC_TRAFFIC_BYTES_PER_LAUNCH_C2 = (2 * 68.075e9 + 15.422e9) / 87
+# for wide coalesced reads): (2 x 55.090 GB + 12.634 GB) / 42 launches of gemm_nt_kernel<double,0>.
+# PMC collection serialises kernels, so it cannot run inside the timed region; other
+# configurations report null.
+PMC_TRAFFIC_BYTES_PER_LAUNCH_C2 = (2 * 55.090e9 + 12.634e9) / 42
 PMC_TRAFFIC_NB = 1024
 
 
@@ -364,7 +365,7 @@ def main():
                 "frac": achieved / peak,
                 "traffic": (PMC_TRAFFIC_BYTES_PER_LAUNCH_C2
                             if (args.workload == "c2" and nb_used == PMC_TRAFFIC_NB and world == 1
-                                and la_used == 1) else None),
+                                and la_used == 1 and fst_used == 1100) else None),
                 "traffic_unit": "bytes/launch (PMC, profiles/r01_h_pmc_hbm_traffic_nb1024.md)",
                 "algorithmic_bytes_per_launch": alg_bytes / max(alg_launches, 1),
                 "avg_launch_ms": acc["syrk_ms"] / launches,

@@ -90,7 +90,12 @@ const char* tgp_last_error(void); /* thread-local message of the last failing ca
 int tgp_ctx_create(int device, void* stream, tgp_ctx** out);
 int tgp_ctx_destroy(tgp_ctx* ctx);
 int tgp_ctx_sync(tgp_ctx* ctx);
-/* tuning knobs: key in {"nb_outer","lookahead","profile"}; returns previous value via *old */
+/* tuning knobs; returns the previous value via *old:
+ *   "nb_outer"          outer panel width of the blocked Cholesky (default 1024)
+ *   "lookahead"         1: factor the next panel beside the trailing update (default), 0: off
+ *   "first_small_tiles" look-ahead block-column updates of at most this many 128x128 tiles
+ *                       run on 64x64 tiles (default 1100)
+ *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings) */
 int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* old);
 /* name (<=255 chars), CU count, memory bytes, clock kHz of the ctx's device */
 int tgp_ctx_device_info(tgp_ctx* ctx, char* name, int name_len, int32_t* cus, int64_t* mem_bytes,
@@ -229,8 +234,10 @@ int tgp_solver_get_factor(tgp_solver* s, void* L_host);
 /* device pointers of the padded factor (column-major, ld = n_pad) for zero-copy hosts */
 int tgp_solver_device_factor(tgp_solver* s, void** L_dev, int64_t* n_pad);
 /* last-call timings measured with HIP events on the ctx stream when option "profile"=1:
- * ms[0]=assembly, ms[1]=potrf total, ms[2]=sum of trailing-update (syrk) kernels,
- * ms[3]=number of trailing-update launches, ms[4]=trsv, ms[5]=panel (potf2+trsm) kernels */
+ * ms[0]=assembly of the first panel's columns (the rest is assembled beside the factorisation),
+ * ms[1]=potrf total, ms[2]=sum of the 128x128-tile trailing-update launches (event spans),
+ * ms[3]=number of those launches, ms[4]=separate trsv pass (0 when fused), ms[5]=unused,
+ * ms[6]=algorithmic flops of those launches */
 int tgp_solver_timings(tgp_solver* s, double* ms, int n);
 
 #ifdef __cplusplus

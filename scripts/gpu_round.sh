@@ -1,11 +1,22 @@
 #!/bin/bash
+# final-state evidence: gpu tests, default bench, kernel stats, PMC traffic passes, timeline
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 {
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -5
-for w in c2 n4096 n8192; do bash scripts/bench_variants.sh "--workload $w" | tail -1 | cut -c1-200; done
-for t in 1100 2200 4400; do echo "## first_small_tiles=$t n32768"; TGP_HIP_OPTIONS=first_small_tiles=$t bash scripts/bench_variants.sh "--workload n32768 --steps 3 --warmup 1" | tail -1 | cut -c1-90; done
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -3
+timeout 600 python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_default.json; cat gpurun_out/bench_default.json
+cd /tmp
+rm -rf /tmp/p0; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p0 -o st -- python $R/bench.py --no-cpu-baseline 2>&1 | grep '"metric"' | cut -c1-200
+python $R/scripts/prof_top.py $(find /tmp/p0 -name "*.db" | head -1) 14 | tee $R/gpurun_out/kernel_stats.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+rm -rf /tmp/p1; timeout 600 rocprofv3 --pmc $C --kernel-trace -d /tmp/p1 -o pm -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile 2>&1 | grep '"metric"' | cut -c1-100
+python $R/scripts/pmc_summary.py $(find /tmp/p1 -name "*.db" | head -1) $C | tee $R/gpurun_out/pmc_$C.txt
+done
+rm -rf /tmp/prof
+timeout 300 rocprofv3 --kernel-trace -d /tmp/prof -o tl -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile 2>&1 | grep '"metric"' | cut -c1-120
+python $R/scripts/timeline.py $(find /tmp/prof -name "*.db" | head -1) $R/gpurun_out/timeline_c2.csv 2000 | tail -1
+python $R/scripts/timeline_panels.py $R/gpurun_out/timeline_c2.csv | tee $R/gpurun_out/panels.txt
 } > $R/gpurun_out/round.log 2>&1
 cat $R/gpurun_out/round.log

@@ -1,28 +1,47 @@
-"""Per-panel view of a timeline CSV written by timeline.py (last bench step):
-first-part update, rest update, chain length, and which of them gated the next panel."""
-import csv
+"""Per-panel view of a timeline CSV written by timeline.py (last bench step): the look-ahead
+block-column update (`first`), the big trailing update beside the chain (`rest`), the length
+of the potf2/trsm chain of the next panel, and which of the two finished last."""
 import sys
 from collections import defaultdict
 
-rows = list(csv.DictReader(open(sys.argv[1])))
-idx = [i for i, r in enumerate(rows) if "kmat_kernel" in r["name"]]
-step = rows[idx[-1]:]
-t0 = float(step[0]["start"])
-print("step %.0f us, %d kernels" % (float(step[-1]["end"]) - t0, len(step)))
+
+def read(path):
+    rows = []
+    with open(path) as f:
+        f.readline()
+        for line in f:
+            a = line.rstrip("\n").split(",", 2)
+            b = a[2].rsplit(",", 7)
+            rows.append({"start": float(a[0]), "end": float(a[1]), "name": b[0].replace(", ", "_"),
+                         "queue": b[1], "grid": int(b[5])})
+    return rows
+
+
+rows = read(sys.argv[1])
+idx = [i for i, r in enumerate(rows) if r["name"].startswith("kmat_kernel")]
+# the last step starts at the last kmat launch that follows a reduction kernel (two kmat launches per step)
+starts = [i for i in idx if i == 0 or not rows[i - 1]["name"].startswith("kmat_kernel")]
+step = rows[starts[-1]:]
+t0 = step[0]["start"]
+print("step %.0f us, %d kernels" % (step[-1]["end"] - t0, len(step)))
 dur = defaultdict(list)
 for r in step:
-    dur[r["name"][:26]].append(float(r["end"]) - float(r["start"]))
+    dur[r["name"][:30]].append(r["end"] - r["start"])
 for k, v in dur.items():
     v.sort()
-    print(f"  {k:28s} n={len(v):4d} sum={sum(v)/1e3:8.2f} ms  med={v[len(v)//2]:7.1f} min={v[0]:7.1f} max={v[-1]:7.1f}")
-big = [(float(r["start"]) - t0, float(r["end"]) - t0) for r in step if r["name"].startswith("gemm_nt_kernel")]
-chain = [(float(r["start"]) - t0, float(r["end"]) - t0) for r in step
-         if ("potf2" in r["name"] or "trsm" in r["name"])]
-prev_end = 0
-for i in range(0, len(big) - 1, 2):
-    fp, rest = sorted(big[i:i + 2])
-    nxt = big[i + 2][0] if i + 2 < len(big) else 1e12
-    ch = [c for c in chain if c[0] >= fp[1] - 1 and c[1] <= nxt + 1]
-    cend = max(c[1] for c in ch) if ch else 0
-    print(f"panel {i//2+1:2d}: first {fp[1]-fp[0]:5.0f} | rest {rest[1]-rest[0]:6.0f} (start+{rest[0]-fp[1]:4.0f}) "
-          f"chain {cend-fp[1]:6.0f} n={len(ch):2d} | {'chain' if cend > rest[1] else 'gemm '} by {abs(cend-rest[1]):5.0f}")
+    print(f"  {k:30s} n={len(v):4d} sum={sum(v)/1e3:8.2f} ms  med={v[len(v)//2]:7.1f} min={v[0]:7.1f} max={v[-1]:7.1f}")
+big = [r for r in step if r["name"].startswith("gemm_nt_kernel")]
+mainq = big[0]["queue"] if big else None
+firsts = [r for r in step if r["name"].startswith("gemm_nt_small") and r["queue"] == mainq]
+chain = [r for r in step if r["name"].startswith("potf2") or r["name"].startswith("trsm")]
+for i, rest in enumerate(big):
+    fp = [f for f in firsts if f["end"] <= rest["start"] + 1]
+    fp = fp[-1] if fp else None
+    nxt = big[i + 1]["start"] if i + 1 < len(big) else 1e18
+    nxt_first = [f for f in firsts if f["start"] > rest["start"]]
+    lim = min(nxt, nxt_first[0]["start"] if nxt_first else 1e18)
+    ch = [c for c in chain if c["start"] >= (fp["end"] if fp else rest["start"]) - 1 and c["end"] <= lim + 1]
+    cend = max(c["end"] for c in ch) if ch else 0
+    base = fp["end"] if fp else rest["start"]
+    print(f"panel {i+1:2d}: first {(fp['end']-fp['start']) if fp else 0:5.0f} | rest {rest['end']-rest['start']:6.0f} "
+          f"chain {cend-base:6.0f} n={len(ch):2d} | {'chain' if cend > rest['end'] else 'gemm '} by {abs(cend-rest['end']):5.0f}")
