@@ -767,8 +767,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       // panel take the host longer than a small update takes the GPU) ...
       const int64_t m2 = mt - kbn;
       if (m2 > 0) {
-        TGP_TRY(trailing(m2, m2, kb, P + kbn, A + (next + kbn) * ld + next + kbn,
-                         ctx->lookahead >= 2 ? 2 : 0));
+        TGP_TRY(trailing(m2, m2, kb, P + kbn, A + (next + kbn) * ld + next + kbn, 0));
       }
       // 3. ... while the side stream factors the next panel
       TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));

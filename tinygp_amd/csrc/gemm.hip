@@ -540,14 +540,8 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   } else {
     g.nblk = g.tm * g.tn;
   }
-  // role 2 = trailing update that runs beside the look-ahead panel: 16 KiB of unused dynamic
-  // LDS caps it at ONE workgroup per CU, so half of every CU's registers / LDS stays free
-  // and the panel kernels (potf2, trsm, in-panel update) start at once instead of waiting
-  // ~half a tile time for a slot.
   if (role == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
-  else if (role == 2)
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 16384, st, g);
   else
     hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
   TGP_HIP_TRY(hipGetLastError());

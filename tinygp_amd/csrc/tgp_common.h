@@ -112,8 +112,9 @@ int launch_kmat_gemv(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int 
                      const T* X2, const T* v, T* out);
 
 // C (m x n) = beta*C + alpha*A*B^T ; mode 0: C -= A B^T ; mode 1: C = A B^T.
-// role: 0 = trailing update (profiled as the dominant kernel), 1 = everything else,
-// 3 = in-panel update that skips the first 128x128 diagonal tile (potf2 folds it in).
+// role: 0 = trailing update (profiled as the dominant kernel), 1 = everything else (64x64
+// tiles when k <= 256), 3 = in-panel update that skips the first 128x128 diagonal tile (potf2
+// folds it in), 4 = 64x64 tiles at any k (latency-bound look-ahead block-column update).
 template <typename T>
 int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k, const T* A,
                    int64_t lda, const T* B, int64_t ldb, T* C, int64_t ldc, int lower, int mode,
