@@ -154,3 +154,24 @@ def test_transforms_fold_into_coordinates():
     np.testing.assert_allclose(P.ravel(), X[:, 1])
     with pytest.raises(NotImplementedError):
         (transforms.Linear(2.0, kernels.Exp()) + kernels.Exp())._lower(x)
+
+
+def test_bench_trailing_update_accounting():
+    """bench.py's algorithmic-bytes model mirrors the launch shapes of the blocked Cholesky."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("bench", Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # one panel: nothing to update
+    assert bench.trailing_update_bytes(1024, 1024, 8) == (0, 0)
+    # two panels: one block-column update of 8x8 tiles' lower trapezoid (1024 x 1024, k = 1024)
+    total, launches = bench.trailing_update_bytes(2048, 1024, 8)
+    entries = 1024 * 1024 - 1024 * 1023 // 2
+    assert launches == 1 and total == 8 * (2 * entries + 1024 * 1024)
+    # ... which runs on the small-tile kernel (36 tiles <= threshold) and is then not counted
+    assert bench.trailing_update_bytes(2048, 1024, 8, first_small_tiles=1100) == (0, 0)
+    # c2: 15 block-column updates + 14 rest updates; all block columns are under the threshold
+    assert bench.trailing_update_bytes(16384, 1024, 8)[1] == 29
+    assert bench.trailing_update_bytes(16384, 1024, 8, first_small_tiles=1100)[1] == 14
