@@ -43,13 +43,16 @@ PMC_TRAFFIC_BYTES_PER_LAUNCH_C2 = (2 * 55.090e9 + 12.634e9) / 42
 PMC_TRAFFIC_NB = 1024
 
 
-def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles: int = 0):
-    """(algorithmic bytes, launches) of one factorisation's trailing-update launches.
+def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles: int = 0,
+                          first_split: int = 0):
+    """(algorithmic bytes, launches) of one factorisation's 128x128-tile trailing-update launches.
 
     Mirrors the launch shapes of csrc/chol.hip (look-ahead: next panel's block column, then
     the rest).  Per launch: the lower-trapezoid entries of C are read and written once and the
-    panel operand (m x kb) is read once.  Block-column updates of at most `first_small_tiles`
-    128x128 tiles run on the 64x64-tile kernel and are not part of the profiled kernel.
+    panel operand (m x k) is read once.  Block-column updates of at most `first_small_tiles`
+    128x128 tiles run on the 64x64-tile kernel and are not part of the profiled kernel; from
+    the second panel on a block-column update is issued in two k-ranges (`first_split` blocks
+    early, the rest after the panel).
     """
     total, launches = 0, 0
     k0 = 0
@@ -67,8 +70,12 @@ def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles:
             if which == 0 and tiles <= first_small_tiles:
                 continue
             entries = nn * m - nn * (nn - 1) // 2
-            total += itemsize * (2 * entries + m * kb)
-            launches += 1
+            ks = [kb]
+            if which == 0 and k0 > 0 and 0 < first_split < kb // 128:
+                ks = [first_split * 128, kb - first_split * 128]
+            for k in ks:
+                total += itemsize * (2 * entries + m * k)
+                launches += 1
         k0 = nxt
     return total, launches
 
@@ -289,6 +296,8 @@ def main():
     ctx.set_option("lookahead", la_used)
     fst_used = ctx.set_option("first_small_tiles", 0)
     ctx.set_option("first_small_tiles", fst_used)
+    fsp_used = ctx.set_option("first_split", 0)
+    ctx.set_option("first_split", fsp_used)
 
     X, y = synthetic.make_inputs(n, d, spec["dtype"])
 
@@ -356,7 +365,7 @@ def main():
         if not args.no_profile and acc["syrk_ms"] > 0:
             n_pad = -(-n // 128) * 128
             alg_bytes, alg_launches = trailing_update_bytes(n_pad, int(nb_used), np.dtype(dt).itemsize,
-                                                             int(fst_used))
+                                                             int(fst_used), int(fsp_used))
             achieved = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12
             launches = max(acc["syrk_launches"], 1.0)
             roofline = {
@@ -365,7 +374,7 @@ def main():
                 "frac": achieved / peak,
                 "traffic": (PMC_TRAFFIC_BYTES_PER_LAUNCH_C2
                             if (args.workload == "c2" and nb_used == PMC_TRAFFIC_NB and world == 1
-                                and la_used == 1 and fst_used == 1100) else None),
+                                and la_used == 1 and fst_used == 1100 and fsp_used == 5) else None),
                 "traffic_unit": "bytes/launch (PMC, profiles/r01_h_pmc_hbm_traffic_nb1024.md)",
                 "algorithmic_bytes_per_launch": alg_bytes / max(alg_launches, 1),
                 "avg_launch_ms": acc["syrk_ms"] / launches,

@@ -95,6 +95,8 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "lookahead"         1: factor the next panel beside the trailing update (default), 0: off
  *   "first_small_tiles" look-ahead block-column updates of at most this many 128x128 tiles
  *                       run on 64x64 tiles (default 1100)
+ *   "first_split"       blocks of a panel after which its share of the next block-column
+ *                       update is issued early, beside the panel's last blocks (default 5; 0 off)
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings) */
 int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* old);
 /* name (<=255 chars), CU count, memory bytes, clock kHz of the ctx's device */

@@ -171,6 +171,7 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   if (!strcmp(key, "nb_outer")) slot = &ctx->nb_outer;
   else if (!strcmp(key, "lookahead")) slot = &ctx->lookahead;
   else if (!strcmp(key, "profile")) slot = &ctx->profile;
+  else if (!strcmp(key, "first_split")) slot = &ctx->first_split;
   else if (!strcmp(key, "first_small_tiles")) slot = &ctx->first_small_tiles;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)

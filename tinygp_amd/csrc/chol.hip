@@ -14,6 +14,8 @@
 // trsm    X L^T = B for a 128-column panel: one wave per 16 rows, transposed recurrence
 //         Y_j = inv(L_jj) (B_j^T - sum_{k<j} L_jk Y_k) so that an MFMA result (D layout)
 //         is directly the next MFMA's B operand -- no LDS, no shuffles.
+#include <functional>
+
 #include "tgp_common.h"
 
 namespace tgp {
@@ -681,7 +683,10 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
                            (int32_t)j0, pend ? (const T*)(A + (j0 - TILE) * ld + j0) : (const T*)nullptr,
                            ld);
   };
-  auto panel = [&](hipStream_t st, int64_t k0, int64_t kb, bool head_done) -> int {
+  // `after_blocks` / `mid`: once that many blocks of the panel are final, mid() is called with
+  // ev_d recorded behind the last of them (the caller hangs an early partial update on it).
+  auto panel = [&](hipStream_t st, int64_t k0, int64_t kb, bool head_done, int64_t after_blocks,
+                   const std::function<int()>& mid) -> int {
     for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
       T* Ljj = A + j0 * ld + j0;
       T* dj = dinv + (j0 / TILE) * 2048;
@@ -705,9 +710,11 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
         TGP_HIP_TRY(hipStreamWaitEvent(S2, ctx->ev_d, 0));
         TGP_TRY(launch_trsv_fwd_step<T>(S2, mb, Ljj, ld, dj, y + j0));
       }
+      if (after_blocks > 0 && upd && j0 + TILE == k0 + after_blocks * TILE) TGP_TRY(mid());
     }
     return TGP_OK;
   };
+  const std::function<int()> no_mid = []() { return TGP_OK; };
   auto trailing = [&](int64_t m, int64_t nn, int64_t kb, const T* P, T* C, int role) -> int {
     ProfSpan sp{};
     const bool prof = prof_on && role != 4;  // spans time the 128x128-tile kernel only
@@ -740,13 +747,20 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     TGP_TRY(join_assembly());
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
       const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
-      TGP_TRY(panel(S0, k0, kb, false));
+      TGP_TRY(panel(S0, k0, kb, false, 0, no_mid));
       const int64_t next = k0 + kb, mt = n - next;
       if (mt > 0) TGP_TRY(trailing(mt, mt, kb, A + k0 * ld + next, A + next * ld + next, 0));
     }
   } else {
-    TGP_TRY(panel(S0, 0, (n < NB) ? n : NB, false));
+    TGP_TRY(panel(S0, 0, (n < NB) ? n : NB, false, 0, no_mid));
     TGP_TRY(join_assembly());
+    int64_t k_done = 0;
+    // With fewer 128x128 tiles than ~2 rounds of workgroup slots the block-column update is
+    // a round of long serial k-loops, two per CU on some CUs: 64x64 tiles spread it evenly.
+    auto first_role = [&](int64_t m, int64_t nn) -> int {
+      const int64_t tiles = (m / TILE) * (nn / TILE) - (nn / TILE) * (nn / TILE - 1) / 2;
+      return tiles <= ctx->first_small_tiles ? 4 : 0;
+    };
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
       const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
       const int64_t next = k0 + kb, mt = n - next;
@@ -754,11 +768,10 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       const int64_t kbn = (mt < NB) ? mt : NB;
       const T* P = A + k0 * ld + next;
       // 1. block column of the next panel first ...
-      // With fewer 128x128 tiles than workgroup slots (512) the update is one round of long
-      // serial k-loops, two per CU on some CUs: 64x64 tiles spread it evenly (role 4).
-      const int64_t first_tiles = (mt / TILE) * (kbn / TILE) - (kbn / TILE) * (kbn / TILE - 1) / 2;
-      TGP_TRY(trailing(mt, kbn, kb, P, A + next * ld + next,
-                       first_tiles <= ctx->first_small_tiles ? 4 : 0));
+      // (`k_done` columns of this panel were already applied while its last blocks were
+      // being factored -- see `early` below.)
+      TGP_TRY(trailing(mt, kbn, kb - k_done, P + k_done * ld, A + next * ld + next, first_role(mt, kbn)));
+      k_done = 0;
       // the panel's first potf2 goes in front of the big update on the main stream: issued
       // beside it, it waits a whole round of tiles (~0.3 ms) for a free CU
       TGP_TRY(potf2_at(S0, next, false));
@@ -769,9 +782,23 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       if (m2 > 0) {
         TGP_TRY(trailing(m2, m2, kb, P + kbn, A + (next + kbn) * ld + next + kbn, 0));
       }
-      // 3. ... while the side stream factors the next panel
+      // 3. ... while the side stream factors the next panel.  Once its first `first_split`
+      // blocks are final, their share of the block-column update that will gate the panel
+      // AFTER it is issued behind the running update, so that only the last blocks' share
+      // (a quarter of the k-range) is left on the critical path between two chains.
       TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
-      TGP_TRY(panel(S1, next, kbn, true));
+      const int64_t next2 = next + kbn, mt2 = n - next2;
+      const int64_t kbn2 = (mt2 < NB) ? mt2 : NB;
+      const int64_t split = (mt2 > 0 && ctx->first_split > 0 && ctx->first_split < kbn / TILE)
+                                ? ctx->first_split : 0;
+      const std::function<int()> early = [&]() -> int {
+        TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_d, 0));
+        TGP_TRY(trailing(mt2, kbn2, split * TILE, A + next * ld + next2, A + next2 * ld + next2,
+                         first_role(mt2, kbn2)));
+        k_done = split * TILE;
+        return TGP_OK;
+      };
+      TGP_TRY(panel(S1, next, kbn, true, split, early));
       TGP_HIP_TRY(hipEventRecord(ctx->ev_b, S1));
       TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_b, 0));
     }

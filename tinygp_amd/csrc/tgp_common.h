@@ -71,6 +71,7 @@ struct tgp_ctx {
   int64_t nb_outer = 1024;  // measured best for N = 4k .. 32k (profiles/r01_f_nb_sweep.txt)
   int64_t lookahead = 1;
   int64_t profile = 0;
+  int64_t first_split = 5;  // blocks of a panel after which its share of the next block-column update is issued early (0: off)
   int64_t first_small_tiles = 1100;  // look-ahead block-column updates up to this many tiles use 64x64 tiles
   // small device scratch: scal[0..15] doubles, info int
   double* d_scal = nullptr;
