@@ -50,9 +50,9 @@ def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles:
     Mirrors the launch shapes of csrc/chol.hip (look-ahead: next panel's block column, then
     the rest).  Per launch: the lower-trapezoid entries of C are read and written once and the
     panel operand (m x k) is read once.  Block-column updates of at most `first_small_tiles`
-    128x128 tiles run on the 64x64-tile kernel and are not part of the profiled kernel; from
-    the second panel on a block-column update is issued in two k-ranges (`first_split` blocks
-    early, the rest after the panel).
+    128x128 tiles run on the 64x64-tile kernel and are not part of the profiled kernel; a
+    block-column update is issued in two k-ranges (`first_split` blocks early, the rest after
+    the panel).
     """
     total, launches = 0, 0
     k0 = 0
@@ -71,7 +71,7 @@ def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles:
                 continue
             entries = nn * m - nn * (nn - 1) // 2
             ks = [kb]
-            if which == 0 and k0 > 0 and 0 < first_split < kb // 128:
+            if which == 0 and 0 < first_split < kb // 128:
                 ks = [first_split * 128, kb - first_split * 128]
             for k in ks:
                 total += itemsize * (2 * entries + m * k)

@@ -752,8 +752,6 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       if (mt > 0) TGP_TRY(trailing(mt, mt, kb, A + k0 * ld + next, A + next * ld + next, 0));
     }
   } else {
-    TGP_TRY(panel(S0, 0, (n < NB) ? n : NB, false, 0, no_mid));
-    TGP_TRY(join_assembly());
     int64_t k_done = 0;
     // With fewer 128x128 tiles than ~2 rounds of workgroup slots the block-column update is
     // a round of long serial k-loops, two per CU on some CUs: 64x64 tiles spread it evenly.
@@ -761,6 +759,25 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       const int64_t tiles = (m / TILE) * (nn / TILE) - (nn / TILE) * (nn / TILE - 1) / 2;
       return tiles <= ctx->first_small_tiles ? 4 : 0;
     };
+    {  // first panel: on the side stream too, so that the main stream can take the early share
+      const int64_t kb0 = (n < NB) ? n : NB, mt0 = n - kb0;
+      const int64_t kbn0 = (mt0 < NB) ? mt0 : NB;
+      const int64_t split = (mt0 > 0 && ctx->first_split > 0 && ctx->first_split < kb0 / TILE)
+                                ? ctx->first_split : 0;
+      const std::function<int()> early = [&]() -> int {
+        TGP_TRY(join_assembly());
+        TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_d, 0));
+        TGP_TRY(trailing(mt0, kbn0, split * TILE, A + kb0, A + kb0 * ld + kb0, first_role(mt0, kbn0)));
+        k_done = split * TILE;
+        return TGP_OK;
+      };
+      TGP_HIP_TRY(hipEventRecord(ctx->ev_a, S0));
+      TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
+      TGP_TRY(panel(S1, 0, kb0, false, split, early));
+      TGP_HIP_TRY(hipEventRecord(ctx->ev_b, S1));
+      TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_b, 0));
+      TGP_TRY(join_assembly());
+    }
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
       const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
       const int64_t next = k0 + kb, mt = n - next;
