@@ -228,6 +228,29 @@ def test_mid_sizes_against_golden(golden_dir):
     np.testing.assert_allclose(gp.log_probability(yb), g["bench_m32_n2000__logp"], rtol=LL_RTOL)
 
 
+@pytest.mark.parametrize("n", [1100, 2500, 3333, 5000])
+def test_ragged_multi_panel_sizes_against_oracle(n):
+    """Sizes that are multiples of neither the 128 tile nor the 1024 outer panel: several outer
+    panels with a short last one (look-ahead, early block-column share, side-stream assembly
+    and the fused forward substitution all take their edge branches)."""
+    X, y = _cases.synthetic.make_inputs(n, 1)
+    gp = GaussianProcess(_cases.synthetic.config_kernel(kernels, "expsq"), X, diag=0.01)
+    ref = o.GaussianProcess(_cases.synthetic.config_kernel(o, "expsq"), X, diag=0.01)
+    np.testing.assert_allclose(gp.log_probability(y), ref.log_probability(y), rtol=LL_RTOL)
+    t = np.linspace(X[0], X[-1], 37)
+    np.testing.assert_allclose(gp.predict(y, t), ref.predict(y, t), **TOL)
+    # the optimiser-step entry point (fused assembly + factorisation + solve) on the same solver
+    k2 = 1.3**2 * kernels.ExpSquared(2.0)
+    ll2 = gp.solver.factor_log_probability(y, k2)
+    ref2 = o.GaussianProcess(1.3**2 * o.ExpSquared(2.0), X, diag=0.01).log_probability(y)
+    np.testing.assert_allclose(ll2, ref2, rtol=LL_RTOL)
+    X32 = X.astype(np.float32)
+    gp32 = GaussianProcess(_cases.synthetic.config_kernel(kernels, "expsq"), X32, diag=np.float32(0.1))
+    ref32 = o.GaussianProcess(_cases.synthetic.config_kernel(o, "expsq"), X32.astype(np.float64), diag=0.1)
+    np.testing.assert_allclose(gp32.log_probability(y.astype(np.float32)), ref32.log_probability(y),
+                               rtol=5e-4)
+
+
 def _factor_property_checks(gp, X, k, diag, seed):
     """Size-independent properties: (i) L^-T L^-1 (K z) == z with K z from the fused
     kernel mat-vec, which never touches the factor; (ii) L^-1 (L z) == z."""
