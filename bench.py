@@ -239,7 +239,7 @@ def run_distributed(args, spec, X, y, rank, local_rank, world, dist, torch):
     if rank == 0:
         flops = n**3 / 3.0
         result = ({
-            "metric": "GP log_probability evals/sec + Cholesky TFLOP/s (fp64), N=16,384",
+            "metric": f"GP log_probability evals/sec + Cholesky TFLOP/s ({'fp64' if dt == np.float64 else 'fp32'}), N={n:,}",
             "value": args.steps / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64" if dt == np.float64 else "f32",
@@ -390,7 +390,7 @@ def main():
             if args.stages:
                 print(json.dumps(extra, indent=1), file=sys.stderr)
         out = {
-            "metric": "GP log_probability evals/sec + Cholesky TFLOP/s (fp64), N=16,384",
+            "metric": f"GP log_probability evals/sec + Cholesky TFLOP/s ({'fp64' if dt == np.float64 else 'fp32'}), N={n:,}",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
