@@ -1,11 +1,10 @@
 #!/bin/bash
-# BASELINE config 4's matrix (N = 131072, fp64: a 137 GB factor) on ONE MI355X
+# BASELINE config 5's matrix (N = 262144, fp32: a 256 GiB factor) on ONE MI355X
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 {
-rocm-smi --showmeminfo vram 2>/dev/null | grep -i "total\|used" | head -4
-timeout 240 python bench.py --workload n131072 --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-1500
+timeout 300 python bench.py --workload n262144f32 --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | tail -3 | cut -c1-1600
 } > $R/gpurun_out/round.log 2>&1
 cat $R/gpurun_out/round.log
