@@ -1,6 +1,7 @@
-"""Per-panel view of a timeline CSV written by timeline.py (last bench step): the look-ahead
-block-column update (`first`), the big trailing update beside the chain (`rest`), the length
-of the potf2/trsm chain of the next panel, and which of the two finished last."""
+"""Per-panel view of a timeline CSV written by timeline.py (last bench step): `gate` = the last
+share of the look-ahead block-column update (64x64 tiles) before the chain starts, `rest` =
+the big trailing update beside the chain, the length of the potf2/trsm chain of the next
+panel, and which of the two finished last."""
 import sys
 from collections import defaultdict
 
@@ -35,13 +36,15 @@ mainq = big[0]["queue"] if big else None
 firsts = [r for r in step if r["name"].startswith("gemm_nt_small") and r["queue"] == mainq]
 chain = [r for r in step if r["name"].startswith("potf2") or r["name"].startswith("trsm")]
 for i, rest in enumerate(big):
-    fp = [f for f in firsts if f["end"] <= rest["start"] + 1]
-    fp = fp[-1] if fp else None
-    nxt = big[i + 1]["start"] if i + 1 < len(big) else 1e18
-    nxt_first = [f for f in firsts if f["start"] > rest["start"]]
-    lim = min(nxt, nxt_first[0]["start"] if nxt_first else 1e18)
-    ch = [c for c in chain if c["start"] >= (fp["end"] if fp else rest["start"]) - 1 and c["end"] <= lim + 1]
+    # the panel's own first potf2 runs on the main stream just before `rest`
+    lo = rest["start"] - 80
+    hi = (big[i + 1]["start"] - 80) if i + 1 < len(big) else 1e18
+    ch = [c for c in chain if lo <= c["start"] < hi]
+    fp = [f for f in firsts if lo - 1 <= f["start"] < hi]       # early + final shares issued in this window
+    fin = [f for f in firsts if f["end"] <= rest["start"] + 1]  # the share that gated this chain
+    gate = fin[-1] if fin else None
     cend = max(c["end"] for c in ch) if ch else 0
-    base = fp["end"] if fp else rest["start"]
-    print(f"panel {i+1:2d}: first {(fp['end']-fp['start']) if fp else 0:5.0f} | rest {rest['end']-rest['start']:6.0f} "
-          f"chain {cend-base:6.0f} n={len(ch):2d} | {'chain' if cend > rest['end'] else 'gemm '} by {abs(cend-rest['end']):5.0f}")
+    cstart = min(c["start"] for c in ch) if ch else 0
+    print(f"panel {i+1:2d}: gate {(gate['end']-gate['start']) if gate else 0:5.0f} | rest {rest['end']-rest['start']:6.0f} "
+          f"chain {cend-cstart:6.0f} n={len(ch):2d} early+final shares {len(fp)} | "
+          f"{'chain' if cend > rest['end'] else 'gemm '} by {abs(cend-rest['end']):5.0f}")
