@@ -251,6 +251,26 @@ def test_ragged_multi_panel_sizes_against_oracle(n):
                                rtol=5e-4)
 
 
+@pytest.mark.parametrize("n,reps", [(5000, 40), (4096, 40), (16384, 6)])
+def test_multi_stream_schedule_is_deterministic(n, reps):
+    """Race detector: the factorisation runs on five streams; its arithmetic has fixed
+    reduction orders and no atomics, so repeated fused evaluations of the same inputs must
+    be BIT-identical.  A missing stream dependency shows up as an occasional different bit
+    pattern (scripts/stress_determinism.py is the long version)."""
+    X, y = _cases.synthetic.make_inputs(n, 1)
+    ks = [1.5**2 * kernels.ExpSquared(2.5), 1.4**2 * kernels.ExpSquared(2.2)]
+    solver = DirectSolver(ks[0], X, noise.Diagonal(np.full(n, 0.01)))
+    solver.set_residual(y)
+    ref = [solver.factor_log_probability(None, k) for k in ks]
+    assert all(np.isfinite(ref))
+    for r in range(reps):
+        assert solver.factor_log_probability(None, ks[r % 2]) == ref[r % 2], (n, r)
+    solver.refactor(ks[0])
+    L1 = np.array(solver.scale_tril)
+    solver.refactor(ks[0])
+    assert np.array_equal(L1, np.array(solver.scale_tril))
+
+
 def _factor_property_checks(gp, X, k, diag, seed):
     """Size-independent properties: (i) L^-T L^-1 (K z) == z with K z from the fused
     kernel mat-vec, which never touches the factor; (ii) L^-1 (L z) == z."""
