@@ -4,6 +4,6 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 {
-timeout 600 python scripts/stress_determinism.py
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -5
 } > $R/gpurun_out/round.log 2>&1
 cat $R/gpurun_out/round.log
