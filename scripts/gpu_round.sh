@@ -4,6 +4,6 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 {
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -5
+for w in n512 n1024 n2048 n4096 n8192 c2; do echo "## $w"; bash scripts/bench_variants.sh "--workload $w --steps 20 --warmup 5" | tail -1 | cut -c1-90; done
 } > $R/gpurun_out/round.log 2>&1
 cat $R/gpurun_out/round.log
