@@ -4,6 +4,8 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 {
-for w in n512 n1024 n2048 n4096 n8192 c2; do echo "## $w"; bash scripts/bench_variants.sh "--workload $w --steps 20 --warmup 5" | tail -1 | cut -c1-90; done
+timeout 60 ./scripts/probe_potf2 | tail -10
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_gp.py -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert|Mismatch|Max abs|Max rel" | tail -8
+for w in c2 n4096 n8192; do bash scripts/bench_variants.sh "--workload $w" | tail -1 | cut -c1-70; done
 } > $R/gpurun_out/round.log 2>&1
 cat $R/gpurun_out/round.log

@@ -15,6 +15,7 @@
 //         Y_j = inv(L_jj) (B_j^T - sum_{k<j} L_jk Y_k) so that an MFMA result (D layout)
 //         is directly the next MFMA's B operand -- no LDS, no shuffles.
 #include <functional>
+#include <type_traits>
 
 #include "tgp_common.h"
 
@@ -114,8 +115,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   __shared__ __attribute__((aligned(16))) T S[36 * 256];
-  __shared__ __attribute__((aligned(16))) T Wb[16 * 16];  // Wb[k * 16 + c] = W[c][k]
-  __shared__ T Rs[16];                                     // 1 / L_ii of the current block
+  __shared__ T Rs[2 * 16];                                 // 1 / L_ii of the current / previous block
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar address math
   const int lrow = lane & 15;
@@ -223,138 +223,141 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   __syncthreads();
 
-  // P1 for diagonal block kb (wave 0 only; lanes 16..63 mirror lanes 0..15)
-  auto factor_diag = [&](int kb) {
+  // ---- column block kb: unblocked right-looking elimination with lane = ROW, for the diagonal
+  // block AND the blocks below it at once.  Lanes 0..15 of an eliminating wave hold the 16 rows
+  // of the diagonal block, lanes 16..63 the rows of three blocks below it (group g: blocks
+  // kb+1+3g .. kb+3+3g).  The pivot-row values every lane needs are broadcast from lanes
+  // 0..15 through v_readlane -> SGPR operands, so the rows below ride along in the same VALU
+  // instructions for free: there is no separate "L_ik = A_ik L_kk^-T" phase (and no 16x16
+  // inverse) on the critical path.  With more than three blocks below, waves 1 (and 2) take
+  // the other groups and simply repeat the diagonal block's elimination in their lanes 0..15
+  // -- no communication between the eliminating waves.
+  auto factor_panel = [&](int kb, int grp) {
     const int k0 = kb * 16;
-      const int i = lrow;
-      T* D = &S[blk(kb, kb)];
-      T a[16];
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // opaque: lane predicates are recomputed here, not hoisted
+                                  // out of the kb loop as dozens of live SGPR masks
+    const int lr = ln & 15;
+    const int i0 = (ln < 16) ? kb : kb + 3 * grp + (ln >> 4);
+    const bool keep = (i0 < 8) && (ln >= 16 || grp == 0);  // rows this wave writes back
+    T* B0 = &S[blk(i0 < 8 ? i0 : kb, kb)];
+    T a0[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = D[c * 16 + i];
-      // The pivot of column j+1 is predicted from scalars that exist BEFORE the vector update
-      // of step j lands (d_{j+1} = a_{j+1,j+1} - a_{j+1,j}^2 / d_j), so the reciprocal chain
-      // -- the critical path of the 16 sequential columns -- never waits for a VALU -> readlane
-      // round trip; the vector updates run in its shadow.
-      int bad = 0;
-      T d = readlane(a[0], 0);
+    for (int c = 0; c < 16; ++c) a0[c] = B0[c * 16 + lr];
+    // The pivot of column j+1 is predicted from scalars that exist BEFORE the vector update
+    // of step j lands (d_{j+1} = a_{j+1,j+1} - a_{j+1,j}^2 / d_j), so the reciprocal chain
+    // -- the critical path of the 16 sequential columns -- never waits for a VALU -> readlane
+    // round trip; the vector updates run in its shadow.
+    int bad = 0;
+    T d = readlane(a0[0], 0);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (!(d > T(0)) && bad == 0) bad = j + 1;
-        const T rinv = fast_rcp(d);
-        if (j + 1 < 16) {
-          const T t = readlane(a[j], j + 1), u = readlane(a[j + 1], j + 1);
-          d = u - (t * t) * rinv;
-        }
-        const T v = a[j] * rinv;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) a[c] -= v * readlane(a[j], c);
+    for (int j = 0; j < 16; ++j) {
+      if (!(d > T(0)) && bad == 0) bad = j + 1;
+      const T rinv = fast_rcp(d);
+      if (j + 1 < 16) {
+        const T t = readlane(a0[j], j + 1), u = readlane(a0[j + 1], j + 1);
+        d = u - (t * t) * rinv;
       }
-      if (bad != 0 && lane == 0) atomicCAS(info, 0, pivot_base + k0 + bad);
-      T dd = a[0];
+      const T w0 = a0[j] * rinv;
 #pragma unroll
-      for (int j = 1; j < 16; ++j) dd = (i == j) ? a[j] : dd;
-      const T rs = fast_rsqrt(dd);  // 1 / L_ii; NaN poisons the factor when d <= 0
+      for (int c = j + 1; c < 16; ++c) a0[c] -= w0 * readlane(a0[j], c);  // (row c, col j)
+    }
+    if (grp == 0 && bad != 0 && ln == 0) atomicCAS(info, 0, pivot_base + k0 + bad);
+    // scale column j by 1 / L_jj = rsqrt(d_j): one vector rsqrt over the diagonal (lane j
+    // holds d_j in a0[j]) instead of sixteen scalar ones inside the loop
+    T dd = a0[0];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const T rsj = readlane(rs, j);
-        a[j] = (i >= j) ? a[j] * rsj : T(0);
-      }
-      // L block (zeros above the diagonal) and 1/L_ii to LDS: the inversion below reads them
-      // back as same-address broadcasts (no SGPR traffic: hoisted v_readlane results spilled)
-      if (lane < 16) {
+    for (int j = 1; j < 16; ++j) dd = (lr == j) ? a0[j] : dd;
+    const T rs = fast_rsqrt(dd);  // lanes 0..15: 1 / L_ii; NaN / inf poisons the factor when d <= 0
 #pragma unroll
-        for (int c = 0; c < 16; ++c) D[c * 16 + i] = a[c];
-        Rs[i] = rs;
-      }
-      // W = L^-1, lane c owns column c, outer-product order (short dependency chain):
-      //   x_k = s_k / L_kk ;  s_i -= L_ik x_k  (i > k)
-      T sv[16], x[16];
+    for (int j = 0; j < 16; ++j) a0[j] *= readlane(rs, j);
+    if (grp == 0 && ln < 16) Rs[(kb & 1) * 16 + lr] = rs;
+    // (entries above the diagonal of the diagonal block are left as they are: nothing reads
+    // them in LDS and the final store writes zeros there)
+    if (keep) {
 #pragma unroll
-      for (int ii = 0; ii < 16; ++ii) sv[ii] = (ii == i) ? T(1) : T(0);
+      for (int c = 0; c < 16; ++c) B0[c * 16 + lr] = a0[c];
+    }
+  };
+  // W = L_kk^-1 (one wave, off the critical path; only the panel solves that FOLLOW this kernel
+  // need it): lane c owns column c, outer-product order, operands as LDS broadcasts.
+  auto invert_diag = [&](int kb) {
+    int i = lrow;
+    asm volatile("" : "+v"(i));  // see factor_panel
+    const T* D = &S[blk(kb, kb)];
+    const T* R = &Rs[(kb & 1) * 16];
+    T* out = dinv + kb * 256 + i * 16;  // element (row c, col i) of W at i * 16 + c
+    T sv[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        x[k] = sv[k] * Rs[k];
+    for (int ii = 0; ii < 16; ++ii) sv[ii] = (ii == i) ? T(1) : T(0);
 #pragma unroll
-        for (int ii = k + 1; ii < 16; ++ii) sv[ii] -= D[k * 16 + ii] * x[k];
-      }
-      if (lane < 16) {
+    for (int k = 0; k < 16; ++k) {
+      const T xk = sv[k] * R[k];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          Wb[i * 16 + c] = x[c];               // row k = i of Wb holds W[:, k]
-          dinv[kb * 256 + i * 16 + c] = x[c];  // element (row c, col i) of W at i*16 + c
-        }
-      }
-      };
+      for (int ii = k + 1; ii < 16; ++ii) sv[ii] -= D[k * 16 + ii] * xk;
+      sv[k] = xk;
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) out[c] = sv[c];
+    }
+  };
+  // A_ij -= L_ik L_jk^T on the MFMAs (one 16x16 block pair per call)
+  auto update_pair = [&](int ib, int jb, int kb) {
+    T* Cij = &S[blk(ib, jb)];
+    const T* Xi = &S[blk(ib, kb)];
+    const T* Xj = &S[blk(jb, kb)];
+    acc_t acc, acc2 = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Cij[M::drow(lane, r) * 16 + lrow];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int kk = M::drow(lane, s);
+      const T xj = -Xj[kk * 16 + lrow], xi = Xi[kk * 16 + lrow];
+      if (s & 1) acc2 = M::mma(xj, xi, acc2);
+      else acc = M::mma(xj, xi, acc);
+    }
+    acc += acc2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] = acc[r];
+  };
 
-  if (w == 0) factor_diag(0);
+  // eliminating waves of step kb: one per three blocks below the diagonal block
+  auto n_elim = [](int kb) { return kb >= 7 ? 1 : (7 - kb + 2) / 3; };
   for (int kb = 0; kb < 8; ++kb) {
     POTF2_STAMP(1 + 4 * kb);
+    if (w < n_elim(kb)) factor_panel(kb, w);
     POTF2_STAMP(2 + 4 * kb);
-    __syncthreads();
+    __syncthreads();  // column block kb of L is final; the updates of step kb-1 are complete
     POTF2_STAMP(3 + 4 * kb);
-    // ---- P2: L_ik = A_ik W^T for the blocks below (block i -> wave (i-kb-1)) ----------
-    {
-      const int ib = kb + 1 + w;
-      if (ib < 8) {
-        T* X = &S[blk(ib, kb)];
-        acc_t acc = acc_t{0, 0, 0, 0}, acc2 = acc_t{0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int kk = M::drow(lane, s);
-          const T wv = Wb[kk * 16 + lrow] /* W[c=lrow][kk] */, xv = X[kk * 16 + lrow] /* A_ik[r=lrow][kk] */;
-          if (s & 1) acc2 = M::mma(wv, xv, acc2);
-          else acc = M::mma(wv, xv, acc);
-        }
-        acc += acc2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) X[M::drow(lane, r) * 16 + lrow] = acc[r];
-      }
+    if (kb == 7) {
+      if (w == 1) invert_diag(7);
+      break;
     }
+    // column block kb+1 first (all that the next elimination needs): one pair per wave
+    if (kb + 1 + w < 8) update_pair(kb + 1 + w, kb + 1, kb);
     __syncthreads();
     POTF2_STAMP(4 + 4 * kb);
-    // ---- P3: A_ij -= L_ik L_jk^T for kb < j <= i.  Wave 0 takes the next diagonal block first
-    // and factors it straight away (in-kernel look-ahead: P1 of step kb+1 hides under the
-    // other waves' updates); waves 1..7 share the remaining pairs.
-    {
-      auto update_pair = [&](int ib, int jb) {
-        T* Cij = &S[blk(ib, jb)];
-        const T* Xi = &S[blk(ib, kb)];
-        const T* Xj = &S[blk(jb, kb)];
-        acc_t acc, acc2 = acc_t{0, 0, 0, 0};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = Cij[M::drow(lane, r) * 16 + lrow];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int kk = M::drow(lane, s);
-          const T xj = -Xj[kk * 16 + lrow], xi = Xi[kk * 16 + lrow];
-          if (s & 1) acc2 = M::mma(xj, xi, acc2);
-          else acc = M::mma(xj, xi, acc);
-        }
-        acc += acc2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] = acc[r];
-      };
-      if (w == 0) {
-        if (kb + 1 < 8) {
-          update_pair(kb + 1, kb + 1);
-          factor_diag(kb + 1);
-        }
-      } else {
-        int cnt = 0;
-        for (int jb = kb + 1; jb < 8; ++jb)
-          for (int ib = jb; ib < 8; ++ib) {
-            if (ib == kb + 1 && jb == kb + 1) continue;
-            if ((cnt++ % 7) + 1 != w) continue;
-            update_pair(ib, jb);
-          }
-      }
+    // the eliminating waves go straight on to column block kb+1; beside them one wave inverts
+    // L_kk and the others update the remaining pairs (in-kernel look-ahead)
+    const int ne = n_elim(kb + 1);
+    if (w == ne) {
+      invert_diag(kb);
+    } else if (w > ne) {
+      const int nw = 7 - ne;
+      int cnt = 0;
+      for (int jb = kb + 2; jb < 8; ++jb)
+        for (int ib = jb; ib < 8; ++ib)
+          if ((cnt++ % nw) + ne + 1 == w) update_pair(ib, jb, kb);
     }
-    __syncthreads();
   }
+  __syncthreads();
 
   POTF2_STAMP(33);
   // write L; everything above the diagonal of the tile is zero (clean diagonal tiles)
-  for (int e = tid; e < 128 * 128; e += 512) {
+#pragma unroll 8
+  for (int q = 0; q < 32; ++q) {
+    const int e = tid + 512 * q;
     const int c = e >> 7, r = e & 127;
     const int i = r >> 4, j = c >> 4;
     A[int64_t(c) * ld + r] = (r >= c) ? S[blk(i, j) + (c & 15) * 16 + (r & 15)] : T(0);
