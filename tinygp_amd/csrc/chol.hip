@@ -322,6 +322,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] = acc[r];
   };
 
+  // the 128 x 16 strip of column block cb of the tile -> global (zeros above the diagonal)
+  auto store_strip = [&](int cb, int q0, int q1) {
+#pragma unroll 4
+    for (int q = q0; q < q1; ++q) {
+      const int e = lane + 64 * q;  // 128 rows x 16 columns
+      const int cl = e >> 7, r = e & 127, c = cb * 16 + cl;
+      A[int64_t(c) * ld + r] = (r >= c) ? S[blk(r >> 4, cb) + cl * 16 + (r & 15)] : T(0);
+    }
+  };
   // eliminating waves of step kb: one per three blocks below the diagonal block
   auto n_elim = [](int kb) { return kb >= 7 ? 1 : (7 - kb + 2) / 3; };
   for (int kb = 0; kb < 8; ++kb) {
@@ -349,19 +358,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int jb = kb + 2; jb < 8; ++jb)
         for (int ib = jb; ib < 8; ++ib)
           if ((cnt++ % nw) + ne + 1 == w) update_pair(ib, jb, kb);
+      // column block kb is final: it goes out under the next step, a slice per updating wave
+      const int sl = w - ne - 1;
+      store_strip(kb, sl * 32 / nw, (sl + 1) * 32 / nw);
     }
   }
   __syncthreads();
 
   POTF2_STAMP(33);
-  // write L; everything above the diagonal of the tile is zero (clean diagonal tiles)
-#pragma unroll 8
-  for (int q = 0; q < 32; ++q) {
-    const int e = tid + 512 * q;
-    const int c = e >> 7, r = e & 127;
-    const int i = r >> 4, j = c >> 4;
-    A[int64_t(c) * ld + r] = (r >= c) ? S[blk(i, j) + (c & 15) * 16 + (r & 15)] : T(0);
-  }
+  // column blocks 0..6 went out while later steps ran; the last one now, a slice per wave
+  store_strip(7, 4 * w, 4 * w + 4);
   POTF2_STAMP(34);
 }
 
