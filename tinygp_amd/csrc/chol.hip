@@ -259,8 +259,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         d = u - (t * t) * rinv;
       }
       const T w0 = a0[j] * rinv;
+      // (row c, col j) of the diagonal block, fetched one element ahead of its use so that the
+      // SGPR write -> VALU read wait states of v_readlane are covered by the previous FMA
+      T bnext = (j + 1 < 16) ? readlane(a0[j], j + 1) : T(0);
 #pragma unroll
-      for (int c = j + 1; c < 16; ++c) a0[c] -= w0 * readlane(a0[j], c);  // (row c, col j)
+      for (int c = j + 1; c < 16; ++c) {
+        const T bc = bnext;
+        if (c + 1 < 16) bnext = readlane(a0[j], c + 1);
+        a0[c] -= w0 * bc;
+      }
     }
     if (grp == 0 && bad != 0 && ln == 0) atomicCAS(info, 0, pivot_base + k0 + bad);
     // scale column j by 1 / L_jj = rsqrt(d_j): one vector rsqrt over the diagonal (lane j
