@@ -73,13 +73,16 @@ __device__ __forceinline__ float fast_rsqrt(float x) {
 // potf2: 128x128 diagonal block in ONE workgroup (8 waves), matrix resident in LDS.
 //
 // Right-looking over 16-column blocks kb = 0..7:
-//   P1  wave 0 factors the 16x16 diagonal block in registers (lane = row; cross-lane
-//       broadcasts through v_readlane -> SGPR operands) and inverts it (W = L_kk^-1);
-//   P2  the blocks below are solved with MFMAs:  L_ik = A_ik W^T       (one block per wave)
-//   P3  rank-16 trailing update with MFMAs:      A_ij -= L_ik L_jk^T   (block pairs per wave)
-// Every MFMA operand is "16 consecutive rows at fixed k" of the column-major LDS image
-// (leading dimension 144: conflict-free), and every D tile is written back row-contiguous.
-// The eight W blocks are also stored to `dinv` for the trsm / trsv kernels.
+//   E   the whole column block (diagonal block + the blocks below it) is eliminated in VALU
+//       registers with lane = row; the pivot-row values are broadcast through v_readlane ->
+//       SGPR operands (1..3 eliminating waves, three blocks below the diagonal per wave);
+//   U1  rank-16 update of column block kb+1 with MFMAs (one block pair per wave) -- all that
+//       the next elimination needs;
+//   U2  beside the next elimination: the remaining block pairs (A_ij -= L_ik L_jk^T), the
+//       16x16 inverse W = L_kk^-1 (stored to `dinv` for the trsm / trsv kernels that follow)
+//       and the write-out of the finished column strip.
+// Every MFMA operand is "16 consecutive rows at fixed k" of a column-major 16x16 block of the
+// LDS image, and every D tile is written back row-contiguous.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ double readlane(double v, int lane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -92,7 +95,7 @@ __device__ __forceinline__ float readlane(float v, int lane) {
 }
 
 // LDS image: only the 36 lower 16x16 blocks, each contiguous and column-major
-// (element (r, c) of block (i, j) at blk(i, j) * 256 + c * 16 + r).  72 KiB + W: small
+// (element (r, c) of block (i, j) at blk(i, j) * 256 + c * 16 + r).  72 KiB: small
 // enough to share a CU with one 74 KiB GEMM workgroup during look-ahead, and a 32-lane
 // operand read (16 rows x 2 k) is 256 contiguous bytes: conflict-free without padding.
 __device__ __forceinline__ constexpr int blk(int i, int j) { return (i * (i + 1) / 2 + j) * 256; }
