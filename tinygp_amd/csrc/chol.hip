@@ -360,17 +360,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // the eliminating waves go straight on to column block kb+1; beside them one wave inverts
     // L_kk and the others update the remaining pairs (in-kernel look-ahead)
     const int ne = n_elim(kb + 1);
-    if (w == ne) {
-      invert_diag(kb);
-    } else if (w > ne) {
-      const int nw = 7 - ne;
-      int cnt = 0;
-      for (int jb = kb + 2; jb < 8; ++jb)
-        for (int ib = jb; ib < 8; ++ib)
-          if ((cnt++ % nw) + ne + 1 == w) update_pair(ib, jb, kb);
-      // column block kb is final: it goes out under the next step, a slice per updating wave
-      const int sl = w - ne - 1;
-      store_strip(kb, sl * 32 / nw, (sl + 1) * 32 / nw);
+    // fp64 MFMA and fp64 VALU share a SIMD's ALUs and wave w runs on SIMD w % 4: an
+    // elimination alone on its SIMD takes 4.7 k cycles instead of 5.0-5.8 k.  Once a single
+    // wave eliminates (column blocks 4..7) there are few enough block pairs left for the wave
+    // that shares its SIMD (wave 4) to sit the step out; the earlier steps need all eight.
+    const bool reserve = ne == 1;
+    const bool sits_out = reserve && w >= 4 && w < 4 + ne;
+    if (w >= ne && !sits_out) {
+      const int nwk = reserve ? 8 - 2 * ne : 8 - ne;                      // working waves
+      const int idx = (reserve && w >= 4) ? w - 2 * ne : w - ne;          // 0 .. nwk-1
+      if (idx == 0) {
+        invert_diag(kb);
+      } else {
+        int cnt = 0;
+        for (int jb = kb + 2; jb < 8; ++jb)
+          for (int ib = jb; ib < 8; ++ib)
+            if ((cnt++ % (nwk - 1)) + 1 == idx) update_pair(ib, jb, kb);
+        // column block kb is final: it goes out under the next step, a slice per updating wave
+        store_strip(kb, (idx - 1) * 32 / (nwk - 1), idx * 32 / (nwk - 1));
+      }
     }
   }
   __syncthreads();
