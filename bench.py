@@ -398,7 +398,7 @@ def main():
             "config": {"workload": (f"{spec['name']}: {spec['kernel']} kernel, {d}-D X, N={n}, "
                                     f"{'fp64' if dt == np.float64 else 'fp32'}, dense Cholesky + tri-solve"),
                        "n": n, "d": d, "diag": spec["diag"],
-                       "parallelism": "replicas" if world > 1 else "single",
+                       "parallelism": f"replicas x{world} (one evaluation stream per GPU, no data-path collective)" if world > 1 else "single",
                        "nb_outer": int(nb_used)},
             "roofline": roofline,
         }
