@@ -119,6 +119,75 @@ def test_gp_vs_textbook_formulas():
             o.assert_allclose(gp.predict(y, x), k(x, x) @ np.linalg.solve(K, y))
 
 
+def test_oracle_against_60_digit_arithmetic():
+    """Known answers in (near-)exact arithmetic: the formulas of kernels/stationary.py:76-153
+    and gp.py:313-361, written out once more with mpmath at 60 digits on the reference's
+    test_solver.py:16-57 data.  Pins the oracle's double-precision results (kernel entries,
+    log-likelihood, conditional mean and variance) to the rounding error of the inputs."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 60
+    x, y, t = _cases.data_solver()
+    diag = 0.1
+    X, Y, Tt = [mp.mpf(float(v)) for v in x], [mp.mpf(float(v)) for v in y], [mp.mpf(float(v)) for v in t]
+    s3, s5, two_pi = mp.sqrt(3), mp.sqrt(5), 2 * mp.pi
+
+    def m32(r):
+        return (1 + s3 * r) * mp.e ** (-s3 * r)
+
+    def m52(r):
+        return (1 + s5 * r + 5 * r * r / 3) * mp.e ** (-s5 * r)
+
+    # 1-D inputs: every metric is |dx|.  Hyper-parameters enter as the doubles the oracle sees.
+    scal = {v: mp.mpf(float(v)) for v in ("1.8", "1.5", "0.9", "0.7")}
+    for name in ("solver_m32", "solver_m52", "solver_exp", "solver_cos", "solver_sum", "expsq"):
+        k = _cases.kernel_zoo(o)[name]
+
+        def fd(d, name=name):
+            a, l, a2, l2 = (scal[v] for v in ("1.8", "1.5", "0.9", "0.7"))
+            if name == "solver_m32":
+                return a * a * m32(d / l)
+            if name == "solver_m52":
+                return a * a * m52(d / l)
+            if name == "solver_exp":
+                return a * a * mp.e ** (-d / l)
+            if name == "solver_cos":
+                return a * a * mp.cos(two_pi * d / l)
+            if name == "solver_sum":
+                return a * a * m32(d / l) + a2 * a2 * m52(d / l2)
+            return mp.e ** (-(d / l) ** 2 / 2)
+
+        n, m = len(X), len(Tt)
+        K = mp.matrix(n, n)
+        for i in range(n):
+            for j in range(n):
+                K[i, j] = fd(abs(X[i] - X[j])) + (mp.mpf(diag) if i == j else 0)
+        Ks = mp.matrix(n, m)
+        for i in range(n):
+            for j in range(m):
+                Ks[i, j] = fd(abs(X[i] - Tt[j]))
+        # kernel entries
+        got = k(x, t)
+        want = np.array([[float(Ks[i, j]) for j in range(m)] for i in range(n)])
+        # (cos(2 pi r) at r ~ 4 amplifies the rounding of its argument: absolute 1e-14)
+        np.testing.assert_allclose(got, want, rtol=2e-15, atol=5e-14)
+        L = mp.cholesky(K)
+        yv = mp.matrix(Y)
+        alpha = mp.lu_solve(K, yv)
+        logdet = 2 * sum(mp.log(L[i, i]) for i in range(n))
+        ll = -(yv.T * alpha)[0, 0] / 2 - logdet / 2 - mp.mpf(n) / 2 * mp.log(two_pi)
+        gp = o.GaussianProcess(k, x, diag=diag)
+        np.testing.assert_allclose(float(gp.log_probability(y)), float(ll), rtol=1e-11)
+        mu = Ks.T * alpha
+        loc, var = gp.predict(y, t, return_var=True)
+        np.testing.assert_allclose(loc, [float(mu[j]) for j in range(m)], rtol=1e-9, atol=1e-11)
+        jitter = mp.sqrt(mp.mpf(float(np.finfo(np.float64).eps)))
+        want_var = []
+        for j in range(m):
+            v = mp.lu_solve(K, Ks[:, j])
+            want_var.append(float(fd(mp.mpf(0)) - sum(Ks[i, j] * v[i] for i in range(n)) + jitter))
+        np.testing.assert_allclose(var, want_var, rtol=1e-8, atol=1e-10)
+
+
 def test_means_equivalent():
     # test_gp.py:41-51 (y is a scalar there: it broadcasts against loc)
     rng = np.random.default_rng(1058390)
