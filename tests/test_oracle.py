@@ -188,6 +188,48 @@ def test_oracle_against_60_digit_arithmetic():
         np.testing.assert_allclose(var, want_var, rtol=1e-8, atol=1e-10)
 
 
+def test_oracle_metrics_against_60_digit_arithmetic():
+    """The same in 3-D, where the metric matters (kernels/distance.py:30-59): the default L1
+    distance of Matern-3/2, the L2 default of ExpSquared, RationalQuadratic's squared L1
+    distance (stationary.py:232-235 with the base-class squared_distance) and an explicit L2."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 60
+    x, y, t, diag = _cases.data_george(3)
+    X = [[mp.mpf(float(v)) for v in row] for row in x]
+    T3 = [[mp.mpf(float(v)) for v in row] for row in t]
+    ell, s3 = mp.mpf(1.5), mp.sqrt(3)
+
+    def l1(a, b):
+        return sum(abs(p - q) for p, q in zip(a, b))
+
+    def l2sq(a, b):
+        return sum((p - q) ** 2 for p, q in zip(a, b))
+
+    funcs = {
+        "matern32": lambda a, b: (1 + s3 * l1(a, b) / ell) * mp.e ** (-s3 * l1(a, b) / ell),
+        "expsq": lambda a, b: mp.e ** (-l2sq(a, b) / ell**2 / 2),
+        "ratquad": lambda a, b: (1 + l1(a, b) ** 2 / (2 * mp.mpf(1.5))) ** (-mp.mpf(1.5)),
+        "l2_m32": lambda a, b: ((1 + s3 * mp.sqrt(l2sq(a, b)) / ell)
+                                * mp.e ** (-s3 * mp.sqrt(l2sq(a, b)) / ell)),
+    }
+    n, m = len(X), len(T3)
+    for name, f in funcs.items():
+        k = _cases.kernel_zoo(o)[name]
+        want = np.array([[float(f(X[i], T3[j])) for j in range(m)] for i in range(n)])
+        np.testing.assert_allclose(k(x, t), want, rtol=4e-15, atol=1e-17)
+        K = mp.matrix(n, n)
+        for i in range(n):
+            for j in range(n):
+                K[i, j] = f(X[i], X[j]) + (mp.mpf(float(diag[i])) if i == j else 0)
+        L = mp.cholesky(K)
+        yv = mp.matrix([mp.mpf(float(v)) for v in y])
+        alpha = mp.lu_solve(K, yv)
+        ll = (-(yv.T * alpha)[0, 0] / 2 - sum(mp.log(L[i, i]) for i in range(n))
+              - mp.mpf(n) / 2 * mp.log(2 * mp.pi))
+        got = float(o.GaussianProcess(k, x, diag=diag).log_probability(y))
+        np.testing.assert_allclose(got, float(ll), rtol=1e-11)
+
+
 def test_means_equivalent():
     # test_gp.py:41-51 (y is a scalar there: it broadcasts against loc)
     rng = np.random.default_rng(1058390)
