@@ -242,6 +242,26 @@ int tgp_solver_device_factor(tgp_solver* s, void** L_dev, int64_t* n_pad);
  * ms[6]=algorithmic flops of those launches */
 int tgp_solver_timings(tgp_solver* s, double* ms, int n);
 
+/* ---- schedule dry run (test infrastructure of the host logic; needs no GPU) -------------
+ * The kernel launches and event operations tgp_solver_factor (fused = 0) or
+ * tgp_solver_factor_logprob (fused = 1) would enqueue on the library's five streams for an
+ * n_pad x n_pad problem (n_pad a multiple of 128), in host order, without any HIP call.
+ * Ten int64 per record: kind, stream, v[0..7].
+ *   kind 1 potf2     v = {tile offset, pending-update operand offset or -1, ld}
+ *        2 trsm      v = {L tile offset, B offset, rows, ld}
+ *        3 gemm      v = {A, B, C offsets, m, n, k, lower | role << 8, ld}   (C -= A B^T)
+ *        4 forward-substitution step   v = {L tile offset, rows below, ld}
+ *        5 event record  v = {event}          6 stream wait  v = {event}
+ *        7 assembly      v = {first column tile, column tiles, ld, flags}
+ *        8 residual copy into the work vector     9 final reductions
+ *   stream 0 main, 1 panel, 2 solve, 3 update, 4 assembly; offsets are element offsets from
+ *   the matrix base (column-major, leading dimension ld).
+ * tests/test_schedule.py replays the records and checks that every pair of conflicting
+ * accesses is ordered by stream order or an event. */
+int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t first_split,
+                     int64_t first_small_tiles, int32_t fused, int64_t* out, int64_t cap_records,
+                     int64_t* n_records);
+
 #ifdef __cplusplus
 }
 #endif

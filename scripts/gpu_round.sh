@@ -1,10 +1,11 @@
 #!/bin/bash
-# the driver's multi-GPU launch line, at one process (all that a 1-GPU box can run)
+# full GPU suite + default bench after the dry-run instrumentation of the schedule
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 {
-timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-300
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -3
+timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-260
 } > $R/gpurun_out/round.log 2>&1
 cat $R/gpurun_out/round.log

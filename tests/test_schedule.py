@@ -1,0 +1,178 @@
+"""Host logic of the factorisation schedule, checked without a GPU.
+
+``tgp_trace_factor`` replays what ``tgp_solver_factor`` / ``tgp_solver_factor_logprob`` would
+enqueue on the library's five streams (same code path, launches replaced by records).  The
+checker below models every record's reads and writes at 128 x 128 tile granularity and
+verifies with vector clocks that each pair of conflicting accesses (write-write, write-read,
+read-write) is ordered by stream order or by an event record / wait pair -- i.e. that the
+multi-stream schedule has no data race by construction.  (The GPU suite's determinism test is
+the empirical counterpart.)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tinygp_amd import _ffi
+
+NSTREAMS = 5
+KIND = {1: "potf2", 2: "trsm", 3: "gemm", 4: "trsv_step", 5: "record", 6: "wait", 7: "assembly",
+        8: "residual_copy", 9: "reductions"}
+
+
+def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1):
+    lib = _ffi.load_library()
+    cap = 40 * (n_pad // 128) + 256
+    out = np.zeros(cap * 10, dtype=np.int64)
+    n = C.c_int64()
+    st = lib.tgp_trace_factor(n_pad, nb, lookahead, first_split, first_small, fused,
+                              out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n))
+    assert st == 0, lib.tgp_last_error()
+    return out[: n.value * 10].reshape(-1, 10).tolist()
+
+
+def accesses(rec, T):
+    """(reads, writes): sets of resources.  ('A', tr, tc) matrix tile, ('D', j) 16x16 inverses
+    of block j, ('Y', j) 128 entries of the solved vector."""
+    kind, _, *v = rec
+    R, W = set(), set()
+
+    def tile(off, ld):
+        assert off >= 0 and off % 128 == 0 and (off % ld) % 128 == 0, (rec, off)
+        return (off % ld) // 128, (off // ld) // 128
+
+    if kind == 7:  # assembly of lower tiles of column tiles [tc0, tc0 + ntc)
+        tc0, ntc = v[0], v[1]
+        W |= {("A", tr, tc) for tc in range(tc0, tc0 + ntc) for tr in range(tc, T)}
+    elif kind == 8:
+        W |= {("Y", j) for j in range(T)}
+    elif kind == 9:
+        R |= {("A", j, j) for j in range(T)} | {("Y", j) for j in range(T)}
+    elif kind == 1:
+        tr, tc = tile(v[0], v[2])
+        assert tr == tc
+        W.add(("A", tr, tc)); R.add(("A", tr, tc)); W.add(("D", tr))
+        if v[1] >= 0:
+            R.add(("A",) + tile(v[1], v[2]))
+    elif kind == 2:
+        ld = v[3]
+        lr, lc = tile(v[0], ld)
+        assert lr == lc
+        R |= {("A", lr, lc), ("D", lr)}
+        br, bc = tile(v[1], ld)
+        for i in range(v[2] // 128):
+            R.add(("A", br + i, bc)); W.add(("A", br + i, bc))
+    elif kind == 3:
+        ld = v[7]
+        (ar, ac), (brr, bcc), (cr, cc) = tile(v[0], ld), tile(v[1], ld), tile(v[2], ld)
+        m, n, k = v[3] // 128, v[4] // 128, v[5] // 128
+        lower, role = v[6] & 0xFF, v[6] >> 8
+        for tj in range(n):
+            for ti in range(m):
+                if lower and ti < tj:
+                    continue
+                if role == 3 and ti == 0 and tj == 0:
+                    continue  # folded into the next potf2
+                R.add(("A", cr + ti, cc + tj)); W.add(("A", cr + ti, cc + tj))
+        R |= {("A", ar + ti, ac + kk) for ti in range(m) for kk in range(k)}
+        R |= {("A", brr + tj, bcc + kk) for tj in range(n) for kk in range(k)}
+    elif kind == 4:
+        ld = v[2]
+        lr, lc = tile(v[0], ld)
+        assert lr == lc
+        R |= {("A", lr, lc), ("D", lr)}
+        R.add(("Y", lr)); W.add(("Y", lr))
+        for i in range(1, v[1] // 128 + 1):
+            R.add(("A", lr + i, lc)); R.add(("Y", lr + i)); W.add(("Y", lr + i))
+    return R, W
+
+
+def find_races(recs, T, limit=5):
+    clock = [[0] * NSTREAMS for _ in range(NSTREAMS)]
+    snap = {}
+    last_w = {}   # resource -> (stream, counter, index)
+    readers = {}  # resource -> list of (stream, counter, index) since the last write
+    races = []
+
+    def ordered(prev, now_clock):
+        s, c, _ = prev
+        return now_clock[s] >= c
+
+    for idx, rec in enumerate(recs):
+        kind, s = rec[0], rec[1]
+        assert 0 <= s < NSTREAMS, rec
+        if kind == 5:
+            snap[rec[2]] = list(clock[s])
+            continue
+        if kind == 6:
+            if rec[2] in snap:
+                clock[s] = [max(a, b) for a, b in zip(clock[s], snap[rec[2]])]
+            continue
+        clock[s][s] += 1
+        now = list(clock[s])
+        me = (s, now[s], idx)
+        R, W = accesses(rec, T)
+        for r in R | W:
+            lw = last_w.get(r)
+            if lw is not None and not ordered(lw, now):
+                races.append((r, lw[2], idx, "after write"))
+        for r in W:
+            for rd in readers.get(r, ()):
+                if rd[2] != idx and not ordered(rd, now):
+                    races.append((r, rd[2], idx, "write after read"))
+        for r in W:
+            last_w[r] = me
+            readers[r] = []
+        for r in R - W:
+            readers.setdefault(r, []).append(me)
+        if len(races) >= limit:
+            break
+    return [(r, f"#{i} {KIND[recs[i][0]]} s{recs[i][1]}", f"#{j} {KIND[recs[j][0]]} s{recs[j][1]}", why)
+            for r, i, j, why in races[:limit]]
+
+
+CONFIGS = [
+    # n_pad, nb, lookahead, first_split, first_small, fused
+    (128, 1024, 1, 5, 1100, 1),
+    (1024, 1024, 1, 5, 1100, 1),
+    (1152, 1024, 1, 5, 1100, 1),
+    (2560, 1024, 1, 5, 1100, 1),
+    (2560, 1024, 1, 5, 1100, 0),
+    (3456, 1024, 1, 5, 1100, 1),
+    (5120, 1024, 1, 5, 1100, 1),
+    (5120, 1024, 0, 5, 1100, 1),
+    (5120, 1024, 1, 0, 1100, 1),
+    (5120, 1024, 1, 7, 0, 1),
+    (5120, 512, 1, 3, 1100, 1),
+    (4096, 2048, 1, 5, 1100, 1),
+    (16384, 1024, 1, 5, 1100, 1),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[f"n{c[0]}-nb{c[1]}-la{c[2]}-fs{c[3]}-st{c[4]}-f{c[5]}" for c in CONFIGS])
+def test_schedule_has_no_data_race(cfg):
+    n_pad = cfg[0]
+    recs = trace(*cfg)
+    T = n_pad // 128
+    # every block column is factored exactly once, in order
+    potf2 = [r for r in recs if r[0] == 1]
+    assert [(r[2] % r[4]) // 128 for r in potf2] == list(range(T))
+    if cfg[5]:
+        assert sum(1 for r in recs if r[0] == 4) == T  # one forward-substitution step per block
+    assert find_races(recs, T) == []
+
+
+def test_checker_sees_a_missing_dependency():
+    """The checker is not vacuous: dropping the waits that order the in-panel update before
+    the next trsm, or the join of the side-stream assembly, must be reported."""
+    recs = trace(2560)
+    T = 2560 // 128
+    no_update_wait = [r for r in recs if not (r[0] == 6 and r[1] == 1 and r[2] == 4)]  # panel waits ev_e
+    assert len(no_update_wait) < len(recs)
+    assert find_races(no_update_wait, T)
+    no_join = [r for r in recs if not (r[0] == 6 and r[1] == 0 and r[2] == 5)]  # main waits ev_asm
+    assert len(no_join) < len(recs)
+    assert find_races(no_join, T)
+    no_chain_wait = [r for r in recs if not (r[0] == 6 and r[1] == 0 and r[2] == 1)]  # main waits ev_b
+    assert len(no_chain_wait) < len(recs)
+    assert find_races(no_chain_wait, T)

@@ -96,6 +96,7 @@ SIGNATURES = {
     "tgp_solver_get_factor": [_vp, _vp],
     "tgp_solver_device_factor": [_vp, _pvp, _pi64],
     "tgp_solver_timings": [_vp, _pdbl, _int],
+    "tgp_trace_factor": [_i64, _i64, _i64, _i64, _i64, _i32, _pi64, _i64, _pi64],
 }
 
 

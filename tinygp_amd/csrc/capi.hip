@@ -80,6 +80,35 @@ struct tgp_solver {
     TGP_HIP_TRY(hipSetDevice((s)->ctx->device));                      \
   } while (0)
 
+// K(X, X) + noise into the lower tiles of A.  Only the first panel's columns gate the
+// factorisation: the rest of K is assembled on its own stream beside the first panel's
+// potf2/trsm chain (potrf waits for it before the first trailing update).
+template <typename T>
+static int assemble_lower(tgp_ctx* ctx, const tgp::KProg& kp, int64_t n, int d, const T* X,
+                          const T* diag, T* A, int64_t npad) {
+  using namespace tgp;
+  const int64_t tc = npad / 128;
+  int64_t t1 = tc;
+  if (ctx->lookahead != 0 && ctx->asm_stream != nullptr) {
+    int64_t nb = ctx->nb_outer / 128;
+    if (nb < 1) nb = 1;
+    if (nb < tc) t1 = nb;
+  }
+  const int flags = KMAT_LOWER | KMAT_PAD_IDENTITY;
+  if (t1 < tc) {
+    TGP_TRY(ev_record(ctx, ctx->ev_asm, ctx->stream));  // X / noise uploads are on the main stream
+    TGP_TRY(st_wait(ctx, ctx->asm_stream, ctx->ev_asm));
+  }
+  TGP_TRY(launch_kmat_cols<T>(ctx, ctx->stream, kp, n, n, d, X, X, diag, A, npad, npad, npad, flags, 0, t1));
+  if (t1 < tc) {
+    TGP_TRY(launch_kmat_cols<T>(ctx, ctx->asm_stream, kp, n, n, d, X, X, diag, A, npad, npad, npad,
+                                flags, t1, tc - t1));
+    TGP_TRY(ev_record(ctx, ctx->ev_asm, ctx->asm_stream));
+    ctx->asm_pending = true;
+  }
+  return TGP_OK;
+}
+
 extern "C" {
 
 int tgp_abi_version(void) { return TGP_ABI_VERSION; }
@@ -462,31 +491,7 @@ static int factor_impl(tgp_solver* s, const tgp_kop* prog, int nops, const void*
                                  hipMemcpyHostToDevice, ctx->stream));
       TGP_TRY(launch_set_lower_from_rowmajor<T>(ctx, s->n, s->npad, (const T*)s->scratch, A, s->npad));
     } else {
-      // Only the first panel's columns gate the factorisation: the rest of K is assembled
-      // on its own stream beside the first panel's potf2/trsm chain (potrf waits for it
-      // before the first trailing update).
-      const int64_t tc = s->npad / 128;
-      int64_t t1 = tc;
-      if (ctx->lookahead != 0 && ctx->asm_stream != nullptr) {
-        int64_t nb = ctx->nb_outer / 128;
-        if (nb < 1) nb = 1;
-        if (nb < tc) t1 = nb;
-      }
-      const int flags = KMAT_LOWER | KMAT_PAD_IDENTITY;
-      if (t1 < tc) {
-        TGP_HIP_TRY(hipEventRecord(ctx->ev_asm, ctx->stream));  // X / noise uploads are on S0
-        TGP_HIP_TRY(hipStreamWaitEvent(ctx->asm_stream, ctx->ev_asm, 0));
-      }
-      TGP_TRY(launch_kmat_cols<T>(ctx, ctx->stream, s->kp, s->n, s->n, s->d, (const T*)s->X,
-                                  (const T*)s->X, (const T*)s->diag, A, s->npad, s->npad, s->npad,
-                                  flags, 0, t1));
-      if (t1 < tc) {
-        TGP_TRY(launch_kmat_cols<T>(ctx, ctx->asm_stream, s->kp, s->n, s->n, s->d, (const T*)s->X,
-                                    (const T*)s->X, (const T*)s->diag, A, s->npad, s->npad,
-                                    s->npad, flags, t1, tc - t1));
-        TGP_HIP_TRY(hipEventRecord(ctx->ev_asm, ctx->asm_stream));
-        ctx->asm_pending = true;
-      }
+      TGP_TRY(assemble_lower<T>(ctx, s->kp, s->n, s->d, (const T*)s->X, (const T*)s->diag, A, s->npad));
     }
     if (prof) TGP_HIP_TRY(hipEventRecord(e1, ctx->stream));
     if (fused) {
@@ -903,6 +908,58 @@ int tgp_solver_timings(tgp_solver* s, double* ms, int n) {
   SOLVER_GUARD(s);
   TGP_ARG_CHECK(ms != nullptr && n >= 0, "bad argument");
   for (int i = 0; i < n && i < 8; ++i) ms[i] = s->ms[i];
+  return TGP_OK;
+}
+
+// Dry run of tgp_solver_factor / tgp_solver_factor_logprob: the sequence of kernel launches and
+// event operations the five streams would receive for an n_pad x n_pad problem, without a GPU
+// (no HIP call is made).  Ten int64 per record: kind, stream, v[0..7] (tgp_trace_rec).
+int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t first_split,
+                     int64_t first_small_tiles, int32_t fused, int64_t* out, int64_t cap_records,
+                     int64_t* n_records) {
+  using namespace tgp;
+  TGP_ARG_CHECK(n_pad > 0 && n_pad % 128 == 0 && out != nullptr && n_records != nullptr,
+                "trace: n_pad must be a positive multiple of 128");
+  tgp_ctx ctx;
+  auto fake = [](uintptr_t v) { return reinterpret_cast<void*>(v); };
+  ctx.stream = (hipStream_t)fake(0x10);
+  ctx.panel_stream = (hipStream_t)fake(0x20);
+  ctx.solve_stream = (hipStream_t)fake(0x30);
+  ctx.update_stream = (hipStream_t)fake(0x40);
+  ctx.asm_stream = (hipStream_t)fake(0x50);
+  ctx.ev_a = (hipEvent_t)fake(0x100);
+  ctx.ev_b = (hipEvent_t)fake(0x110);
+  ctx.ev_c = (hipEvent_t)fake(0x120);
+  ctx.ev_d = (hipEvent_t)fake(0x130);
+  ctx.ev_e = (hipEvent_t)fake(0x140);
+  ctx.ev_asm = (hipEvent_t)fake(0x150);
+  ctx.nb_outer = nb_outer;
+  ctx.lookahead = lookahead;
+  ctx.first_split = first_split;
+  ctx.first_small_tiles = first_small_tiles;
+  std::vector<tgp_trace_rec> recs;
+  ctx.trace = &recs;
+  // never dereferenced: only differences of these pointers are recorded
+  double* base = static_cast<double*>(fake(uintptr_t(1) << 40));
+  double* dinv = static_cast<double*>(fake(uintptr_t(2) << 40));
+  double* y = static_cast<double*>(fake(uintptr_t(3) << 40));
+  double* X = static_cast<double*>(fake(uintptr_t(4) << 40));
+  ctx.trace_base = base;
+  KProg kp{};
+  TGP_TRY(assemble_lower<double>(&ctx, kp, n_pad, 1, X, X, base, n_pad));
+  if (fused) trace_push(&ctx, 8, ctx.stream);  // residual -> work vector (main stream)
+  int32_t info = 0;
+  const int st = potrf<double>(&ctx, n_pad, base, n_pad, dinv, &info, fused ? y : nullptr);
+  if (st < 0) return st;
+  trace_push(&ctx, 9, ctx.stream);  // reductions over diag(L) and the solved vector (main stream)
+  *n_records = (int64_t)recs.size();
+  TGP_ARG_CHECK((int64_t)recs.size() <= cap_records, "trace: %lld records, room for %lld",
+                (long long)recs.size(), (long long)cap_records);
+  for (size_t i = 0; i < recs.size(); ++i) {
+    out[10 * i] = recs[i].kind;
+    out[10 * i + 1] = recs[i].stream;
+    for (int q = 0; q < 8; ++q) out[10 * i + 2 + q] = recs[i].v[q];
+  }
   return TGP_OK;
 }
 

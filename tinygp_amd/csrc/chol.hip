@@ -617,7 +617,10 @@ __global__ __launch_bounds__(256) void trsv_update_bwd_kernel(int64_t ncols,
 template <typename T>
 int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_t* info,
                  int32_t pivot_base, const T* Xp, int64_t ldx) {
-  (void)ctx;
+  if (ctx->trace) {  // v: tile offset, pending-update operand offset (-1: none), ld
+    trace_push(ctx, 1, st, trace_off(ctx, A), trace_off(ctx, Xp), ld);
+    return TGP_OK;
+  }
   if (Xp != nullptr)
     hipLaunchKernelGGL((potf2_kernel<T, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
                        pivot_base, Xp, ldx);
@@ -631,9 +634,12 @@ int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_
 template <typename T>
 int launch_trsm(tgp_ctx* ctx, hipStream_t st, int64_t m, const T* L, int64_t ldl, const T* dinv,
                 T* B, int64_t ldb) {
-  (void)ctx;
   if (m == 0) return TGP_OK;
   TGP_ARG_CHECK(m % 16 == 0, "trsm: m must be a multiple of 16");
+  if (ctx->trace) {  // v: L tile offset, B offset, rows, ld
+    trace_push(ctx, 2, st, trace_off(ctx, L), trace_off(ctx, B), m, ldl);
+    return TGP_OK;
+  }
   hipLaunchKernelGGL((trsm_kernel<T>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, st, m, L,
                      ldl, dinv, B, ldb);
   TGP_HIP_TRY(hipGetLastError());
@@ -651,8 +657,12 @@ int compute_dinv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* dinv) {
 
 // one forward-substitution step: y[0:128] <- L_jj^-1 y[0:128]; y[128:128+m] -= L[below] y[0:128]
 template <typename T>
-int launch_trsv_fwd_step(hipStream_t st, int64_t m_below, const T* Ljj, int64_t ld, const T* dj,
-                         T* yj) {
+int launch_trsv_fwd_step(tgp_ctx* ctx, hipStream_t st, int64_t m_below, const T* Ljj, int64_t ld,
+                         const T* dj, T* yj) {
+  if (ctx->trace) {  // v: L tile offset, rows below, ld
+    trace_push(ctx, 4, st, trace_off(ctx, Ljj), m_below, ld);
+    return TGP_OK;
+  }
   hipLaunchKernelGGL((trsv_diag_fwd_kernel<T>), dim3(1), dim3(128), 0, st, Ljj, ld, dj, yj);
   if (m_below > 0)
     hipLaunchKernelGGL((trsv_update_fwd_kernel<T>), dim3((unsigned)((m_below + 255) / 256)),
@@ -689,14 +699,14 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   if (n == 0) return TGP_OK;
   hipStream_t S0 = ctx->stream, S1 = ctx->panel_stream, S2 = ctx->solve_stream;
   if (y != nullptr) {  // S2 must see y (uploaded on S0)
-    TGP_HIP_TRY(hipEventRecord(ctx->ev_c, S0));
-    TGP_HIP_TRY(hipStreamWaitEvent(S2, ctx->ev_c, 0));
+    TGP_TRY(ev_record(ctx, ctx->ev_c, S0));
+    TGP_TRY(st_wait(ctx, S2, ctx->ev_c));
   }
   int64_t NB = ctx->nb_outer;
   if (NB < TILE) NB = TILE;
   NB = NB / TILE * TILE;
-  TGP_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int32_t), S0));
-  const bool prof_on = ctx->profile != 0;
+  if (!ctx->trace) TGP_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int32_t), S0));
+  const bool prof_on = ctx->profile != 0 && !ctx->trace;
   std::vector<ProfSpan> spans;
   ctx->ev_used = 0;
 
@@ -719,23 +729,23 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       T* dj = dinv + (j0 / TILE) * 2048;
       const bool pend = j0 > k0;  // in-panel update from block column j0-128 still in flight
       if (pend || !head_done) TGP_TRY(potf2_at(st, j0, pend));
-      if (pend) TGP_HIP_TRY(hipStreamWaitEvent(st, ctx->ev_e, 0));  // rest of that update
+      if (pend) TGP_TRY(st_wait(ctx, st, ctx->ev_e));  // rest of that update
       const int64_t mb = n - (j0 + TILE);
       if (mb > 0) TGP_TRY(launch_trsm<T>(ctx, st, mb, Ljj, ld, dj, Ljj + TILE, ld));
       const int64_t nc = (k0 + kb) - (j0 + TILE);
       const bool upd = mb > 0 && nc > 0;
       // one marker behind the trsm serves both side streams (every marker between two
       // kernels of the chain costs it a few microseconds)
-      if (y != nullptr || upd) TGP_HIP_TRY(hipEventRecord(ctx->ev_d, st));
+      if (y != nullptr || upd) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
       if (upd) {
-        TGP_HIP_TRY(hipStreamWaitEvent(S3, ctx->ev_d, 0));
+        TGP_TRY(st_wait(ctx, S3, ctx->ev_d));
         TGP_TRY(launch_gemm_nt<T>(ctx, S3, mb, nc, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
                                   A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, 3));
-        TGP_HIP_TRY(hipEventRecord(ctx->ev_e, S3));
+        TGP_TRY(ev_record(ctx, ctx->ev_e, S3));
       }
       if (y != nullptr) {
-        TGP_HIP_TRY(hipStreamWaitEvent(S2, ctx->ev_d, 0));
-        TGP_TRY(launch_trsv_fwd_step<T>(S2, mb, Ljj, ld, dj, y + j0));
+        TGP_TRY(st_wait(ctx, S2, ctx->ev_d));
+        TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, mb, Ljj, ld, dj, y + j0));
       }
       if (after_blocks > 0 && upd && j0 + TILE == k0 + after_blocks * TILE) TGP_TRY(mid());
     }
@@ -764,7 +774,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   // columns right of the first panel may still be in assembly (capi.hip, factor_impl)
   auto join_assembly = [&]() -> int {
     if (ctx->asm_pending) {
-      TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_asm, 0));
+      TGP_TRY(st_wait(ctx, S0, ctx->ev_asm));
       ctx->asm_pending = false;
     }
     return TGP_OK;
@@ -793,16 +803,16 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
                                 ? ctx->first_split : 0;
       const std::function<int()> early = [&]() -> int {
         TGP_TRY(join_assembly());
-        TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_d, 0));
+        TGP_TRY(st_wait(ctx, S0, ctx->ev_d));
         TGP_TRY(trailing(mt0, kbn0, split * TILE, A + kb0, A + kb0 * ld + kb0, first_role(mt0, kbn0)));
         k_done = split * TILE;
         return TGP_OK;
       };
-      TGP_HIP_TRY(hipEventRecord(ctx->ev_a, S0));
-      TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
+      TGP_TRY(ev_record(ctx, ctx->ev_a, S0));
+      TGP_TRY(st_wait(ctx, S1, ctx->ev_a));
       TGP_TRY(panel(S1, 0, kb0, false, split, early));
-      TGP_HIP_TRY(hipEventRecord(ctx->ev_b, S1));
-      TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_b, 0));
+      TGP_TRY(ev_record(ctx, ctx->ev_b, S1));
+      TGP_TRY(st_wait(ctx, S0, ctx->ev_b));
       TGP_TRY(join_assembly());
     }
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
@@ -819,7 +829,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       // the panel's first potf2 goes in front of the big update on the main stream: issued
       // beside it, it waits a whole round of tiles (~0.3 ms) for a free CU
       TGP_TRY(potf2_at(S0, next, false));
-      TGP_HIP_TRY(hipEventRecord(ctx->ev_a, S0));
+      TGP_TRY(ev_record(ctx, ctx->ev_a, S0));
       // 2. ... the main stream updates the rest (enqueued first: the ~90 API calls of a
       // panel take the host longer than a small update takes the GPU) ...
       const int64_t m2 = mt - kbn;
@@ -830,30 +840,32 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       // blocks are final, their share of the block-column update that will gate the panel
       // AFTER it is issued behind the running update, so that only the last blocks' share
       // (a quarter of the k-range) is left on the critical path between two chains.
-      TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
+      TGP_TRY(st_wait(ctx, S1, ctx->ev_a));
       const int64_t next2 = next + kbn, mt2 = n - next2;
       const int64_t kbn2 = (mt2 < NB) ? mt2 : NB;
       const int64_t split = (mt2 > 0 && ctx->first_split > 0 && ctx->first_split < kbn / TILE)
                                 ? ctx->first_split : 0;
       const std::function<int()> early = [&]() -> int {
-        TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_d, 0));
+        TGP_TRY(st_wait(ctx, S0, ctx->ev_d));
         TGP_TRY(trailing(mt2, kbn2, split * TILE, A + next * ld + next2, A + next2 * ld + next2,
                          first_role(mt2, kbn2)));
         k_done = split * TILE;
         return TGP_OK;
       };
       TGP_TRY(panel(S1, next, kbn, true, split, early));
-      TGP_HIP_TRY(hipEventRecord(ctx->ev_b, S1));
-      TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_b, 0));
+      TGP_TRY(ev_record(ctx, ctx->ev_b, S1));
+      TGP_TRY(st_wait(ctx, S0, ctx->ev_b));
     }
   }
   if (y != nullptr) {
-    TGP_HIP_TRY(hipEventRecord(ctx->ev_c, S2));
-    TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_c, 0));
+    TGP_TRY(ev_record(ctx, ctx->ev_c, S2));
+    TGP_TRY(st_wait(ctx, S0, ctx->ev_c));
   }
   int32_t info = 0;
-  TGP_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, S0));
-  TGP_HIP_TRY(hipStreamSynchronize(S0));
+  if (!ctx->trace) {
+    TGP_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, S0));
+    TGP_HIP_TRY(hipStreamSynchronize(S0));
+  }
   if (prof_on) {
     ctx->prof_syrk_ms = 0;
     ctx->prof_syrk_flops = 0;
@@ -877,7 +889,7 @@ int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int tra
   if (!transpose) {
     for (int64_t kb = 0; kb < nb; ++kb) {
       const int64_t j0 = kb * TILE;
-      TGP_TRY(launch_trsv_fwd_step<T>(st, n - (j0 + TILE), L + j0 * ld + j0, ld, dinv + kb * 2048,
+      TGP_TRY(launch_trsv_fwd_step<T>(ctx, st, n - (j0 + TILE), L + j0 * ld + j0, ld, dinv + kb * 2048,
                                       y + j0));
     }
   } else {

@@ -505,11 +505,15 @@ template <typename T>
 int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k, const T* A,
                    int64_t lda, const T* B, int64_t ldb, T* C, int64_t ldc, int lower, int mode,
                    int role) {
-  (void)ctx;
   TGP_ARG_CHECK(m % BM == 0 && n % BN == 0 && k % BK == 0 && k > 0,
                 "gemm_nt: m,n must be multiples of %d and k of %d (got %lld,%lld,%lld)", BM, BK,
                 (long long)m, (long long)n, (long long)k);
   if (m == 0 || n == 0) return TGP_OK;
+  if (ctx->trace) {  // v: A, B, C offsets, m, n, k, lower | role << 8, ld (all operands share it)
+    trace_push(ctx, 3, st, trace_off(ctx, A), trace_off(ctx, B), trace_off(ctx, C), m, n, k,
+               int64_t(lower) | (int64_t(role) << 8), ldc);
+    return TGP_OK;
+  }
   GemmArgs<T> g;
   g.skip00 = 0;
   TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");

@@ -374,12 +374,15 @@ template <typename T>
 int launch_kmat_cols(tgp_ctx* ctx, hipStream_t st, const KProg& kp, int64_t n1, int64_t n2, int d,
                      const T* X1, const T* X2, const T* diag, T* out, int64_t ld, int64_t rows_out,
                      int64_t cols_out, int flags, int64_t tc0, int64_t ntc) {
-  (void)ctx;
   TGP_ARG_CHECK(d >= 1 && d <= TGP_MAX_DIM, "input dimension must be 1..%d (got %d)", TGP_MAX_DIM, d);
   TGP_ARG_CHECK(rows_out >= n1 && cols_out >= n2 && ld >= rows_out, "kmat: bad output extents");
   if (rows_out == 0 || cols_out == 0 || ntc <= 0) return TGP_OK;
   const int64_t tr = (rows_out + KT - 1) / KT, tc = (cols_out + KT - 1) / KT;
   TGP_ARG_CHECK(tc0 >= 0 && tc0 + ntc <= tc, "kmat: column tile range outside the matrix");
+  if (ctx->trace) {  // v: first column tile, number of column tiles, ld, flags
+    trace_push(ctx, 7, st, tc0, ntc, ld, flags);
+    return TGP_OK;
+  }
   TGP_ARG_CHECK(ntc <= 65535, "kmat: too many column tiles");
   dim3 grid((unsigned)tr, (unsigned)ntc);
   const size_t shmem = 2 * size_t(KT) * d * sizeof(T);

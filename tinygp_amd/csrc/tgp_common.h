@@ -56,6 +56,15 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 }  // namespace tgp
 
+// Dry-run record of one enqueued operation (tgp_trace_factor): the factorisation's schedule
+// without a GPU, for the host-side dependency checker in tests/test_schedule.py.
+struct tgp_trace_rec {
+  int64_t kind;    // 1 potf2, 2 trsm, 3 gemm, 4 forward-substitution step, 5 event record,
+                   // 6 stream wait, 7 assembly of column tiles
+  int64_t stream;  // 0 main, 1 panel, 2 solve, 3 update, 4 assembly
+  int64_t v[8];    // operands as element offsets from the matrix base (see capi.hip)
+};
+
 // One HIP device + stream (+ a high-priority side stream for panel look-ahead).
 struct tgp_ctx {
   int device = 0;
@@ -86,9 +95,57 @@ struct tgp_ctx {
   double prof_syrk_ms = 0, prof_syrk_flops = 0, prof_panel_ms = 0;
   int64_t prof_syrk_launches = 0;
   int cus = 0;
+  // dry run: launches and event operations are recorded here instead of being issued
+  std::vector<tgp_trace_rec>* trace = nullptr;
+  const void* trace_base = nullptr;  // matrix base pointer of the traced factorisation
 };
 
 namespace tgp {
+
+// ---- dry-run helpers ----------------------------------------------------------------
+inline int64_t trace_stream_id(const tgp_ctx* ctx, hipStream_t st) {
+  if (st == ctx->stream) return 0;
+  if (st == ctx->panel_stream) return 1;
+  if (st == ctx->solve_stream) return 2;
+  if (st == ctx->update_stream) return 3;
+  if (st == ctx->asm_stream) return 4;
+  return -1;
+}
+inline int64_t trace_event_id(const tgp_ctx* ctx, hipEvent_t ev) {
+  if (ev == ctx->ev_a) return 0;
+  if (ev == ctx->ev_b) return 1;
+  if (ev == ctx->ev_c) return 2;
+  if (ev == ctx->ev_d) return 3;
+  if (ev == ctx->ev_e) return 4;
+  if (ev == ctx->ev_asm) return 5;
+  return -1;
+}
+template <typename T>
+inline int64_t trace_off(const tgp_ctx* ctx, const T* p) {
+  return p == nullptr ? -1 : int64_t(p - static_cast<const T*>(ctx->trace_base));
+}
+inline void trace_push(tgp_ctx* ctx, int64_t kind, hipStream_t st, int64_t a = 0, int64_t b = 0,
+                       int64_t c = 0, int64_t d = 0, int64_t e = 0, int64_t f = 0, int64_t g = 0,
+                       int64_t h = 0) {
+  ctx->trace->push_back(tgp_trace_rec{kind, trace_stream_id(ctx, st), {a, b, c, d, e, f, g, h}});
+}
+// event record / stream wait that honour the dry run
+inline int ev_record(tgp_ctx* ctx, hipEvent_t ev, hipStream_t st) {
+  if (ctx->trace) {
+    trace_push(ctx, 5, st, trace_event_id(ctx, ev));
+    return TGP_OK;
+  }
+  TGP_HIP_TRY(hipEventRecord(ev, st));
+  return TGP_OK;
+}
+inline int st_wait(tgp_ctx* ctx, hipStream_t st, hipEvent_t ev) {
+  if (ctx->trace) {
+    trace_push(ctx, 6, st, trace_event_id(ctx, ev));
+    return TGP_OK;
+  }
+  TGP_HIP_TRY(hipStreamWaitEvent(st, ev, 0));
+  return TGP_OK;
+}
 
 int ensure_dinv(tgp_ctx* ctx, size_t bytes);
 int ensure_work(tgp_ctx* ctx, size_t bytes);
@@ -128,6 +185,9 @@ template <typename T>
 int launch_trsm(tgp_ctx* ctx, hipStream_t st, int64_t m, const T* L, int64_t ldl, const T* dinv,
                 T* B, int64_t ldb);
 
+template <typename T>
+int launch_trsv_fwd_step(tgp_ctx* ctx, hipStream_t st, int64_t m_below, const T* Ljj, int64_t ld,
+                         const T* dj, T* yj);
 template <typename T>
 int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host, T* y = nullptr);
 template <typename T>
