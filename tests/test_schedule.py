@@ -176,3 +176,27 @@ def test_checker_sees_a_missing_dependency():
     no_chain_wait = [r for r in recs if not (r[0] == 6 and r[1] == 0 and r[2] == 1)]  # main waits ev_b
     assert len(no_chain_wait) < len(recs)
     assert find_races(no_chain_wait, T)
+
+
+@pytest.mark.parametrize("n_pad,nb,split,small", [(16384, 1024, 5, 1100), (32768, 1024, 5, 1100),
+                                                    (16384, 1024, 0, 0), (8192, 512, 3, 200)])
+def test_bench_accounting_matches_the_launches(n_pad, nb, split, small):
+    """bench.py's algorithmic-bytes model (roofline.algorithmic_bytes_per_launch) is derived from
+    launch shapes; they must be the shapes the library really launches for the profiled kernel
+    (128 x 128-tile GEMM, role 0, on the main stream)."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("bench", Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    recs = trace(n_pad, nb, 1, split, small, 1)
+    total, launches = 0, 0
+    for r in recs:
+        if r[0] == 3 and (r[8] >> 8) == 0:
+            assert r[1] == 0 and (r[8] & 0xFF) == 1
+            m, n, k = r[5], r[6], r[7]
+            entries = n * m - n * (n - 1) // 2
+            total += 8 * (2 * entries + m * k)
+            launches += 1
+    assert (total, launches) == bench.trailing_update_bytes(n_pad, nb, 8, small, split)
