@@ -242,6 +242,56 @@ int tgp_solver_device_factor(tgp_solver* s, void** L_dev, int64_t* n_pad);
  * ms[6]=algorithmic flops of those launches */
 int tgp_solver_timings(tgp_solver* s, double* ms, int n);
 
+/* ---- block-cyclic column Cholesky over the GPUs of one node (BASELINE configs 4 / 5) ----------
+ * The reference has NO multi-device code; these entry points are one RANK's share
+ * of the same path -- `DirectSolver.__init__` (solvers/direct.py:49-53: assembly + cholesky),
+ * `GaussianProcess.log_probability` (gp.py:126-138, 313-320) and the posterior mean of
+ * `GaussianProcess._condition` (gp.py:330-334, 353-359) -- for a matrix cut into block columns
+ * of width nb owned cyclically (block column j on rank j mod world).  One process per GPU; the
+ * collectives (RCCL panel broadcast, slice broadcast of the backward solve, one all-reduce of
+ * the (M,) mean) are issued by the host between these calls (tinygp_amd/distributed.py), which
+ * is also where the order of calls per step is documented.  Every call is asynchronous on the
+ * context's streams except tgp_dist_end / tgp_dist_cond_mean_partial / tgp_dist_get_column.
+ *
+ * ring0/ring1 (tgp_dist_slot_elems(n, nb) elements each) and x (n_pad = ceil(n/nb)*nb elements)
+ * are device buffers of the CALLER (torch tensors, so that torch.distributed can send them):
+ *   ring slot of panel k = ring[k & 1] = [(nb/128)*2048 inverse 16x16 diagonal blocks |
+ *                                         (n_pad - k nb) x nb panel, column-major, ld = rows]
+ *   x: the replicated right-hand side: residual -> L^-1 r (after tgp_dist_end) -> K^-1 r. */
+typedef struct tgp_dist tgp_dist;
+int64_t tgp_dist_slot_elems(int64_t n, int64_t nb);
+int tgp_dist_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X_host,
+                    const void* noise_diag_host, int64_t nb, int32_t world, int32_t rank,
+                    void* ring0_dev, void* ring1_dev, void* x_dev, tgp_dist** out);
+int tgp_dist_destroy(tgp_dist* h);
+/* hipStream_t of the context: which = 0 main (updates), 1 panel (chain + pack); the host makes
+ * its RCCL calls wait on / be waited on by these */
+int tgp_dist_stream(tgp_dist* h, int which, void** stream_out);
+/* K(X, X) + noise for the owned block columns (kernels/base.py:84-103, noise.py:77-78) */
+int tgp_dist_assemble(tgp_dist* h, const tgp_kop* prog, int nops);
+/* start of a factorisation; resid_host (n,) != NULL: also forward-substitute it (gp.py:318-320) */
+int tgp_dist_begin(tgp_dist* h, const void* resid_host);
+/* owner of panel 0: factor + pack it (no-op on the other ranks) */
+int tgp_dist_first_panel(tgp_dist* h);
+/* panel k has arrived in its ring slot (the main stream already waits for it): forward-
+ * substitution step k; on the owner of panel k+1 also the look-ahead update, chain and pack */
+int tgp_dist_after_recv(tgp_dist* h, int64_t k);
+/* update of all remaining owned block columns by panel k: one fp64/fp32 MFMA launch */
+int tgp_dist_rest(tgp_dist* h, int64_t k);
+/* joins the streams; *info = this rank's potrf info (host: MIN over ranks of the non-zero
+ * ones), *sumsq = |L^-1 r|^2, *logdet_half = sum log L_ii (direct.py:61-64), identical on
+ * every rank */
+int tgp_dist_end(tgp_dist* h, int32_t* info, double* sumsq, double* logdet_half);
+/* backward substitution (solve_triangular(..., trans=1), direct.py:68; gp.py:334), block k, on
+ * its owner: x_k <- L_kk^-T (x_k - L[below, k]^T x[below]); the host then broadcasts x_k */
+int tgp_dist_bwd_step(tgp_dist* h, int64_t k);
+/* this rank's share of K(X*, X) alpha over its owned columns (gp.py:353-359 via
+ * kernels/base.py:68-82), fused, into out_dev (m,); the host all-reduces it */
+int tgp_dist_cond_mean_partial(tgp_dist* h, const tgp_kop* prog, int nops, int64_t m,
+                               const void* Xt_host, void* out_dev);
+/* inspection: local block column l (rows from its diagonal block down, ld = rows) to the host */
+int tgp_dist_get_column(tgp_dist* h, int64_t l, void* out_host);
+
 /* ---- schedule dry run (test infrastructure of the host logic; needs no GPU) -------------
  * The kernel launches and event operations tgp_solver_factor (fused = 0) or
  * tgp_solver_factor_logprob (fused = 1) would enqueue on the library's five streams for an

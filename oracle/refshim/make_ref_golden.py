@@ -1,0 +1,142 @@
+#!/usr/bin/env python
+"""Golden vectors from the reference ITSELF: imports /root/reference/src/tinygp unmodified on
+top of the NumPy stand-ins in this directory (README.md) and writes tests/golden/ref_*.npz.
+
+    python oracle/refshim/make_ref_golden.py [--fast]     (build container only)
+
+TEST INFRASTRUCTURE ONLY.  The fixtures are committed; the reference never travels.
+Cases, seeds and shapes: tests/_cases.py (each cites the reference test it comes from).
+"""
+import argparse
+import sys
+import time
+import types
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parents[1]
+REFERENCE_SRC = Path("/root/reference/src")
+
+
+def import_reference():
+    """The reference package exactly as it lies under /root/reference (read-only)."""
+    if not (REFERENCE_SRC / "tinygp" / "gp.py").exists():
+        raise SystemExit(f"{REFERENCE_SRC} not found: the reference only exists in the build container")
+    sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
+    for p in (str(HERE), str(REFERENCE_SRC)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import jax  # noqa: F401  the stand-in
+
+    assert "refshim" in jax.__version__, "a real jax is importable: use it instead of the shim"
+    # generated at build time by hatch-vcs (pyproject.toml), absent from the source tree
+    ver = types.ModuleType("tinygp.tinygp_version")
+    ver.__version__ = "0+reference-tree"
+    sys.modules.setdefault("tinygp.tinygp_version", ver)
+    import tinygp
+
+    assert Path(tinygp.__file__).resolve().is_relative_to(REFERENCE_SRC)
+    return tinygp
+
+
+def kernels_golden(tinygp, cases):
+    x1, x2 = cases.data_kernels()
+    xs, _, ts = cases.data_solver()
+    res = {}
+    for name, k in cases.kernel_zoo(tinygp.kernels).items():
+        res[f"{name}__5d"] = np.asarray(k(x1, x2))
+        res[f"{name}__1d"] = np.asarray(k(xs, ts))
+        res[f"{name}__diag"] = np.asarray(k(x1))
+    return res
+
+
+def gp_golden(tinygp, cases):
+    res = {}
+    for name, (gp, y, t) in cases.gp_cases(tinygp.kernels, tinygp.GaussianProcess).items():
+        res[f"{name}__logp"] = np.float64(gp.log_probability(y))
+        res[f"{name}__norm"] = np.float64(gp.solver.normalization())
+        res[f"{name}__var"] = np.asarray(gp.variance)
+        c0 = gp.condition(y)
+        res[f"{name}__self_loc"] = np.asarray(c0.gp.loc)
+        res[f"{name}__self_var"] = np.asarray(c0.gp.variance)
+        c1 = gp.condition(y, t)
+        res[f"{name}__test_logp"] = np.float64(c1.log_probability)
+        res[f"{name}__test_loc"] = np.asarray(c1.gp.loc)
+        res[f"{name}__test_var"] = np.asarray(c1.gp.variance)
+        res[f"{name}__test_cov"] = np.asarray(c1.gp.covariance)
+        # predict() variants (gp.py:225-271)
+        res[f"{name}__predict_nomean"] = np.asarray(gp.predict(y, t, include_mean=False))
+        # the conditioned process is itself a GP (gp.py:380-385): its mean function at new
+        # points (means.py:58-86) and a second conditioning on "observations" at t
+        tn = t[:5] + 0.05
+        res[f"{name}__cmean_new"] = np.asarray(
+            [np.float64(c1.gp.mean_function(x)) for x in tn])
+        y2 = np.asarray(c1.gp.loc) + 0.1 * np.cos(np.arange(len(t)))
+        c2 = c1.gp.condition(y2, tn)
+        res[f"{name}__recond_logp"] = np.float64(c2.log_probability)
+        res[f"{name}__recond_loc"] = np.asarray(c2.gp.loc)
+        res[f"{name}__recond_var"] = np.asarray(c2.gp.variance)
+    return res
+
+
+def config_golden(tinygp, cases, fast):
+    """BASELINE.json config 1 (N = 1024) in full; larger sizes as scalars (the looped vmap
+    makes N^2 Python calls: N = 4096 takes minutes, skipped with --fast)."""
+    res = {}
+    syn = cases.synthetic
+    for n in (1024,) if fast else (1024, 4096):
+        X, y = syn.make_inputs(n, 1)
+        gp = tinygp.GaussianProcess(syn.config_kernel(tinygp.kernels, "expsq"), X, diag=0.01)
+        alpha = np.asarray(gp.solver.solve_triangular(y))
+        L = np.asarray(gp.solver.scale_tril)
+        res[f"expsq_n{n}__logp"] = np.float64(gp.log_probability(y))
+        res[f"expsq_n{n}__norm"] = np.float64(gp.solver.normalization())
+        res[f"expsq_n{n}__alpha_head"] = alpha[:16]
+        res[f"expsq_n{n}__alpha_tail"] = alpha[-16:]
+        res[f"expsq_n{n}__Ldiag_head"] = np.diag(L)[:16]
+        res[f"expsq_n{n}__Ldiag_tail"] = np.diag(L)[-16:]
+        if n == 1024:
+            xt = np.linspace(0, n / 100, 64)
+            c = gp.condition(y, xt)
+            res["expsq_n1024__test_loc"] = np.asarray(c.gp.loc)
+            res["expsq_n1024__test_var"] = np.asarray(c.gp.variance)
+    if not fast:
+        X3, y3 = syn.make_inputs(2048, 3)
+        gp = tinygp.GaussianProcess(syn.config_kernel(tinygp.kernels, "matern52"), X3, diag=0.01)
+        res["m52_3d_n2048__logp"] = np.float64(gp.log_probability(y3))
+        xb, yb = cases.data_benchmark(2000)
+        gp = tinygp.GaussianProcess(cases.kernel_zoo(tinygp.kernels)["bench_m32"], xb, diag=0.01)
+        res["bench_m32_n2000__logp"] = np.float64(gp.log_probability(yb))
+        # config 5's kernel (Sum(ExpSquared, Matern32)), posterior mean at test points, fp64
+        X5, y5 = syn.make_inputs(1024, 1)
+        gp = tinygp.GaussianProcess(syn.config_kernel(tinygp.kernels, "sum"), X5, diag=0.1)
+        xt = np.linspace(0, 10.24, 128)
+        res["sum_n1024__logp"] = np.float64(gp.log_probability(y5))
+        res["sum_n1024__test_loc"] = np.asarray(gp.predict(y5, xt))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fast", action="store_true", help="skip the N >= 2000 cases")
+    ap.add_argument("--out", default=str(ROOT / "tests" / "golden"))
+    args = ap.parse_args()
+    tinygp = import_reference()
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import _cases
+
+    out = Path(args.out)
+    for fname, fn in (("ref_kernels.npz", lambda: kernels_golden(tinygp, _cases)),
+                      ("ref_gp.npz", lambda: gp_golden(tinygp, _cases)),
+                      ("ref_configs.npz", lambda: config_golden(tinygp, _cases, args.fast))):
+        t0 = time.time()
+        res = fn()
+        np.savez_compressed(out / fname, **res)
+        print(f"{fname}: {len(res)} arrays, {time.time() - t0:.1f} s")
+
+
+if __name__ == "__main__":
+    main()

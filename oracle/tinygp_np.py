@@ -357,6 +357,19 @@ def _eval_mean(mean, X):  # means.py:31-55 + the vmap at gp.py:86-87
     return np.broadcast_to(np.asarray(mean, dtype=np.asarray(X).dtype), (n,)).copy()
 
 
+class ConditionedMean:  # means.py:58-86 (`means.Conditioned`): k(x, X) . alpha (+ mean(x))
+    def __init__(self, X, alpha, kernel, include_mean, mean_function=None):
+        self.X, self.alpha, self.kernel = X, alpha, kernel
+        self.include_mean, self.mean_function = include_mean, mean_function
+
+    def __call__(self, x):  # ONE point, like the reference (vmapped by its callers)
+        xs = np.asarray(x)[None]
+        mu = self.kernel(xs, self.X)[0] @ self.alpha  # means.py:81-82
+        if self.include_mean and self.mean_function is not None:  # means.py:83-85
+            mu = mu + _eval_mean(self.mean_function, xs)[0]
+        return mu
+
+
 # --------------------------------------------------------------------------
 # gp.py
 # --------------------------------------------------------------------------
@@ -447,6 +460,8 @@ class GaussianProcess:
         if X_test is None:
             X_test = self.X
         gp = GaussianProcess(Conditioned(self.X, self.solver, kernel), X_test, noise=noise,
+                             mean=ConditionedMean(self.X, alpha, kernel, include_mean=include_mean,
+                                                  mean_function=self.mean_function),  # gp.py:210-216
                              mean_value=mean_value, covariance_value=covariance_value)
         return ConditionResult(log_prob, gp)
 

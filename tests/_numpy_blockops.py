@@ -1,7 +1,13 @@
 """TEST INFRASTRUCTURE: a NumPy/SciPy stand-in for tinygp_amd.distributed.HipBlockOps so the
-block-cyclic schedule (ownership, look-ahead, broadcasts, slice all-reduces) can run under
-`gloo` on CPUs.  Same method signatures, torch CPU tensors as buffers, the oracle's kernel
-evaluation for assembly.  Never imported by the product."""
+block-cyclic schedule (ownership, look-ahead order, ring slots, panel broadcasts, replicated
+forward solve, slice broadcasts of the backward solve, the (M,) all-reduce) can run under `gloo`
+on CPUs.  Same methods and the same buffer layout as csrc/dist.hip -- local block columns side
+by side in one column-major matrix with GLOBAL rows, ring slot = [dinv | rows x nb panel] --
+torch CPU tensors as the buffers the collectives see, the oracle's kernel evaluation for
+assembly.  Never imported by the product."""
+import contextlib
+import re
+
 import numpy as np
 import scipy.linalg as sla
 import torch
@@ -10,80 +16,142 @@ from oracle import ref_prog
 
 
 class NumpyBlockOps:
-    def context(self):
-        import contextlib
+    def setup(self, P, noise_diag, nb, world, rank):
+        self.P, self.diag = P, noise_diag
+        self.n, self.d = P.shape
+        self.nb, self.G, self.rank = nb, world, rank
+        self.dtype = P.dtype
+        self.nblk = -(-self.n // nb)
+        self.npad = self.nblk * nb
+        self.nloc = len(range(rank, self.nblk, world))
+        self.nd = (nb // 128) * 2048
+        tdt = torch.float64 if P.dtype == np.float64 else torch.float32
+        self.ring = [torch.zeros(self.nd + self.npad * nb, dtype=tdt) for _ in range(2)]
+        self.x = torch.zeros(self.npad, dtype=tdt)
+        self.xn = self.x.numpy()  # shares memory
+        self.A = np.zeros((self.npad, max(self.nloc, 1) * nb), dtype=P.dtype, order="F")
+        self.calls = []  # host-order log of the schedule (asserted by the tests)
 
+    def stream(self, which):
         return contextlib.nullcontext()
 
-    def empty(self, nelem, dtype):
-        return torch.empty(int(nelem), dtype=torch.float64 if np.dtype(dtype) == np.float64 else torch.float32)
+    def slot(self, k, rows):
+        return self.ring[k & 1][: self.nd + rows * self.nb]
 
-    def zeros(self, nelem, dtype):
-        return torch.zeros(int(nelem), dtype=torch.float64 if np.dtype(dtype) == np.float64 else torch.float32)
+    def x_slice(self, k):
+        return self.x[k * self.nb:(k + 1) * self.nb]
 
-    def from_numpy(self, a):
-        return torch.from_numpy(np.ascontiguousarray(a).copy())
+    def scalar(self, v):
+        return torch.tensor([v], dtype=torch.float64)
 
-    @staticmethod
-    def _mat(t, rows, cols, off=0):
-        """column-major (rows x cols) view with leading dimension = the panel's row count."""
-        a = t.numpy()
-        return a[off:].reshape(-1)  # flat; callers index explicitly
+    def _panel_view(self, k):
+        rows = self.npad - k * self.nb
+        return self.ring[k & 1].numpy()[self.nd: self.nd + rows * self.nb].reshape((rows, self.nb), order="F")
 
-    def assemble(self, prog, X, diag, n, d, j0, nb, out, rows):
-        Xn = X.numpy().reshape(n, d)
-        dg = diag.numpy()
-        M = np.zeros((rows, nb), dtype=Xn.dtype)
-        n1, n2 = max(n - j0, 0), max(min(nb, n - j0), 0)
-        if n1 and n2:
-            M[:n1, :n2] = ref_prog.eval_matrix(prog, Xn[j0:j0 + n1], Xn[j0:j0 + n2])
-            idx = np.arange(n2)
-            M[idx, idx] += dg[j0:j0 + n2]
-        for i in range(min(rows, nb)):  # identity padding
-            if i >= n1 or i >= n2:
-                M[i, i] = 1.0
-        out.numpy()[: rows * nb] = M.reshape(-1, order="F")
+    def _col(self, l):
+        return self.A[:, l * self.nb:(l + 1) * self.nb]
 
-    def factor_panel(self, P, rows, nb):
-        M = P.numpy()[: rows * nb].reshape((rows, nb), order="F")
+    def assemble(self, prog):
+        self.calls.append(("assemble",))
+        nb, n = self.nb, self.n
+        for l in range(self.nloc):
+            j0 = (l * self.G + self.rank) * nb
+            C = self._col(l)
+            C[:] = 0.0
+            n1, n2 = max(n - j0, 0), max(min(nb, n - j0), 0)
+            if n1 and n2:
+                C[j0:j0 + n1, :n2] = ref_prog.eval_matrix(prog, self.P[j0:j0 + n1], self.P[j0:j0 + n2])
+                idx = np.arange(n2)
+                C[j0 + idx, idx] += self.diag[j0:j0 + n2]
+            for i in range(nb):  # identity padding
+                if i >= n2:
+                    C[j0 + i, i] = 1.0
+
+    def begin(self, resid):
+        self.calls.append(("begin",))
+        self.info = 0
+        self.logdet = np.zeros(self.nblk)
+        self.solving = resid is not None
+        self.xn[:] = 0.0
+        if self.solving:
+            self.xn[: self.n] = resid
+
+    def _factor_and_pack(self, k):
+        self.calls.append(("panel", k))
+        nb, l = self.nb, k // self.G
+        M = self._col(l)[k * nb:]
         if not np.all(np.isfinite(np.tril(M[:nb]))):  # poisoned by an earlier failing pivot
             M[:] = np.nan
-            P.numpy()[: rows * nb] = M.reshape(-1, order="F")
-            return 0
-        try:
-            L = sla.cholesky(M[:nb], lower=True, check_finite=False)
-        except sla.LinAlgError as e:
-            import re
+        else:
+            try:
+                L = sla.cholesky(M[:nb], lower=True, check_finite=False)
+                M[:nb] = L
+                if M.shape[0] > nb:
+                    M[nb:] = sla.solve_triangular(L, M[nb:].T, lower=True, check_finite=False).T
+            except sla.LinAlgError as e:
+                minor = int(re.search(r"(\d+)-th leading minor", str(e)).group(1))
+                if self.info == 0:
+                    self.info = k * nb + minor
+                M[:] = np.nan
+        self._panel_view(k)[:] = M
 
-            k = int(re.search(r"(\d+)-th leading minor", str(e)).group(1))
-            M[:] = np.nan
-            P.numpy()[: rows * nb] = M.reshape(-1, order="F")
-            return k
-        M[:nb] = L
-        if rows > nb:
-            M[nb:] = sla.solve_triangular(L, M[nb:].T, lower=True, check_finite=False).T
-        P.numpy()[: rows * nb] = M.reshape(-1, order="F")
-        return 0
+    def first_panel(self):
+        if 0 % self.G == self.rank:
+            self._factor_and_pack(0)
 
-    def update(self, P, prow, off, Cj, crow, nb):
-        Pm = P.numpy()[: prow * nb].reshape((prow, nb), order="F")
-        Cm = Cj.numpy()[: crow * nb].reshape((crow, nb), order="F")
-        A = Pm[off:off + crow]
-        Cm -= A @ Pm[off:off + nb].T
-        Cj.numpy()[: crow * nb] = Cm.reshape(-1, order="F")
+    def after_recv(self, k):
+        self.calls.append(("after_recv", k))
+        nb = self.nb
+        P = self._panel_view(k)
+        if self.solving:
+            with np.errstate(all="ignore"):
+                xk = sla.solve_triangular(P[:nb], self.xn[k * nb:(k + 1) * nb], lower=True, check_finite=False)
+                self.xn[k * nb:(k + 1) * nb] = xk
+                self.xn[(k + 1) * nb:] -= P[nb:] @ xk
+        with np.errstate(all="ignore"):
+            self.logdet[k] = np.sum(np.log(np.diag(P[:nb])))
+        k1 = k + 1
+        if k1 < self.nblk and k1 % self.G == self.rank:
+            C = self._col(k1 // self.G)[k1 * nb:]
+            C -= P[nb:] @ P[nb:2 * nb].T
+            self._factor_and_pack(k1)
 
-    def solve_diag(self, P, rows, nb, t):
-        L = P.numpy()[: rows * nb].reshape((rows, nb), order="F")[:nb]
-        t.numpy()[:] = sla.solve_triangular(L, t.numpy(), lower=True, check_finite=False)
+    def rest(self, k):
+        self.calls.append(("rest", k))
+        nb = self.nb
+        P = self._panel_view(k)
+        for l in range(self.nloc):
+            j = l * self.G + self.rank
+            if j <= k or j == k + 1:
+                continue
+            off = (j - k) * nb
+            self._col(l)[j * nb:] -= P[off:] @ P[off:off + nb].T
 
-    def gemv_sub(self, P, rows, nb, x, w_below):
-        if rows > nb:
-            M = P.numpy()[: rows * nb].reshape((rows, nb), order="F")
-            w_below.numpy()[: rows - nb] -= M[nb:] @ x.numpy()
+    def end(self):
+        self.calls.append(("end",))
+        with np.errstate(all="ignore"):
+            return self.info, float(np.sum(self.xn ** 2)) if self.solving else 0.0, float(np.sum(self.logdet))
 
-    def sum_log_diag(self, P, rows, nb, nvalid):
-        L = P.numpy()[: rows * nb].reshape((rows, nb), order="F")
-        return float(np.sum(np.log(np.diag(L[:nb])[:nvalid])))
+    def bwd_step(self, k):
+        if k % self.G != self.rank:
+            return
+        self.calls.append(("bwd", k))
+        nb = self.nb
+        C = self._col(k // self.G)
+        xk = self.xn[k * nb:(k + 1) * nb] - C[(k + 1) * nb:].T @ self.xn[(k + 1) * nb:]
+        self.xn[k * nb:(k + 1) * nb] = sla.solve_triangular(C[k * nb:(k + 1) * nb], xk, lower=True, trans=1,
+                                                            check_finite=False)
 
-    def sum_squares(self, x, nvalid):
-        return float(np.sum(x.numpy()[:nvalid] ** 2))
+    def cond_mean_partial(self, prog, Pt):
+        out = np.zeros(Pt.shape[0], dtype=self.dtype)
+        for l in range(self.nloc):
+            j0 = (l * self.G + self.rank) * self.nb
+            cnt = min(self.nb, self.n - j0)
+            if cnt <= 0:
+                break
+            out += ref_prog.eval_matrix(prog, Pt, self.P[j0:j0 + cnt]) @ self.xn[j0:j0 + cnt]
+        return torch.from_numpy(out)
+
+    def column(self, l, rows):
+        j0 = (l * self.G + self.rank) * self.nb
+        return self._col(l)[j0:].copy()

@@ -1,6 +1,7 @@
-"""The block-cyclic multi-GPU schedule under `gloo`, world size 2, on CPUs: ownership,
-look-ahead order, panel broadcasts and the slice all-reduces of the forward solve, with a
-NumPy stand-in for the per-block HIP kernels (tests/_numpy_blockops.py)."""
+"""The block-cyclic multi-GPU schedule under `gloo` on CPUs, world sizes 2, 3 and 4: ownership,
+look-ahead order, ring-slot reuse, panel broadcasts, the replicated forward solve, the slice
+broadcasts of the backward solve and the (M,) all-reduce of the conditional mean -- with a NumPy
+stand-in for the per-rank device operations (tests/_numpy_blockops.py)."""
 import os
 import sys
 from pathlib import Path
@@ -13,7 +14,11 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _worker(rank, world, port, n, nb, bad, q):
+def _kernels(mod):
+    return 1.5**2 * mod.ExpSquared(2.5) + 0.3 * mod.Matern32(1.2)
+
+
+def _worker(rank, world, port, n, nb, bad, m_test, q):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
                       OPENBLAS_NUM_THREADS="1")
@@ -27,44 +32,69 @@ def _worker(rank, world, port, n, nb, bad, q):
         diag = np.full(n, 0.01)
         if bad:
             diag[bad] = -5.0
-        k = 1.5**2 * kernels.ExpSquared(2.5) + 0.3 * kernels.Matern32(1.2)
-        s = BlockCyclicCholesky(k, X, diag, nb=nb, ops=NumpyBlockOps(), dist=dist)
+        ops = NumpyBlockOps()
+        s = BlockCyclicCholesky(_kernels(kernels), X, diag, nb=nb, ops=ops, dist=dist)
         assert s.owned == [j for j in range(s.nblk) if j % world == rank]
         ll = s.log_probability(y)
-        q.put((rank, ll, s.info))
+        mean = None
+        if m_test:
+            xt = np.linspace(X[0], X[-1], m_test)
+            mean = s.condition_mean(y, xt)
+            # a second evaluation (the optimiser step) re-assembles and re-factors in place
+            ll2 = s.log_probability(y, kernel=1.1 * _kernels(kernels))
+        else:
+            ll2 = None
+        # host order of the schedule: the broadcast of panel k+1 must be ENQUEUED between
+        # after_recv(k) and rest(k) -- i.e. panel k+1 is packed before rest(k) is issued
+        calls = ops.calls
+        for k in range(s.nblk - 1):
+            if (k + 1) % world == rank:
+                assert calls.index(("after_recv", k)) < calls.index(("panel", k + 1)) < calls.index(("rest", k))
+        q.put((rank, ll, s.info, mean, ll2, s.bytes_received))
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, n, nb, bad=0):
+def _run(world, n, nb, bad=0, m_test=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nb, bad, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nb, bad, m_test, q)) for r in range(world)]
     [p.start() for p in procs]
-    out = sorted(q.get(timeout=120) for _ in range(world))
+    out = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     return out
 
 
-@pytest.mark.parametrize("world,n,nb", [(2, 450, 128), (2, 512, 256), (3, 600, 128)])
-def test_block_cyclic_log_probability_matches_oracle(world, n, nb):
+@pytest.mark.parametrize("world,n,nb", [(2, 450, 128), (2, 512, 256), (3, 600, 128), (4, 1100, 128)])
+def test_block_cyclic_log_probability_and_condition_mean_match_oracle(world, n, nb):
     from oracle import tinygp_np as o
     from tinygp_amd import synthetic
 
     X, y = synthetic.make_inputs(n, 1)
-    want = float(o.GaussianProcess(1.5**2 * o.ExpSquared(2.5) + 0.3 * o.Matern32(1.2), X,
-                                   diag=0.01).log_probability(y))
-    out = _run(world, n, nb)
-    for rank, ll, info in out:  # every rank ends with the same scalar
+    gp = o.GaussianProcess(_kernels(o), X, diag=0.01)
+    want = float(gp.log_probability(y))
+    xt = np.linspace(X[0], X[-1], 37)
+    want_mean = gp.predict(y, xt)
+    want2 = float(o.GaussianProcess(1.1 * _kernels(o), X, diag=0.01).log_probability(y))
+    out = _run(world, n, nb, m_test=37)
+    nblk = -(-n // nb)
+    npad = nblk * nb
+    for rank, ll, info, mean, ll2, nbytes in out:  # every rank ends with the same results
         assert info == 0
         np.testing.assert_allclose(ll, want, rtol=1e-9)
+        np.testing.assert_allclose(mean, want_mean, rtol=5e-7, atol=5e-7)
+        np.testing.assert_allclose(ll2, want2, rtol=1e-9)
+        # broadcast volume: every panel this rank does not own, rows x nb (+ dinv)
+        expect = sum(((npad - k * nb) * nb + (nb // 128) * 2048) * 8 for k in range(nblk) if k % world != rank)
+        assert nbytes == expect
+    assert len({o_[1] for o_ in out}) == 1  # bit-identical across ranks (replicated solve)
 
 
 def test_block_cyclic_reports_first_bad_pivot_on_every_rank():
     out = _run(2, 500, 128, bad=300)
-    for rank, ll, info in out:
+    for rank, ll, info, *_ in out:
         assert info == 301 and ll == -np.inf
 
 

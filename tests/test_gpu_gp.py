@@ -11,7 +11,7 @@ import pytest
 
 import _cases
 from oracle import tinygp_np as o
-from tinygp_amd import GaussianProcess, kernels, noise
+from tinygp_amd import GaussianProcess, kernels, means, noise
 from tinygp_amd.solvers import DirectSolver
 
 pytestmark = pytest.mark.gpu
@@ -51,6 +51,66 @@ def test_gp_cases_match_oracle_and_golden(name, golden_dir):
     np.testing.assert_allclose(c1.gp.variance, g[f"{name}__test_var"], **TOL)
     np.testing.assert_allclose(c1.gp.covariance, g[f"{name}__test_cov"], **TOL)
     assert _loaded_native()
+
+
+@pytest.mark.parametrize("name", sorted(_cases.gp_cases(o, o.GaussianProcess)))
+def test_gp_cases_match_reference_golden(name, golden_dir):
+    """Against the reference's OWN outputs (tests/golden/ref_gp.npz: /root/reference's classes
+    run unmodified under oracle/refshim), including the conditioned process used as a GP of
+    its own: ``means.Conditioned`` at new points (means.py:58-86) and a second conditioning
+    (gp.py:380-385)."""
+    r = np.load(golden_dir / "ref_gp.npz")
+    gp, y, t = _cases.gp_cases(kernels, GaussianProcess)[name]
+    np.testing.assert_allclose(gp.log_probability(y), r[f"{name}__logp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(gp.solver.normalization(), r[f"{name}__norm"], rtol=LL_RTOL)
+    np.testing.assert_allclose(gp.variance, r[f"{name}__var"], **TOL)
+    c0 = gp.condition(y)
+    np.testing.assert_allclose(c0.gp.loc, r[f"{name}__self_loc"], **TOL)
+    np.testing.assert_allclose(c0.gp.variance, r[f"{name}__self_var"], **TOL)
+    c1 = gp.condition(y, t)
+    np.testing.assert_allclose(c1.log_probability, r[f"{name}__test_logp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(c1.gp.loc, r[f"{name}__test_loc"], **TOL)
+    np.testing.assert_allclose(c1.gp.variance, r[f"{name}__test_var"], **TOL)
+    np.testing.assert_allclose(c1.gp.covariance, r[f"{name}__test_cov"], **TOL)
+    np.testing.assert_allclose(gp.predict(y, t, include_mean=False), r[f"{name}__predict_nomean"], **TOL)
+    tn = t[:5] + 0.05
+    assert isinstance(c1.gp.mean_function, means.Conditioned)
+    np.testing.assert_allclose([c1.gp.mean_function(x) for x in tn], r[f"{name}__cmean_new"], **TOL)
+    np.testing.assert_allclose(c1.gp.mean_function.batch(tn), r[f"{name}__cmean_new"], **TOL)
+    y2 = np.asarray(c1.gp.loc) + 0.1 * np.cos(np.arange(len(t)))
+    c2 = c1.gp.condition(y2, tn)  # conditioning a conditioned GP: host-evaluated Conditioned kernel
+    np.testing.assert_allclose(c2.log_probability, r[f"{name}__recond_logp"], rtol=1e-6)
+    np.testing.assert_allclose(c2.gp.loc, r[f"{name}__recond_loc"], **TOL)
+    np.testing.assert_allclose(c2.gp.variance, r[f"{name}__recond_var"], **TOL)
+    assert np.all(np.isfinite(c2.gp.covariance)) and _loaded_native()
+
+
+def test_reference_golden_configs(golden_dir):
+    """BASELINE config 1 and the mid-size scalars, from the reference's own code."""
+    r = np.load(golden_dir / "ref_configs.npz")
+    syn = _cases.synthetic
+    for n in (1024, 4096):
+        X, y = syn.make_inputs(n, 1)
+        gp = GaussianProcess(syn.config_kernel(kernels, "expsq"), X, diag=0.01)
+        np.testing.assert_allclose(gp.log_probability(y), r[f"expsq_n{n}__logp"], rtol=LL_RTOL)
+        np.testing.assert_allclose(gp.solver.normalization(), r[f"expsq_n{n}__norm"], rtol=LL_RTOL)
+        alpha = gp.solver.solve_triangular(y)
+        np.testing.assert_allclose(alpha[:16], r[f"expsq_n{n}__alpha_head"], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(alpha[-16:], r[f"expsq_n{n}__alpha_tail"], rtol=1e-6, atol=1e-8)
+    cnd = GaussianProcess(syn.config_kernel(kernels, "expsq"), *syn.make_inputs(1024, 1)[:1],
+                          diag=0.01).condition(syn.make_inputs(1024, 1)[1], np.linspace(0, 10.24, 64))
+    np.testing.assert_allclose(cnd.gp.loc, r["expsq_n1024__test_loc"], **TOL)
+    np.testing.assert_allclose(cnd.gp.variance, r["expsq_n1024__test_var"], **TOL)
+    X3, y3 = syn.make_inputs(2048, 3)
+    gp = GaussianProcess(syn.config_kernel(kernels, "matern52"), X3, diag=0.01)
+    np.testing.assert_allclose(gp.log_probability(y3), r["m52_3d_n2048__logp"], rtol=LL_RTOL)
+    xb, yb = _cases.data_benchmark(2000)
+    gp = GaussianProcess(_cases.kernel_zoo(kernels)["bench_m32"], xb, diag=0.01)
+    np.testing.assert_allclose(gp.log_probability(yb), r["bench_m32_n2000__logp"], rtol=LL_RTOL)
+    X5, y5 = syn.make_inputs(1024, 1)  # config 5's kernel: posterior mean at test points
+    gp = GaussianProcess(syn.config_kernel(kernels, "sum"), X5, diag=0.1)
+    np.testing.assert_allclose(gp.log_probability(y5), r["sum_n1024__logp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(gp.predict(y5, np.linspace(0, 10.24, 128)), r["sum_n1024__test_loc"], **TOL)
 
 
 def test_predict_variants_like_george_compat():
@@ -158,6 +218,71 @@ def test_covariance_argument_and_dense_noise():
     gp = GaussianProcess(k, x, diag=0.2, covariance_value=cov)
     np.testing.assert_allclose(gp.log_probability(y), o.GaussianProcess(ko, x, diag=0.2).log_probability(y),
                                rtol=LL_RTOL)
+
+
+def test_refactor_keeps_dense_noise_and_drops_stale_covariance():
+    """a new kernel must neither drop the off-diagonal noise (noise.Dense lives
+    only in the host covariance) nor factor the previous kernel's matrix."""
+    x, y, _ = _cases.data_solver()
+    rng = np.random.default_rng(2)
+    R = rng.normal(size=(50, 50)) * 0.05
+    M = R @ R.T + 0.1 * np.eye(50)
+    gp = GaussianProcess(kernels.Matern52(1.1), x, noise=noise.Dense(M))
+    for k, ko in ((1.7 * kernels.Matern32(0.8), 1.7 * o.Matern32(0.8)),
+                  (kernels.ExpSquared(0.6), o.ExpSquared(0.6))):
+        gp.solver.refactor(k)
+        want = o.GaussianProcess(ko, x, noise=o.Dense(M))
+        np.testing.assert_allclose(gp.solver.log_probability(y), want.log_probability(y), rtol=LL_RTOL)
+        np.testing.assert_allclose(gp.solver.covariance(), want.covariance, **TOL)
+        np.testing.assert_allclose(gp.solver.factor_log_probability(y, k), want.log_probability(y),
+                                   rtol=LL_RTOL)
+    # user-supplied covariance with diagonal noise: a new (device) kernel re-assembles
+    cov = o.Matern52(1.1)(x, x) + 0.2 * np.eye(50)
+    gp = GaussianProcess(kernels.Matern52(1.1), x, diag=0.2, covariance_value=cov)
+    gp.solver.refactor(kernels.Matern32(0.9))
+    np.testing.assert_allclose(gp.solver.log_probability(y),
+                               o.GaussianProcess(o.Matern32(0.9), x, diag=0.2).log_probability(y),
+                               rtol=LL_RTOL)
+    # ... and a host-evaluated kernel rebuilds the host matrix instead of keeping the old one
+    gp.solver.refactor(kernels.Custom(lambda a, b: np.exp(-0.5 * np.sum(np.square(a - b)) / 0.49)))
+    np.testing.assert_allclose(gp.solver.log_probability(y),
+                               o.GaussianProcess(o.ExpSquared(0.7), x, diag=0.2).log_probability(y),
+                               rtol=LL_RTOL)
+
+
+def test_host_evaluated_kernels_factor_on_the_device():
+    """Custom / DotProduct / Polynomial / a user subclass that only overrides evaluate()
+    (reference kernels/base.py:38-57,156-256): the matrix comes from Python, the Cholesky,
+    solves and conditioning from the HIP solver."""
+    x1, _ = _cases.data_kernels()
+    y = np.sin(x1[:, 0])
+    t = x1[:9] + 0.2
+
+    class MyKernel(kernels.Kernel):
+        def evaluate(self, X1, X2):
+            return np.exp(-np.sum(np.abs(X1 - X2)) / 1.5)
+
+    for k, ko in ((MyKernel(), o.Exp(1.5)),
+                  (kernels.Custom(lambda a, b: np.exp(-np.sum(np.abs(a - b)) / 1.5)), o.Exp(1.5)),
+                  (kernels.Custom(lambda a, b: np.exp(-np.sum(np.abs(a - b)) / 1.5)) * 2.0
+                   + kernels.Matern32(0.7), 2.0 * o.Exp(1.5) + o.Matern32(0.7))):
+        gp, ref = GaussianProcess(k, x1, diag=0.05), o.GaussianProcess(ko, x1, diag=0.05)
+        np.testing.assert_allclose(gp.log_probability(y), ref.log_probability(y), rtol=LL_RTOL)
+        c, cr = gp.condition(y, t), ref.condition(y, t)
+        np.testing.assert_allclose(c.gp.loc, cr.gp.loc, **TOL)
+        np.testing.assert_allclose(c.gp.variance, cr.gp.variance, **TOL)
+        np.testing.assert_allclose(c.gp.covariance, cr.gp.covariance, **TOL)
+    K = x1 @ x1.T
+    gp = GaussianProcess(kernels.DotProduct(), x1, diag=0.3)
+    sign, logdet = np.linalg.slogdet(K + 0.3 * np.eye(50))
+    want = -0.5 * y @ np.linalg.solve(K + 0.3 * np.eye(50), y) - 0.5 * logdet - 25 * np.log(2 * np.pi)
+    np.testing.assert_allclose(gp.log_probability(y), want, rtol=LL_RTOL)
+    Kp = ((x1 / 2.0) @ (x1 / 2.0).T + 0.5**2) ** 2
+    gp = GaussianProcess(kernels.Polynomial(order=2, scale=2.0, sigma=0.5), x1, diag=0.3)
+    sign, logdet = np.linalg.slogdet(Kp + 0.3 * np.eye(50))
+    want = -0.5 * y @ np.linalg.solve(Kp + 0.3 * np.eye(50), y) - 0.5 * logdet - 25 * np.log(2 * np.pi)
+    np.testing.assert_allclose(gp.log_probability(y), want, rtol=LL_RTOL)
+    assert _loaded_native()
 
 
 def test_numerical_failure_never_raises():

@@ -25,6 +25,7 @@ def test_kernel_matrix_matches_oracle(name, golden_dir):
     """K1: per-entry agreement <= 4 ulp with NumPy (same operation order, ocml vs libm
     exp/sin/cos/pow) on the 5-D and 1-D fixtures of the reference's kernel tests."""
     g = np.load(golden_dir / "kernels.npz")
+    ref = np.load(golden_dir / "ref_kernels.npz")  # the reference's own outputs (oracle/refshim)
     x1, x2 = _cases.data_kernels()
     xs, _, ts = _cases.data_solver()
     kp, ko = _cases.kernel_zoo(kernels)[name], _cases.kernel_zoo(o)[name]
@@ -39,7 +40,11 @@ def test_kernel_matrix_matches_oracle(name, golden_dir):
         else:
             assert ulp_diff(got, want) <= 4, (name, key, ulp_diff(got, want))
         np.testing.assert_allclose(got, g[f"{name}__{key}"], rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(got, ref[f"{name}__{key}"], rtol=1e-13, atol=1e-14)
+        if name not in ("cosine", "solver_cos", "expsine2", "sum_ops", "prod_ops"):
+            assert ulp_diff(got, ref[f"{name}__{key}"]) <= 4, (name, key)
     np.testing.assert_allclose(kp(x1), ko(x1), rtol=1e-15)
+    np.testing.assert_allclose(kp(x1), ref[f"{name}__diag"], rtol=1e-15)
     # fp32 path: reference tolerance 5e-4 (test_utils.py:15)
     got32 = kp(x1.astype(np.float32), x2.astype(np.float32))
     assert got32.dtype == np.float32

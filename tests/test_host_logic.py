@@ -175,3 +175,34 @@ def test_bench_trailing_update_accounting():
     # c2: 15 block-column updates + 14 rest updates; all block columns are under the threshold
     assert bench.trailing_update_bytes(16384, 1024, 8)[1] == 29
     assert bench.trailing_update_bytes(16384, 1024, 8, first_small_tiles=1100)[1] == 14
+
+
+def test_host_evaluated_kernels_need_no_device():
+    """Custom / DotProduct / Polynomial and a user subclass that only overrides evaluate()
+    (reference kernels/base.py:38-57,156-256) are evaluated in Python; their matrices reach the
+    solver through covariance=.  Values per the reference's test_kernels.py:23-40,54-59."""
+    x1, x2 = _cases.data_kernels()
+    np.testing.assert_allclose(kernels.DotProduct()(x1, x2), x1 @ x2.T)
+    np.testing.assert_allclose(kernels.DotProduct()(x1), np.sum(x1 * x1, axis=1))
+    np.testing.assert_allclose(kernels.DotProduct()(x1[:, 0], x2[:, 0]), np.outer(x1[:, 0], x2[:, 0]))
+    np.testing.assert_allclose(kernels.Polynomial(order=3, scale=2.0, sigma=0.7)(x1, x2),
+                               ((x1 / 2.0) @ (x2 / 2.0).T + 0.49) ** 3)
+    f = lambda a, b: np.exp(-np.sum(np.square(a - b)))  # noqa: E731
+    want = np.exp(-np.sum(np.square(x1[:, None] - x2[None]), axis=-1))
+    np.testing.assert_allclose(kernels.Custom(f)(x1, x2), want)
+    np.testing.assert_allclose(kernels.Custom(f).evaluate(x1[0], x2[1]), want[0, 1])
+
+    class Mine(kernels.Kernel):
+        def evaluate(self, X1, X2):
+            return f(X1, X2)
+
+    np.testing.assert_allclose(Mine()(x1, x2), want)
+    np.testing.assert_allclose(Mine()(x1), np.ones(50))
+    np.testing.assert_allclose(Mine().matmul(x1, x2, np.ones(50)), want.sum(axis=1))
+    # algebra over host-evaluated operands combines the operands' matrices (a device operand
+    # such as Constant or Matern32 is evaluated on the device: covered by the GPU tests)
+    np.testing.assert_allclose((Mine() * Mine() + kernels.DotProduct())(x1, x2), want * want + x1 @ x2.T)
+    with pytest.raises(ValueError):  # base.py:97-102: a vector-valued kernel
+        kernels.Custom(lambda a, b: a - b)(x1, x2)
+    with pytest.raises(NotImplementedError):  # no program and no evaluate()
+        type("Empty", (kernels.Kernel,), {})()(x1, x2)

@@ -1,0 +1,170 @@
+"""Parity pin to the reference's OWN execution.
+
+``tests/golden/ref_*.npz`` were produced by importing ``/root/reference/src/tinygp``
+unmodified on top of the NumPy stand-ins for jax / equinox in ``oracle/refshim``
+(``oracle/refshim/make_ref_golden.py``).  Here:
+
+* the stand-ins are unit-tested (they are the only thing between the reference's source and
+  its numbers);
+* the NumPy oracle is checked against those reference outputs (so "oracle == reference" is
+  a tested statement, and the GPU parity tests can use either);
+* where the reference tree exists (the build container), the generation is re-run and must
+  reproduce the committed fixtures.
+"""
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import _cases
+from oracle import tinygp_np as o
+
+ROOT = Path(__file__).resolve().parent.parent
+SHIM = ROOT / "oracle" / "refshim"
+REFERENCE = Path("/root/reference/src/tinygp")
+
+
+# ---- the stand-ins ----------------------------------------------------------------------------
+def _run_with_shim(code: str) -> str:
+    """The shim shadows `jax`: exercise it in a subprocess so this process stays clean."""
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {str(SHIM)!r})\n" + code],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def test_shim_vmap_jit_at_and_module():
+    out = _run_with_shim('''
+import numpy as np, jax, jax.numpy as jnp, equinox as eqx
+from functools import partial
+from abc import abstractmethod
+f = lambda a, b: jnp.sum(jnp.abs(a - b))
+A, B = np.arange(6.).reshape(3, 2), np.arange(8.).reshape(4, 2) * 0.5
+K = jax.vmap(jax.vmap(f, in_axes=(None, 0)), in_axes=(0, None))(A, B)
+assert K.shape == (3, 4) and np.allclose(K, np.abs(A[:, None] - B[None]).sum(-1))
+assert np.allclose(jax.vmap(f, in_axes=(0, None), out_axes=0)(A, B[1]), np.abs(A - B[1]).sum(-1))
+tree = jax.vmap(lambda d: d["u"] * 2 + d["v"][0])({"u": np.arange(3.), "v": np.ones((3, 2))})
+assert np.allclose(tree, [1, 3, 5])
+assert jax.jit(f) is f and partial(jax.jit, static_argnums=(1,))(f) is f
+M = jnp.asarray(np.zeros((3, 3))).at[jnp.diag_indices(3)].add(np.array([1., 2., 3.]))
+assert np.allclose(M, np.diag([1., 2., 3.])) and jnp.zeros(()).dtype == np.float64
+assert jnp.finfo(M).eps == np.finfo(np.float64).eps
+from jax.scipy import linalg
+assert np.isnan(linalg.cholesky(-np.eye(2), lower=True)).all()          # JAX: NaN, never raises
+L = linalg.cholesky(np.array([[4., 2.], [2., 5.]]), lower=True)
+assert np.allclose(linalg.solve_triangular(L, np.array([2., 5.]), lower=True, trans=1),
+                   np.linalg.solve(L.T, [2., 5.]))
+class Base(eqx.Module):
+    scale: float = eqx.field(default_factory=lambda: jnp.ones(()))
+    tag: str = eqx.field(default="t", static=True)
+    @abstractmethod
+    def f(self): ...
+class Leaf(Base):
+    extra: float | None = None
+    def __check_init__(self):
+        if self.extra is None: raise ValueError("missing")
+    def f(self): return self.scale * self.extra
+assert Leaf(2.0, extra=3.0).f() == 6.0 and Leaf(extra=1.0).tag == "t"
+for bad in (lambda: Leaf(1.0), lambda: Base(1.0)):
+    try: bad()
+    except (ValueError, TypeError): pass
+    else: raise AssertionError("expected an error")
+class Own(eqx.Module):
+    a: float
+    def __init__(self, x): self.a = 2 * x
+class Child(Own):
+    pass
+assert Own(2).a == 4 and Child(3).a == 6
+try: jax.lax.scan(None, None, None)
+except NotImplementedError: print("ok")
+''')
+    assert out.strip() == "ok"
+
+
+# ---- oracle == reference --------------------------------------------------------------------
+def test_oracle_kernels_equal_reference(golden_dir):
+    r = np.load(golden_dir / "ref_kernels.npz")
+    x1, x2 = _cases.data_kernels()
+    xs, _, ts = _cases.data_solver()
+    zoo = _cases.kernel_zoo(o)
+    assert {k.split("__")[0] for k in r.files} == set(zoo)
+    for name, k in zoo.items():
+        # same NumPy primitives in the same order: the entries are bit-identical
+        np.testing.assert_array_equal(k(x1, x2), r[f"{name}__5d"], err_msg=name)
+        np.testing.assert_array_equal(k(xs, ts), r[f"{name}__1d"], err_msg=name)
+        np.testing.assert_array_equal(k(x1), r[f"{name}__diag"], err_msg=name)
+
+
+def test_oracle_gp_equals_reference(golden_dir):
+    r = np.load(golden_dir / "ref_gp.npz")
+    for name, (gp, y, t) in _cases.gp_cases(o, o.GaussianProcess).items():
+        np.testing.assert_allclose(gp.log_probability(y), r[f"{name}__logp"], rtol=1e-12)
+        np.testing.assert_allclose(gp.solver.normalization(), r[f"{name}__norm"], rtol=1e-13)
+        np.testing.assert_allclose(gp.variance, r[f"{name}__var"], rtol=1e-14)
+        c0 = gp.condition(y)
+        np.testing.assert_allclose(c0.gp.loc, r[f"{name}__self_loc"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(c0.gp.variance, r[f"{name}__self_var"], rtol=1e-8, atol=1e-11)
+        c1 = gp.condition(y, t)
+        np.testing.assert_allclose(c1.log_probability, r[f"{name}__test_logp"], rtol=1e-12)
+        np.testing.assert_allclose(c1.gp.loc, r[f"{name}__test_loc"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(c1.gp.variance, r[f"{name}__test_var"], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(c1.gp.covariance, r[f"{name}__test_cov"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(gp.predict(y, t, include_mean=False), r[f"{name}__predict_nomean"],
+                                   rtol=1e-9, atol=1e-11)
+        # the conditioned process as a GP of its own (gp.py:380-385, means.py:58-86)
+        tn = t[:5] + 0.05
+        np.testing.assert_allclose([c1.gp.mean_function(x) for x in tn], r[f"{name}__cmean_new"],
+                                   rtol=1e-9, atol=1e-11)
+        y2 = np.asarray(c1.gp.loc) + 0.1 * np.cos(np.arange(len(t)))
+        c2 = c1.gp.condition(y2, tn)
+        np.testing.assert_allclose(c2.log_probability, r[f"{name}__recond_logp"], rtol=1e-7)
+        np.testing.assert_allclose(c2.gp.loc, r[f"{name}__recond_loc"], rtol=5e-7, atol=5e-7)
+        np.testing.assert_allclose(c2.gp.variance, r[f"{name}__recond_var"], rtol=5e-7, atol=5e-7)
+
+
+def test_oracle_configs_equal_reference(golden_dir):
+    r = np.load(golden_dir / "ref_configs.npz")
+    syn = _cases.synthetic
+    for n in (1024, 4096):
+        X, y = syn.make_inputs(n, 1)
+        gp = o.GaussianProcess(syn.config_kernel(o, "expsq"), X, diag=0.01)
+        np.testing.assert_allclose(gp.log_probability(y), r[f"expsq_n{n}__logp"], rtol=1e-11)
+        np.testing.assert_allclose(gp.solver.normalization(), r[f"expsq_n{n}__norm"], rtol=1e-12)
+        alpha = gp.solver.solve_triangular(y)
+        np.testing.assert_allclose(alpha[:16], r[f"expsq_n{n}__alpha_head"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(alpha[-16:], r[f"expsq_n{n}__alpha_tail"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(np.diag(gp.solver.scale_tril)[-16:], r[f"expsq_n{n}__Ldiag_tail"],
+                                   rtol=1e-10)
+    # north-star datum (SURVEY 8c, N = 1024), now from the reference's own code
+    np.testing.assert_allclose(r["expsq_n1024__logp"], 853.7063780492, rtol=1e-11)
+    X3, y3 = syn.make_inputs(2048, 3)
+    gp = o.GaussianProcess(syn.config_kernel(o, "matern52"), X3, diag=0.01)
+    np.testing.assert_allclose(gp.log_probability(y3), r["m52_3d_n2048__logp"], rtol=1e-11)
+    xb, yb = _cases.data_benchmark(2000)
+    gp = o.GaussianProcess(_cases.kernel_zoo(o)["bench_m32"], xb, diag=0.01)
+    np.testing.assert_allclose(gp.log_probability(yb), r["bench_m32_n2000__logp"], rtol=1e-11)
+    X5, y5 = syn.make_inputs(1024, 1)
+    gp = o.GaussianProcess(syn.config_kernel(o, "sum"), X5, diag=0.1)
+    np.testing.assert_allclose(gp.log_probability(y5), r["sum_n1024__logp"], rtol=1e-11)
+    np.testing.assert_allclose(gp.predict(y5, np.linspace(0, 10.24, 128)), r["sum_n1024__test_loc"],
+                               rtol=1e-9, atol=1e-11)
+
+
+# ---- reproducibility of the fixtures (build container only) ------------------------------------
+@pytest.mark.skipif(not REFERENCE.exists(), reason="the reference tree only exists in the build container")
+def test_reference_rerun_reproduces_the_committed_fixtures(tmp_path, golden_dir):
+    r = subprocess.run([sys.executable, str(SHIM / "make_ref_golden.py"), "--fast", "--out", str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    for fname in ("ref_kernels.npz", "ref_gp.npz", "ref_configs.npz"):
+        new, old = np.load(tmp_path / fname), np.load(golden_dir / fname)
+        assert set(new.files) <= set(old.files)
+        for k in new.files:
+            if fname == "ref_kernels.npz":
+                np.testing.assert_array_equal(new[k], old[k], err_msg=k)
+            else:  # LAPACK thread count may move the last bits
+                np.testing.assert_allclose(new[k], old[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    # nothing was written into the reference tree
+    assert not list(REFERENCE.rglob("__pycache__"))

@@ -97,6 +97,19 @@ SIGNATURES = {
     "tgp_solver_device_factor": [_vp, _pvp, _pi64],
     "tgp_solver_timings": [_vp, _pdbl, _int],
     "tgp_trace_factor": [_i64, _i64, _i64, _i64, _i64, _i32, _pi64, _i64, _pi64],
+    "tgp_dist_slot_elems": [_i64, _i64],
+    "tgp_dist_create": [_vp, _int, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _pvp],
+    "tgp_dist_destroy": [_vp],
+    "tgp_dist_stream": [_vp, _int, _pvp],
+    "tgp_dist_assemble": [_vp, _pkop, _int],
+    "tgp_dist_begin": [_vp, _vp],
+    "tgp_dist_first_panel": [_vp],
+    "tgp_dist_after_recv": [_vp, _i64],
+    "tgp_dist_rest": [_vp, _i64],
+    "tgp_dist_end": [_vp, _pi32, _pdbl, _pdbl],
+    "tgp_dist_bwd_step": [_vp, _i64],
+    "tgp_dist_cond_mean_partial": [_vp, _pkop, _int, _i64, _vp, _vp],
+    "tgp_dist_get_column": [_vp, _i64, _vp],
 }
 
 
@@ -113,7 +126,8 @@ def load_library(path: Path | None = None) -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib_, name)  # AttributeError = ABI drift, deliberately loud
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "tgp_last_error" else C.c_int
+        fn.restype = (C.c_char_p if name == "tgp_last_error"
+                      else C.c_int64 if name == "tgp_dist_slot_elems" else C.c_int)
     return lib_
 
 

@@ -68,17 +68,16 @@ struct tgp_solver {
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+// argument check + context lock (held until the entry point returns) + device selection
 #define CTX_GUARD(ctx)                                                \
-  do {                                                                \
-    TGP_ARG_CHECK((ctx) != nullptr, "null context");                  \
-    TGP_HIP_TRY(hipSetDevice((ctx)->device));                         \
-  } while (0)
+  TGP_ARG_CHECK((ctx) != nullptr, "null context");                    \
+  std::unique_lock<std::recursive_mutex> _tgp_lock((ctx)->mu);        \
+  TGP_HIP_TRY(hipSetDevice((ctx)->device))
 
 #define SOLVER_GUARD(s)                                               \
-  do {                                                                \
-    TGP_ARG_CHECK((s) != nullptr && (s)->ctx != nullptr, "null solver"); \
-    TGP_HIP_TRY(hipSetDevice((s)->ctx->device));                      \
-  } while (0)
+  TGP_ARG_CHECK((s) != nullptr && (s)->ctx != nullptr, "null solver"); \
+  std::unique_lock<std::recursive_mutex> _tgp_lock((s)->ctx->mu);     \
+  TGP_HIP_TRY(hipSetDevice((s)->ctx->device))
 
 // K(X, X) + noise into the lower tiles of A.  Only the first panel's columns gate the
 // factorisation: the rest of K is assembled on its own stream beside the first panel's
@@ -202,6 +201,7 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "profile")) slot = &ctx->profile;
   else if (!strcmp(key, "first_split")) slot = &ctx->first_split;
   else if (!strcmp(key, "first_small_tiles")) slot = &ctx->first_small_tiles;
+  else if (!strcmp(key, "keep_grad_buffers")) slot = &ctx->keep_grad_buffers;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)
     TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);
@@ -463,7 +463,29 @@ static int upload_vec(tgp_solver* s, void* dst, const void* src_host) {
 
 // fused != 0: also alpha = L^-1 resid (into s->vec) overlapped with the factorisation and
 // *logprob = -0.5 |alpha|^2 - normalization.  resid_host NULL -> the resident residual.
+static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
+                       int32_t* info, int fused, const void* resid_host, double* logprob);
+
+// An error return in the middle of the multi-stream schedule must not leave the context
+// half-way: side streams are drained, the assembly marker is cleared and the profiling
+// events go back to the pool, so that the next call starts from a clean state.
 static int factor_impl(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
+                       int32_t* info, int fused, const void* resid_host, double* logprob) {
+  const int st = factor_body(s, prog, nops, cov_host, info, fused, resid_host, logprob);
+  if (st < 0) {
+    tgp_ctx* ctx = s->ctx;
+    ctx->asm_pending = false;
+    ctx->ev_used = 0;
+    s->factored = false;
+    for (hipStream_t q : {ctx->asm_stream, ctx->panel_stream, ctx->update_stream, ctx->solve_stream,
+                          ctx->stream})
+      if (q) (void)hipStreamSynchronize(q);
+    (void)hipGetLastError();
+  }
+  return st;
+}
+
+static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
                        int32_t* info, int fused, const void* resid_host, double* logprob) {
   tgp_ctx* ctx = s->ctx;
   if (nops > 0) {
@@ -724,11 +746,40 @@ int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, doub
   tgp_ctx* ctx = s->ctx;
   const size_t es = esize(s->dtype);
   const size_t mat = size_t(s->npad) * s->npad * es;
-  if (!s->Minv) TGP_HIP_TRY(hipMalloc(&s->Minv, mat));
-  if (!s->Kinv) TGP_HIP_TRY(hipMalloc(&s->Kinv, mat));
-  TGP_TRY(logprob_device(s, resid_host, logprob));  // s->vec = L^-1 r
+  // Two more N_pad^2 matrices (L^-T and K^-1).  They are released again below unless the
+  // context option "keep_grad_buffers" is set (an optimiser loop at moderate N), and always
+  // on failure: an out-of-memory here must not pin 2/3 of the device for the solver's lifetime.
+  auto release = [&]() {
+    if (s->Minv) (void)hipFree(s->Minv);
+    if (s->Kinv) (void)hipFree(s->Kinv);
+    s->Minv = s->Kinv = nullptr;
+  };
+  auto alloc = [&](void** p) -> int {
+    if (*p) return TGP_OK;
+    hipError_t e = hipMalloc(p, mat);
+    if (e != hipSuccess) {
+      *p = nullptr;
+      (void)hipGetLastError();
+      set_error("gradient needs two more %lld x %lld work matrices (%.1f GB each) and the device "
+                "is out of memory: %s", (long long)s->npad, (long long)s->npad, double(mat) / 1e9,
+                hipGetErrorString(e));
+      return e == hipErrorOutOfMemory ? TGP_E_NOMEM : TGP_E_HIP;
+    }
+    return TGP_OK;
+  };
+  int ast = alloc(&s->Minv);
+  if (ast == TGP_OK) ast = alloc(&s->Kinv);
+  if (ast != TGP_OK) {
+    release();
+    return ast;
+  }
+  int gst = logprob_device(s, resid_host, logprob);  // s->vec = L^-1 r
+  if (gst < 0) {
+    release();
+    return gst;
+  }
   std::vector<double> g(size_t(2 * s->kp.n), 0.0);
-  TGP_TRY(dispatch(s->dtype, [&](auto tag) {
+  gst = (dispatch(s->dtype, [&](auto tag) {
     using T = decltype(tag);
     const T* L = (const T*)s->A;
     T* alpha = (T*)s->vec;
@@ -757,7 +808,15 @@ int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, doub
       TGP_HIP_TRY(hipMemcpyAsync(alpha_host, alpha, size_t(s->n) * es, hipMemcpyDeviceToHost, ctx->stream));
     return TGP_OK;
   }));
-  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (gst >= 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    set_error("hipStreamSynchronize failed in tgp_solver_grad");
+    gst = TGP_E_HIP;
+  }
+  if (gst < 0 || ctx->keep_grad_buffers == 0) {
+    (void)hipStreamSynchronize(ctx->stream);
+    release();
+  }
+  if (gst < 0) return gst;
   for (size_t i = 0; i < g.size(); ++i) grad_params[i] = g[i];
   return TGP_OK;
 }

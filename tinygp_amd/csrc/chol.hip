@@ -688,6 +688,58 @@ int prof_event(tgp_ctx* ctx, hipEvent_t* out) {
 }
 }  // namespace
 
+// potf2 of the 128-block at (j0, j0) of A; `pend`: fold the pending in-panel update from block
+// column j0-128 in.  `pivot_off`: global index of A's first row (distributed panels).
+template <typename T>
+int panel_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int64_t pivot_off,
+                int64_t j0, bool pend) {
+  return launch_potf2<T>(ctx, st, A + j0 * ld + j0, ld, dinv + (j0 / TILE) * 2048, ctx->d_info,
+                         (int32_t)(pivot_off + j0),
+                         pend ? (const T*)(A + (j0 - TILE) * ld + j0) : (const T*)nullptr, ld);
+}
+
+// The panel chain: columns [k0, k0 + kb) of the n-row matrix A are factored in 128-column
+// blocks [potf2 | trsm of every row below | in-panel update of the columns to the right].  Per
+// block the critical path is potf2 -> trsm; the in-panel update runs on its own stream
+// (ctx->update_stream) beside the NEXT block's potf2, which folds the update of its own
+// diagonal tile in (role 3 skips that tile).  y != nullptr: forward-substitution step j is
+// queued on ctx->solve_stream as soon as block column j is final.
+// `after_blocks` / `mid`: once that many blocks of the panel are final, mid() is called with
+// ev_d recorded behind the last of them (the caller hangs an early partial update on it).
+// Shared by the single-GPU driver (potrf) and the block-column driver (dist.hip).
+template <typename T>
+int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* dinv,
+                int64_t pivot_off, int64_t k0, int64_t kb, bool head_done, T* y,
+                int64_t after_blocks, const std::function<int()>& mid) {
+  hipStream_t S2 = ctx->solve_stream, S3 = ctx->update_stream;
+  for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
+    T* Ljj = A + j0 * ld + j0;
+    T* dj = dinv + (j0 / TILE) * 2048;
+    const bool pend = j0 > k0;  // in-panel update from block column j0-128 still in flight
+    if (pend || !head_done) TGP_TRY(panel_potf2<T>(ctx, st, A, ld, dinv, pivot_off, j0, pend));
+    if (pend) TGP_TRY(st_wait(ctx, st, ctx->ev_e));  // rest of that update
+    const int64_t mb = n - (j0 + TILE);
+    if (mb > 0) TGP_TRY(launch_trsm<T>(ctx, st, mb, Ljj, ld, dj, Ljj + TILE, ld));
+    const int64_t nc = (k0 + kb) - (j0 + TILE);
+    const bool upd = mb > 0 && nc > 0;
+    // one marker behind the trsm serves both side streams (every marker between two
+    // kernels of the chain costs it a few microseconds)
+    if (y != nullptr || upd) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
+    if (upd) {
+      TGP_TRY(st_wait(ctx, S3, ctx->ev_d));
+      TGP_TRY(launch_gemm_nt<T>(ctx, S3, mb, nc, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
+                                A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, 3));
+      TGP_TRY(ev_record(ctx, ctx->ev_e, S3));
+    }
+    if (y != nullptr) {
+      TGP_TRY(st_wait(ctx, S2, ctx->ev_d));
+      TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, mb, Ljj, ld, dj, y + j0));
+    }
+    if (after_blocks > 0 && upd && j0 + TILE == k0 + after_blocks * TILE) TGP_TRY(mid());
+  }
+  return TGP_OK;
+}
+
 // y != nullptr: also overwrite y (n, zero padded) with L^-1 y.  Block column j of L is final
 // once its trsm has run, so the forward substitution step j (diagonal solve + update of the
 // rows below) is issued on a third stream right behind it and hides under the
@@ -710,46 +762,14 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   std::vector<ProfSpan> spans;
   ctx->ev_used = 0;
 
-  // Panel = 128-column blocks.  Per block the critical path is potf2 -> trsm; the in-panel
-  // update of the columns to the right runs on its own stream (S3) beside the NEXT block's
-  // potf2, which folds the update of its own diagonal tile in (role 3 skips that tile).
-  hipStream_t S3 = ctx->update_stream;
-  // `head_done`: the first block's potf2 was already issued by the caller.
+  // Panel = 128-column blocks (panel_chain above).  `head_done`: the first block's potf2 was
+  // already issued by the caller.
   auto potf2_at = [&](hipStream_t st, int64_t j0, bool pend) -> int {
-    return launch_potf2<T>(ctx, st, A + j0 * ld + j0, ld, dinv + (j0 / TILE) * 2048, ctx->d_info,
-                           (int32_t)j0, pend ? (const T*)(A + (j0 - TILE) * ld + j0) : (const T*)nullptr,
-                           ld);
+    return panel_potf2<T>(ctx, st, A, ld, dinv, 0, j0, pend);
   };
-  // `after_blocks` / `mid`: once that many blocks of the panel are final, mid() is called with
-  // ev_d recorded behind the last of them (the caller hangs an early partial update on it).
   auto panel = [&](hipStream_t st, int64_t k0, int64_t kb, bool head_done, int64_t after_blocks,
                    const std::function<int()>& mid) -> int {
-    for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
-      T* Ljj = A + j0 * ld + j0;
-      T* dj = dinv + (j0 / TILE) * 2048;
-      const bool pend = j0 > k0;  // in-panel update from block column j0-128 still in flight
-      if (pend || !head_done) TGP_TRY(potf2_at(st, j0, pend));
-      if (pend) TGP_TRY(st_wait(ctx, st, ctx->ev_e));  // rest of that update
-      const int64_t mb = n - (j0 + TILE);
-      if (mb > 0) TGP_TRY(launch_trsm<T>(ctx, st, mb, Ljj, ld, dj, Ljj + TILE, ld));
-      const int64_t nc = (k0 + kb) - (j0 + TILE);
-      const bool upd = mb > 0 && nc > 0;
-      // one marker behind the trsm serves both side streams (every marker between two
-      // kernels of the chain costs it a few microseconds)
-      if (y != nullptr || upd) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
-      if (upd) {
-        TGP_TRY(st_wait(ctx, S3, ctx->ev_d));
-        TGP_TRY(launch_gemm_nt<T>(ctx, S3, mb, nc, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
-                                  A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, 3));
-        TGP_TRY(ev_record(ctx, ctx->ev_e, S3));
-      }
-      if (y != nullptr) {
-        TGP_TRY(st_wait(ctx, S2, ctx->ev_d));
-        TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, mb, Ljj, ld, dj, y + j0));
-      }
-      if (after_blocks > 0 && upd && j0 + TILE == k0 + after_blocks * TILE) TGP_TRY(mid());
-    }
-    return TGP_OK;
+    return panel_chain<T>(ctx, st, n, A, ld, dinv, 0, k0, kb, head_done, y, after_blocks, mid);
   };
   const std::function<int()> no_mid = []() { return TGP_OK; };
   auto trailing = [&](int64_t m, int64_t nn, int64_t kb, const T* P, T* C, int role) -> int {
@@ -994,6 +1014,9 @@ int tri_inverse_t(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* din
   template int launch_trsm<T>(tgp_ctx*, hipStream_t, int64_t, const T*, int64_t, const T*, T*,   \
                               int64_t);                                                          \
   template int compute_dinv<T>(tgp_ctx*, int64_t, const T*, int64_t, T*);                        \
+  template int panel_potf2<T>(tgp_ctx*, hipStream_t, T*, int64_t, T*, int64_t, int64_t, bool);   \
+  template int panel_chain<T>(tgp_ctx*, hipStream_t, int64_t, T*, int64_t, T*, int64_t, int64_t, \
+                              int64_t, bool, T*, int64_t, const std::function<int()>&);          \
   template int potrf<T>(tgp_ctx*, int64_t, T*, int64_t, T*, int32_t*, T*);                           \
   template int trsv<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, int, T*);                 \
   template int gemv_sub<T>(tgp_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*);                          \

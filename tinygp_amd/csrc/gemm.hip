@@ -62,6 +62,11 @@ struct GemmArgs {
                // the column tile; bit2: A, B upper-triangular (M M^T), k starts at the ROW tile
   int nblk;    // total workgroups
   int skip00;  // small kernel: skip the 2x2 tiles of the first 128x128 diagonal block
+  // Block-cyclic column map (dist.hip): dG > 0 -> C holds this rank's block columns
+  // l = dl0, dl0+1, ... (dnbt tiles wide each, contiguous in C) of a matrix whose block column
+  // l*dG + dr they are; rows of A / B / C are GLOBAL, tm = global row tiles, and local column
+  // tile tj updates rows >= its global column tile only (lower trapezoid per column tile).
+  int dG, dr, dl0, dnbt;
 };
 
 // Linear workgroup id -> (ti, tj).  Tiles are enumerated column by column (tj major) so
@@ -84,6 +89,27 @@ __device__ __forceinline__ void decode_tile(int b, int tm, int tn, int lower, in
   ti = tj + (b - off(t));
 }
 
+// Block-cyclic variant: local block column q (tiles [q*dnbt, (q+1)*dnbt)) starts at global tile
+// g0(q) = ((dl0 + q) * dG + dr) * dnbt and holds sum_s (tm - g0 - s) tiles.  *gt = global column
+// tile (the B operand's row tile and the first row tile of the column).
+template <typename T>
+__device__ __forceinline__ void decode_tile_dist(int b, const GemmArgs<T>& g, int& ti, int& tj, int& gt) {
+  int q = 0, g0 = (g.dl0 * g.dG + g.dr) * g.dnbt;
+  const int step = g.dG * g.dnbt, tri = g.dnbt * (g.dnbt - 1) / 2;
+  for (;;) {
+    const int cnt = g.dnbt * (g.tm - g0) - tri;
+    if (b < cnt) break;
+    b -= cnt;
+    g0 += step;
+    ++q;
+  }
+  int tir, s;
+  decode_tile(b, g.tm - g0, g.dnbt, 1, tir, s);
+  ti = g0 + tir;
+  tj = q * g.dnbt + s;
+  gt = g0 + s;
+}
+
 // ROLE only changes the kernel's name (rocprof separates the trailing update from the rest)
 template <typename T, int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
@@ -102,8 +128,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     const int xcd = bid % nx, idx = bid / nx;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  int ti, tj;
-  decode_tile(bid, g.tm, g.tn, g.lower, ti, tj);
+  int ti, tj, gt;
+  if (g.dG > 0) {
+    decode_tile_dist<T>(bid, g, ti, tj, gt);
+  } else {
+    decode_tile(bid, g.tm, g.tn, g.lower, ti, tj);
+    gt = tj;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1;
@@ -111,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 
   // staging: wave w loads k-rows {w, w+4, w+8, w+12}; a lane loads 2 consecutive rows
   const T* Ag = g.A + i0 + lane * 2;
-  const T* Bg = g.B + j0 + lane * 2;
+  const T* Bg = g.B + int64_t(gt) * BN + lane * 2;
   v2_t ra[BK / 4], rb[BK / 4];
 
   auto load_global = [&](int kt) {
@@ -516,6 +547,7 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   }
   GemmArgs<T> g;
   g.skip00 = 0;
+  g.dG = g.dr = g.dl0 = g.dnbt = 0;
   TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");
   // short-K updates, and (role 4) a latency-bound update with too few big tiles to fill the chip
   if ((((role == 1 || role == 3) && k <= 256) || role == 4) && (mode == 0 || mode == 1)) {
@@ -548,6 +580,38 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
     hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+// Trailing update of a rank's block columns l >= l0 (nloc of them, nb wide) by a panel:
+//   C_loc[i, c] -= sum_k P[i, k] P[col(c), k]   for i >= col(c),
+// with P addressed by GLOBAL row (caller passes the panel pointer minus its first row) and
+// col(c) the global column of local column c under the cyclic map j = l * G + rank.
+template <typename T>
+int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb, int64_t k,
+                        const T* P, int64_t ldp, T* Cloc, int64_t ldc, int G, int rank, int64_t l0,
+                        int64_t nloc) {
+  TGP_ARG_CHECK(n_rows % BM == 0 && nb % BN == 0 && k % BK == 0 && k > 0 && G >= 1 && rank >= 0 &&
+                    rank < G && l0 >= 0,
+                "gemm_nt_dist: bad shape");
+  if (nloc <= 0) return TGP_OK;
+  GemmArgs<T> g;
+  g.skip00 = 0;
+  g.A = P; g.B = P; g.C = Cloc + l0 * nb * ldc;
+  g.lda = ldp; g.ldb = ldp; g.ldc = ldc;
+  g.tm = int(n_rows / BM); g.tn = int(nloc * (nb / BN));
+  g.k = int(k); g.lower = 1; g.mode = 0;
+  g.dG = G; g.dr = rank; g.dl0 = int(l0); g.dnbt = int(nb / BN);
+  int64_t total = 0;
+  for (int64_t q = 0; q < nloc; ++q) {
+    const int64_t g0 = ((l0 + q) * G + rank) * g.dnbt;
+    TGP_ARG_CHECK(g0 + g.dnbt <= g.tm, "gemm_nt_dist: block column outside the matrix");
+    total += int64_t(g.dnbt) * (g.tm - g0) - int64_t(g.dnbt) * (g.dnbt - 1) / 2;
+  }
+  TGP_ARG_CHECK(total < (int64_t(1) << 31), "gemm_nt_dist: too many tiles");
+  g.nblk = int(total);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -596,6 +660,8 @@ int ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops) {
 }
 
 #define TGP_INST(T)                                                                              \
+  template int launch_gemm_nt_dist<T>(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const T*, \
+                                      int64_t, T*, int64_t, int, int, int64_t, int64_t);         \
   template int launch_gemm_nt<T>(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const T*,     \
                                  int64_t, const T*, int64_t, T*, int64_t, int, int, int);
 TGP_INST(float)

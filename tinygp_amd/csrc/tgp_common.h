@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
+#include <mutex>
 #include <vector>
 
 #include "../../include/tgp_hip.h"
@@ -67,6 +69,10 @@ struct tgp_trace_rec {
 
 // One HIP device + stream (+ a high-priority side stream for panel look-ahead).
 struct tgp_ctx {
+  // every extern "C" entry point that takes this context (or a solver built on it) holds this
+  // lock for its whole duration: the scratch below (d_scal, d_work, events, asm_pending) is
+  // shared by all solvers of the context, so two host threads are serialised, not raced
+  std::recursive_mutex mu;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -81,6 +87,7 @@ struct tgp_ctx {
   int64_t lookahead = 1;
   int64_t profile = 0;
   int64_t first_split = 5;  // blocks of a panel after which its share of the next block-column update is issued early (0: off)
+  int64_t keep_grad_buffers = 0;  // tgp_solver_grad keeps its two N^2 work matrices between calls
   int64_t first_small_tiles = 1100;  // look-ahead block-column updates up to this many tiles use 64x64 tiles
   // small device scratch: scal[0..15] doubles, info int
   double* d_scal = nullptr;
@@ -179,12 +186,24 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
                    int role);
 
 template <typename T>
+int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb, int64_t k,
+                        const T* P, int64_t ldp, T* Cloc, int64_t ldc, int G, int rank, int64_t l0,
+                        int64_t nloc);
+
+template <typename T>
 int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_t* info,
                  int32_t pivot_base, const T* Xp = nullptr, int64_t ldx = 0);
 template <typename T>
 int launch_trsm(tgp_ctx* ctx, hipStream_t st, int64_t m, const T* L, int64_t ldl, const T* dinv,
                 T* B, int64_t ldb);
 
+template <typename T>
+int panel_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int64_t pivot_off,
+                int64_t j0, bool pend);
+template <typename T>
+int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* dinv,
+                int64_t pivot_off, int64_t k0, int64_t kb, bool head_done, T* y,
+                int64_t after_blocks, const std::function<int()>& mid);
 template <typename T>
 int launch_trsv_fwd_step(tgp_ctx* ctx, hipStream_t st, int64_t m_below, const T* Ljj, int64_t ld,
                          const T* dj, T* yj);
@@ -207,6 +226,10 @@ template <typename T>
 int launch_sum_log_diag(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, int slot);
 template <typename T>
 int launch_sum_squares(tgp_ctx* ctx, int64_t n, const T* y, int slot);
+template <typename T>
+int launch_sum_log_diag_at(tgp_ctx* ctx, hipStream_t st, int64_t n, const T* L, int64_t ld, double* out);
+template <typename T>
+int launch_sum_squares_at(tgp_ctx* ctx, hipStream_t st, int64_t n, const T* y, double* out);
 template <typename T>
 int launch_row_sumsq(tgp_ctx* ctx, int64_t m, int64_t n, const T* B, int64_t ldb, const T* base,
                      T* out);  // out[i] = base[i] - sum_j B[i,j]^2

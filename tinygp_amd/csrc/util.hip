@@ -140,6 +140,21 @@ int launch_sum_squares(tgp_ctx* ctx, int64_t n, const T* y, int slot) {
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
+// the same two reductions on a given stream into a given device slot (dist.hip)
+template <typename T>
+int launch_sum_log_diag_at(tgp_ctx* ctx, hipStream_t st, int64_t n, const T* L, int64_t ld, double* out) {
+  (void)ctx;
+  hipLaunchKernelGGL((sum_log_diag_kernel<T>), dim3(1), dim3(1024), 0, st, n, L, ld, out);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+template <typename T>
+int launch_sum_squares_at(tgp_ctx* ctx, hipStream_t st, int64_t n, const T* y, double* out) {
+  (void)ctx;
+  hipLaunchKernelGGL((sum_squares_kernel<T>), dim3(1), dim3(1024), 0, st, n, y, out);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
 template <typename T>
 int launch_row_sumsq(tgp_ctx* ctx, int64_t m, int64_t n, const T* B, int64_t ldb, const T* base,
                      T* out) {
@@ -190,6 +205,8 @@ int launch_add_diag(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, const T* diag) {
 #define TGP_INST(T)                                                                             \
   template int launch_sum_log_diag<T>(tgp_ctx*, int64_t, const T*, int64_t, int);               \
   template int launch_sum_squares<T>(tgp_ctx*, int64_t, const T*, int);                         \
+  template int launch_sum_log_diag_at<T>(tgp_ctx*, hipStream_t, int64_t, const T*, int64_t, double*); \
+  template int launch_sum_squares_at<T>(tgp_ctx*, hipStream_t, int64_t, const T*, double*);     \
   template int launch_row_sumsq<T>(tgp_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*);\
   template int launch_trmv_lower<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, T*);        \
   template int launch_extract_lower_rowmajor<T>(tgp_ctx*, int64_t, const T*, int64_t, T*);      \

@@ -1,30 +1,41 @@
-"""1-D block-cyclic column Cholesky across the GPUs of one node (BASELINE config 4).
+"""1-D block-cyclic column Cholesky across the GPUs of one node (BASELINE
+configs 4 and 5): distributed ``log_probability`` and posterior mean of ``condition``.
 
-The reference has no multi-device code at all; this is new design for MI355X + RCCL:
+The reference has no multi-device code at all; this is new design for MI355X + RCCL/xGMI:
 
-* the N x N matrix is split into block columns of width ``nb``; block column ``j`` (rows
-  ``j*nb ..`` only -- the lower part) lives on rank ``j mod G`` as one column-major device
-  buffer.  Cyclic ownership keeps the N^3/3 work balanced to within one block while staying
-  "1-D block-column";
-* step ``k``: the owner factors its panel (diagonal block Cholesky + triangular solve of
-  the rows below, both through the C ABI), the ``(N - k nb) x nb`` panel is **broadcast**
-  (``torch.distributed.broadcast`` = ``ncclBroadcast`` over xGMI), and every rank applies
-  the MFMA trailing update to the block columns it owns;
-* look-ahead: the owner of panel ``k+1`` updates and factors it first and its broadcast is
-  posted asynchronously into the second receive buffer, so the transfer and the next
-  panel's latency hide under the remaining updates of step ``k``;
-* forward solve for ``log_probability``: per block one ``nb``-slice all-reduce of the
-  per-rank partial sums, then the owner solves its diagonal block and folds its block
-  column into its partial sum; two scalar all-reduces finish the job.
+* the N x N matrix is cut into block columns of width ``nb``; block column ``j`` lives on rank
+  ``j mod G`` (cyclic ownership keeps the N^3/3 work balanced to within one block and stays
+  "1-D block-column").  A rank holds its block columns side by side in one column-major device
+  matrix (``csrc/dist.hip``);
+* step ``k``: the owner factors panel ``k`` with the single-GPU panel chain on its priority
+  stream and packs it into a ring slot; the slot is **broadcast** (``torch.distributed.broadcast``
+  = ``ncclBroadcast`` over xGMI); every rank updates its own block columns with ONE MFMA launch
+  over all of them;
+* look-ahead: the owner of panel ``k+1`` updates that block column first and runs its chain
+  beside the big update of step ``k``; the broadcast of panel ``k+1`` is enqueued BEFORE that
+  update, so the transfer hides under it as well (two ring slots);
+* ``log_probability`` needs no other exchange: every rank receives every panel, so the forward
+  substitution of the (replicated) right-hand side and ``sum log L_ii`` run redundantly on each
+  rank straight from the received panels, on a side stream, under the updates;
+* ``condition`` mean (config 5): backward substitution block by block on the owners, each
+  solved ``nb``-slice broadcast to all; then every rank evaluates ``K(X*, X_owned) alpha_owned``
+  (fused, K* never formed) and ONE all-reduce of the (M,) vector finishes the job.
 
-One process per GPU.  The schedule is written against a tiny block-operations interface:
-:class:`HipBlockOps` (the product: device pointers into ``libtgp_hip.so``, on torch's
-current stream so that RCCL orders with it) and, in ``tests/`` only, a NumPy stand-in that
-lets the same schedule run under ``gloo`` on CPUs.
+One process per GPU.  The schedule below is written against a small per-rank operations
+interface: :class:`HipBlockOps` (the product: ``tgp_dist_*`` of ``libtgp_hip.so`` on device
+buffers owned by torch so that RCCL can send them) and, in ``tests/`` only, a NumPy stand-in
+that lets the same schedule run under ``gloo`` on CPUs.
+
+Stream contract with RCCL (``torch.distributed`` makes a collective wait for the CURRENT
+stream at call time, and ``work.wait()`` makes the current stream wait for the collective):
+the owner issues the broadcast under the PANEL stream (behind the pack), the receivers
+under the MAIN stream (behind the last reader of that ring slot), everyone waits under the
+MAIN stream.
 """
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 
@@ -34,9 +45,11 @@ from tinygp_amd import _ffi
 
 __all__ = ["HipBlockOps", "BlockCyclicCholesky"]
 
+MAIN, PANEL = 0, 1
+
 
 class HipBlockOps:
-    """Block operations on CUDA(=HIP) torch tensors through the device-pointer C ABI."""
+    """One rank's device state: a ``tgp_dist`` handle + the torch tensors RCCL sends."""
 
     def __init__(self, device: int):
         import torch
@@ -44,109 +57,123 @@ class HipBlockOps:
         self.torch = torch
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        # One dedicated torch stream carries BOTH the HIP kernels (the C ABI launches on the
-        # raw hipStream_t) and, through `context()`, the RCCL collectives torch enqueues, so
-        # broadcasts order against the panel factorisation / trailing updates.
-        self.stream = torch.cuda.Stream(device=self.device)
-        self.ctx = _ffi.Ctx(device=device, stream=self.stream.cuda_stream)
+        self.ctx = _ffi.Ctx(device=device)
         self.lib = _ffi.lib()
+        self.h = None
 
-    def context(self):
-        return self.torch.cuda.stream(self.stream)
+    # -- set-up ------------------------------------------------------------------------
+    def setup(self, P: np.ndarray, noise_diag: np.ndarray, nb: int, world: int, rank: int):
+        torch, lib = self.torch, self.lib
+        n, d = P.shape
+        self.dtype = P.dtype
+        self.nb, self.n = nb, n
+        tdt = torch.float64 if P.dtype == np.float64 else torch.float32
+        nslot = lib.tgp_dist_slot_elems(n, nb)
+        self.nd = (nb // 128) * 2048
+        self.npad = -(-n // nb) * nb
+        self.ring = [torch.empty(nslot, dtype=tdt, device=self.device) for _ in range(2)]
+        self.x = torch.zeros(self.npad, dtype=tdt, device=self.device)
+        torch.cuda.synchronize(self.device)
+        h = C.c_void_p()
+        _ffi.check(lib.tgp_dist_create(self.ctx.handle, _ffi.dtype_code(P.dtype), n, d, _ffi.ptr(P),
+                                       _ffi.ptr(noise_diag), nb, world, rank,
+                                       C.c_void_p(self.ring[0].data_ptr()),
+                                       C.c_void_p(self.ring[1].data_ptr()),
+                                       C.c_void_p(self.x.data_ptr()), C.byref(h)), "tgp_dist_create")
+        self.h = h
+        self.streams = []
+        for which in (MAIN, PANEL):
+            s = C.c_void_p()
+            _ffi.check(lib.tgp_dist_stream(h, which, C.byref(s)), "tgp_dist_stream")
+            self.streams.append(torch.cuda.ExternalStream(s.value, device=self.device))
 
-    # -- buffers ---------------------------------------------------------------------
-    def empty(self, nelem: int, dtype):
-        return self.torch.empty(int(nelem), dtype=self._tdtype(dtype), device=self.device)
+    def stream(self, which: int):
+        """Context manager: collectives issued inside order against that stream of the driver."""
+        return self.torch.cuda.stream(self.streams[which])
 
-    def zeros(self, nelem: int, dtype):
-        return self.torch.zeros(int(nelem), dtype=self._tdtype(dtype), device=self.device)
+    def slot(self, k: int, rows: int):
+        """The broadcast buffer of panel k: [dinv | rows x nb panel]."""
+        return self.ring[k & 1][: self.nd + rows * self.nb]
 
-    def from_numpy(self, a: np.ndarray):
-        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+    def x_slice(self, k: int):
+        return self.x[k * self.nb:(k + 1) * self.nb]
 
-    def _tdtype(self, dtype):
-        return self.torch.float64 if np.dtype(dtype) == np.float64 else self.torch.float32
+    def scalar(self, v: float):
+        return self.torch.tensor([v], dtype=self.torch.float64, device=self.device)
 
-    @staticmethod
-    def _p(t, offset_elems: int = 0):
-        return C.c_void_p(t.data_ptr() + offset_elems * t.element_size())
+    def empty_vec(self, m: int):
+        return self.torch.empty(m, dtype=self.x.dtype, device=self.device)
 
-    def _code(self, t):
-        return _ffi.F64 if t.element_size() == 8 else _ffi.F32
-
-    # -- block kernels ---------------------------------------------------------------
-    def assemble(self, prog, X, diag, n, d, j0, nb, out, rows):
-        """out (rows x nb, ld = rows) = K[j0:, j0:j0+nb] + noise on the diagonal, identity padding."""
+    # -- per-step calls (all asynchronous) ---------------------------------------------------
+    def assemble(self, prog):
         kp, nops = _ffi.as_kprog(prog)
-        n1 = max(n - j0, 0)
-        n2 = max(min(nb, n - j0), 0)
-        _ffi.check(self.lib.tgp_kmat(self.ctx.handle, self._code(out), kp, nops, n1, n2, d,
-                                     self._p(X, min(j0, n) * d), self._p(X, min(j0, n) * d),
-                                     self._p(diag, min(j0, n)), self._p(out), rows, rows, nb, 0),
-                   "tgp_kmat")
+        _ffi.check(self.lib.tgp_dist_assemble(self.h, kp, nops), "tgp_dist_assemble")
 
-    def factor_panel(self, P, rows, nb) -> int:
-        """Diagonal nb x nb block -> L_kk in place, rows below -> P L_kk^-T.  Returns potrf info."""
-        info = C.c_int32()
-        _ffi.check(self.lib.tgp_potrf(self.ctx.handle, self._code(P), nb, self._p(P), rows,
-                                      C.byref(info)), "tgp_potrf")
-        if rows > nb:
-            _ffi.check(self.lib.tgp_trsm_right_lt(self.ctx.handle, self._code(P), rows - nb, nb,
-                                                  self._p(P), rows, self._p(P, nb), rows),
-                       "tgp_trsm_right_lt")
-        return int(info.value)
+    def begin(self, resid):
+        _ffi.check(self.lib.tgp_dist_begin(self.h, _ffi.ptr(resid)), "tgp_dist_begin")
 
-    def update(self, P, prow, off, Cj, crow, nb):
-        """C_j (crow x nb) -= P[off:, :] P[off:off+nb, :]^T on the lower trapezoid (MFMA)."""
-        _ffi.check(self.lib.tgp_gemm_nt(self.ctx.handle, self._code(P), crow, nb, nb, -1.0,
-                                        self._p(P, off), prow, self._p(P, off), prow, 1.0,
-                                        self._p(Cj), crow, 1), "tgp_gemm_nt")
+    def first_panel(self):
+        _ffi.check(self.lib.tgp_dist_first_panel(self.h), "tgp_dist_first_panel")
 
-    def solve_diag(self, P, rows, nb, t):
-        """t <- L_kk^-1 t for the nb x nb diagonal block at the top of the panel."""
-        _ffi.check(self.lib.tgp_trsv(self.ctx.handle, self._code(P), nb, self._p(P), rows, 0,
-                                     self._p(t)), "tgp_trsv")
+    def after_recv(self, k: int):
+        _ffi.check(self.lib.tgp_dist_after_recv(self.h, k), "tgp_dist_after_recv")
 
-    def gemv_sub(self, P, rows, nb, x, w_below):
-        """w_below (rows - nb) -= P[nb:, :] x."""
-        if rows > nb:
-            _ffi.check(self.lib.tgp_gemv_sub(self.ctx.handle, self._code(P), rows - nb, nb,
-                                             self._p(P, nb), rows, self._p(x), self._p(w_below)),
-                       "tgp_gemv_sub")
+    def rest(self, k: int):
+        _ffi.check(self.lib.tgp_dist_rest(self.h, k), "tgp_dist_rest")
 
-    def sum_log_diag(self, P, rows, nb, nvalid) -> float:
-        out = C.c_double()
-        _ffi.check(self.lib.tgp_sum_log_diag(self.ctx.handle, self._code(P), nvalid, self._p(P),
-                                             rows, C.byref(out)), "tgp_sum_log_diag")
-        return out.value
+    def end(self):
+        info, ss, ld = C.c_int32(), C.c_double(), C.c_double()
+        _ffi.check(self.lib.tgp_dist_end(self.h, C.byref(info), C.byref(ss), C.byref(ld)), "tgp_dist_end")
+        return int(info.value), ss.value, ld.value
 
-    def sum_squares(self, x, nvalid) -> float:
-        out = C.c_double()
-        _ffi.check(self.lib.tgp_sum_squares(self.ctx.handle, self._code(x), nvalid, self._p(x),
-                                            C.byref(out)), "tgp_sum_squares")
-        return out.value
+    def bwd_step(self, k: int):
+        _ffi.check(self.lib.tgp_dist_bwd_step(self.h, k), "tgp_dist_bwd_step")
+
+    def cond_mean_partial(self, prog, Pt: np.ndarray):
+        kp, nops = _ffi.as_kprog(prog)
+        out = self.empty_vec(Pt.shape[0])
+        _ffi.check(self.lib.tgp_dist_cond_mean_partial(self.h, kp, nops, Pt.shape[0], _ffi.ptr(Pt),
+                                                       C.c_void_p(out.data_ptr())),
+                   "tgp_dist_cond_mean_partial")
+        return out
+
+    def column(self, l: int, rows: int) -> np.ndarray:
+        out = np.empty((self.nb, rows), dtype=self.dtype)  # column-major (rows x nb)
+        _ffi.check(self.lib.tgp_dist_get_column(self.h, l, _ffi.ptr(out)), "tgp_dist_get_column")
+        return out.T
+
+    def close(self):
+        if self.h is not None:
+            self.lib.tgp_dist_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class BlockCyclicCholesky:
-    """Distributed ``log_probability`` of the dense GP (assembly + Cholesky + forward solve).
+    """Distributed dense GP: ``log_probability`` and the posterior mean of ``condition``.
 
     Args:
         kernel: a :mod:`tinygp_amd.kernels` tree.
         X: (N,) or (N, D) coordinates, replicated on every rank (<= a few MB).
-        noise_diag: (N,) noise variances.
+        noise_diag: (N,) noise variances (``noise.Diagonal``, reference noise.py:55-95).
         nb: block-column width (multiple of 128).
-        ops: block operations (default :class:`HipBlockOps` on ``LOCAL_RANK``).
+        ops: per-rank operations (default :class:`HipBlockOps` on ``LOCAL_RANK``).
         group: ``torch.distributed`` process group (default: the world).
     """
 
-    def __init__(self, kernel, X, noise_diag, *, nb: int = 512, ops=None, group=None, dist=None):
+    def __init__(self, kernel, X, noise_diag, *, nb: int = 1024, ops=None, group=None, dist=None):
         if dist is None:
             import torch.distributed as dist
         self.dist, self.group = dist, group
         self.rank = dist.get_rank(group)
         self.G = dist.get_world_size(group)
-        if nb % 128:
-            raise ValueError("nb must be a multiple of 128")
+        if nb % 128 or nb <= 0:
+            raise ValueError("nb must be a positive multiple of 128")
         X = np.asarray(X)
         P = np.ascontiguousarray(X[:, None] if X.ndim == 1 else X)
         self.dtype = np.dtype(np.float32 if P.dtype == np.float32 else np.float64)
@@ -155,25 +182,19 @@ class BlockCyclicCholesky:
         self.nb = nb
         self.nblk = math.ceil(self.n / nb)
         self.npad = self.nblk * nb
+        self.kernel = kernel
         self.prog = kernel.program()
         if ops is None:
             import os
 
             ops = HipBlockOps(int(os.environ.get("LOCAL_RANK", "0")))
         self.ops = ops
-        with ops.context():
-            self._alloc(P, noise_diag)
-
-    def _alloc(self, P, noise_diag):
-        ops, nb = self.ops, self.nb
-        self.X = ops.from_numpy(P.reshape(-1))
-        self.diag = ops.from_numpy(np.ascontiguousarray(np.broadcast_to(noise_diag, (self.n,)),
-                                                        dtype=self.dtype))
         self.owned = [j for j in range(self.nblk) if j % self.G == self.rank]
-        self.cols = {j: ops.empty(self.rows(j) * nb, self.dtype) for j in self.owned}
-        self.recv = [ops.empty(self.npad * nb, self.dtype) for _ in range(2)]
+        diag = np.ascontiguousarray(np.broadcast_to(noise_diag, (self.n,)), dtype=self.dtype)
+        ops.setup(P, diag, nb, self.G, self.rank)
         self.info = 0
-        self.factored = False
+        self.factored = self.solved = self.have_alpha = False
+        self.bytes_received = 0  # panel bytes this rank received in the last factorisation
 
     def rows(self, j: int) -> int:
         return self.npad - j * self.nb
@@ -181,100 +202,86 @@ class BlockCyclicCholesky:
     def owner(self, j: int) -> int:
         return j % self.G
 
-    def _global_rank(self, r: int) -> int:
+    def _src(self, r: int) -> int:
         return r if self.group is None else self.dist.get_global_rank(self.group, r)
 
-    # -- assembly + factorisation -------------------------------------------------------
-    def assemble(self, kernel=None):
-        with self.ops.context():
-            self._assemble(kernel)
+    # -- the schedule -----------------------------------------------------------------------
+    def _bcast_panel(self, k: int):
+        own = self.owner(k) == self.rank
+        buf = self.ops.slot(k, self.rows(k))
+        if not own:
+            self.bytes_received += buf.numel() * buf.element_size()
+        with self.ops.stream(PANEL if own else MAIN):
+            return self.dist.broadcast(buf, src=self._src(self.owner(k)), group=self.group, async_op=True)
 
-    def factor(self):
-        with self.ops.context():
-            return self._factor()
-
-    def log_probability(self, resid) -> float:
-        """``-0.5 |L^-1 r|^2 - sum log L_ii - n/2 log(2 pi)``; ``-inf`` when not finite."""
-        with self.ops.context():
-            return self._log_probability(resid)
-
-    def _assemble(self, kernel=None):
+    def factor(self, resid=None, kernel=None) -> int:
+        """Assemble K + noise and factor it; with ``resid`` (= y - mean) also ``L^-1 resid``,
+        panel by panel as the panels arrive.  Returns the potrf info agreed by all ranks."""
         if kernel is not None:
-            self.prog = kernel.program()
-        for j in self.owned:
-            self.ops.assemble(self.prog, self.X, self.diag, self.n, self.d, j * self.nb, self.nb,
-                              self.cols[j], self.rows(j))
-        self.factored = False
-
-    def _panel(self, k):
-        """The buffer holding panel k on this rank (own column or receive buffer)."""
-        if self.owner(k) == self.rank:
-            return self.cols[k]
-        return self.recv[k % 2][: self.rows(k) * self.nb]
-
-    def _factor_own(self, k):
-        info = self.ops.factor_panel(self.cols[k], self.rows(k), self.nb)
-        if info > 0 and self.info == 0:
-            self.info = k * self.nb + info
-
-    def _bcast(self, k):
-        return self.dist.broadcast(self._panel(k), src=self._global_rank(self.owner(k)),
-                                   group=self.group, async_op=True)
-
-    def _factor(self):
-        nb, ops = self.nb, self.ops
-        self.info = 0
-        if self.owner(0) == self.rank:
-            self._factor_own(0)
-        work = self._bcast(0)
+            self.kernel, self.prog = kernel, kernel.program()
+        ops = self.ops
+        r = None
+        if resid is not None:
+            r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
+        self.bytes_received = 0
+        ops.assemble(self.prog)
+        ops.begin(r)
+        ops.first_panel()
+        work = self._bcast_panel(0)
         for k in range(self.nblk):
-            work.wait()  # panel k has arrived (RCCL: a stream dependency, not a host block)
-            Pk, prow = self._panel(k), self.rows(k)
-            nxt = k + 1
-            if nxt < self.nblk:
-                if self.owner(nxt) == self.rank:  # look-ahead: next panel first
-                    ops.update(Pk, prow, nb, self.cols[nxt], self.rows(nxt), nb)
-                    self._factor_own(nxt)
-                work = self._bcast(nxt)
-            for j in self.owned:
-                if j > nxt:
-                    ops.update(Pk, prow, (j - k) * nb, self.cols[j], self.rows(j), nb)
+            with ops.stream(MAIN):
+                work.wait()  # RCCL: a stream dependency, not a host block
+            ops.after_recv(k)  # fwd-solve step k; owner of k+1: look-ahead update + chain + pack
+            if k + 1 < self.nblk:
+                work = self._bcast_panel(k + 1)  # enqueued before the big update: overlaps it
+            ops.rest(k)
+        info, self._sumsq, self._logdet = ops.end()
         # agree on the first failing pivot (LAPACK convention), 0 if none
-        t = self._scalar_tensor(float(self.info) if self.info else float(2**52))
+        t = ops.scalar(float(info) if info else float(2**52))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         v = float(t.item())
         self.info = 0 if v >= 2**52 else int(v)
-        self.factored = True
+        self.factored, self.solved, self.have_alpha = True, resid is not None, False
         return self.info
 
-    def _scalar_tensor(self, v: float):
-        return self.ops.from_numpy(np.array([v], dtype=np.float64))
-
-    # -- forward solve + reductions -----------------------------------------------------
-    def _log_probability(self, resid) -> float:
-        if not self.factored:
-            self._assemble()
-            self._factor()
-        nb, ops, dist = self.nb, self.ops, self.dist
-        r = np.zeros(self.npad, dtype=self.dtype)
-        r[: self.n] = np.broadcast_to(resid, (self.n,))
-        y = ops.from_numpy(r)
-        w = ops.zeros(self.npad, self.dtype)  # minus this rank's partial sums  -sum_j L[:, j] x_j
-        ss = logdet = 0.0
-        for k in range(self.nblk):
-            sl = w[k * nb:(k + 1) * nb].clone()
-            dist.all_reduce(sl, group=self.group)
-            if self.owner(k) == self.rank:
-                t = y[k * nb:(k + 1) * nb] + sl
-                ops.solve_diag(self.cols[k], self.rows(k), nb, t)
-                ops.gemv_sub(self.cols[k], self.rows(k), nb, t, w[(k + 1) * nb:])
-                nvalid = max(min(nb, self.n - k * nb), 0)
-                ss += ops.sum_squares(t, nvalid)
-                logdet += ops.sum_log_diag(self.cols[k], self.rows(k), nb, nvalid)
-        t2 = self.ops.from_numpy(np.array([ss, logdet], dtype=np.float64))
-        dist.all_reduce(t2, group=self.group)
-        ss, logdet = (float(v) for v in t2.cpu().numpy())
-        ll = -0.5 * ss - (logdet + 0.5 * self.n * math.log(2.0 * math.pi))
+    def log_probability(self, resid, kernel=None) -> float:
+        """``-0.5 |L^-1 r|^2 - sum log L_ii - n/2 log(2 pi)`` (reference gp.py:313-320,
+        solvers/direct.py:61-64); ``-inf`` when not finite (gp.py:316).  One fused pass:
+        assembly, factorisation and forward solve."""
+        self.factor(resid, kernel)
+        ll = -0.5 * self._sumsq - (self._logdet + 0.5 * self.n * math.log(2.0 * math.pi))
         if self.info or not math.isfinite(ll):
             return -math.inf
         return ll
+
+    def alpha(self, resid):
+        """``K^-1 resid`` replicated on every rank (reference gp.py:330-334): the forward solve
+        rode along with the factorisation; the backward substitution walks the block columns
+        from the last to the first, the owner solves its ``nb`` slice and broadcasts it."""
+        if not (self.factored and self.solved):
+            self.factor(resid)
+        if not self.have_alpha:
+            ops = self.ops
+            for k in reversed(range(self.nblk)):
+                ops.bwd_step(k)
+                with ops.stream(MAIN):
+                    self.dist.broadcast(ops.x_slice(k), src=self._src(self.owner(k)), group=self.group)
+            self.have_alpha = True
+        return self.ops.x
+
+    def condition_mean(self, resid, X_test, kernel=None) -> np.ndarray:
+        """Posterior mean ``K(X*, X) K^-1 resid`` at the test points (reference gp.py:353-359 with
+        ``include_mean=False``; add ``mean(X*)`` on the host), identical on every rank."""
+        self.alpha(resid)
+        Xt = np.asarray(X_test)
+        Pt = np.ascontiguousarray(Xt[:, None] if Xt.ndim == 1 else Xt, dtype=self.dtype)
+        if Pt.shape[1] != self.d:
+            raise ValueError("X_test must have the same number of input dimensions as X")
+        prog = self.prog if kernel is None else kernel.program()
+        part = self.ops.cond_mean_partial(prog, Pt)
+        with self.ops.stream(MAIN):
+            self.dist.all_reduce(part, group=self.group)
+        out = part.cpu().numpy()
+        if self.info:
+            out = np.full_like(out, np.nan)
+        return out

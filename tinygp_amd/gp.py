@@ -193,7 +193,7 @@ class GaussianProcess:
 
     def _kernel_matvec(self, kernel, X_out, alpha):
         fused = getattr(self.solver, "conditional_mean", None)
-        if fused is not None and not isinstance(kernel, kernels.Conditioned):
+        if fused is not None:
             return fused(kernel, X_out, alpha)  # X resident on the device
         return kernel.matmul(X_out, self.X, alpha)
 

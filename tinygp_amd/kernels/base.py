@@ -15,7 +15,8 @@ import numpy as np
 
 from tinygp_amd import _device
 
-__all__ = ["Kernel", "Conditioned", "Sum", "Product", "Constant"]
+__all__ = ["Kernel", "Conditioned", "Custom", "Sum", "Product", "Constant", "DotProduct",
+           "Polynomial"]
 
 # op codes of include/tgp_hip.h
 K_CONST, K_EXP, K_EXPSQ, K_M32, K_M52, K_COS, K_ESS, K_RQ, K_ADD, K_MUL = 0, 1, 2, 3, 4, 5, 6, 7, 16, 17
@@ -93,17 +94,55 @@ class Kernel:
             X2 = None
         if X2 is None:
             X2 = X1
-        prog, P1 = self._lower(X1)
-        _, P2 = self._lower(X2)
+        try:
+            prog, P1 = self._lower(X1)
+            _, P2 = self._lower(X2)
+        except NotImplementedError:
+            return np.dot(self._host_matrix(X1, X2), y)  # host-evaluated kernel (see below)
         return _device.kmat_gemv(prog, P1, P2, y)
 
     def __call__(self, X1, X2=None):
         """Reference ``base.py:84-103``: diagonal (N,) when ``X2`` is None, else (N1, N2)."""
-        prog, P1 = self._lower(X1)
+        try:
+            prog, P1 = self._lower(X1)
+            P2 = None if X2 is None else self._lower(X2)[1]
+        except NotImplementedError:
+            return self._host_diag(X1) if X2 is None else self._host_matrix(X1, X2)
         if X2 is None:
             return _device.kdiag(prog, P1)
-        _, P2 = self._lower(X2)
         return _device.kmat(prog, P1, P2)
+
+    # -- host-evaluated kernels ----------------------------------------------------
+    # A kernel that is an arbitrary Python function of a pair of points (`Custom`, a user
+    # subclass that only overrides `evaluate` -- the reference's extension point,
+    # base.py:38-57) cannot run in a HIP kernel.  Its MATRIX is evaluated here on the host and
+    # handed to the solver through the reference's own `covariance=` channel
+    # (solvers/direct.py:44-52); the factorisation and every solve still run on the device.
+    # Stationary trees never come this way: they lower to a device program or raise.
+    def _host_matrix(self, X1, X2):
+        if type(self).evaluate is Kernel.evaluate:
+            raise NotImplementedError(
+                f"{type(self).__name__} has neither a device program nor an evaluate() method")
+        A, B = np.asarray(X1), np.asarray(X2)
+        K = np.asarray([[self.evaluate(a, b) for b in B] for a in A])
+        if K.ndim != 2:
+            raise ValueError(
+                "Invalid kernel shape: "
+                f"expected ndim = 2, got ndim={K.ndim} "
+                "check the dimensions of parameters and custom kernels")
+        return K
+
+    def _host_diag(self, X):
+        if type(self).evaluate is Kernel.evaluate and type(self).evaluate_diag is Kernel.evaluate_diag:
+            raise NotImplementedError(
+                f"{type(self).__name__} has neither a device program nor an evaluate() method")
+        k = np.asarray([self.evaluate_diag(x) for x in np.asarray(X)])
+        if k.ndim != 1:
+            raise ValueError(
+                "Invalid kernel diagonal shape: "
+                f"expected ndim = 1, got ndim={k.ndim} "
+                "check the dimensions of parameters and custom kernels")
+        return k
 
     # -- algebra (reference base.py:105-126) -------------------------------------
     def __add__(self, other: Any) -> "Kernel":
@@ -166,6 +205,12 @@ class Sum(Kernel):
         self.kernel2._slots(out)
         out.append([None, None])
 
+    def _host_matrix(self, X1, X2):  # an operand is host-evaluated: combine the two matrices
+        return self.kernel1(X1, X2) + self.kernel2(X1, X2)
+
+    def _host_diag(self, X):
+        return self.kernel1(X) + self.kernel2(X)
+
     def __repr__(self):
         return f"Sum({self.kernel1!r}, {self.kernel2!r})"
 
@@ -189,6 +234,12 @@ class Product(Kernel):
         self.kernel2._slots(out)
         out.append([None, None])
 
+    def _host_matrix(self, X1, X2):  # an operand is host-evaluated: combine the two matrices
+        return self.kernel1(X1, X2) * self.kernel2(X1, X2)
+
+    def _host_diag(self, X):
+        return self.kernel1(X) * self.kernel2(X)
+
     def __repr__(self):
         return f"Product({self.kernel1!r}, {self.kernel2!r})"
 
@@ -210,6 +261,56 @@ class Constant(Kernel):
 
     def __repr__(self):
         return f"Constant({self.value!r})"
+
+
+class Custom(Kernel):
+    """A kernel given as a Python function of ONE pair of points (reference ``base.py:156-167``).
+    Host-evaluated; see :meth:`Kernel._host_matrix`."""
+
+    def __init__(self, function):
+        self.function = function
+
+    def evaluate(self, X1, X2):
+        return self.function(X1, X2)
+
+
+class DotProduct(Kernel):
+    """``x_i . x_j`` (reference ``base.py:212-228``); host-evaluated (one GEMM)."""
+
+    def evaluate(self, X1, X2):
+        if np.ndim(X1) == 0:
+            return X1 * X2
+        return np.asarray(X1) @ np.asarray(X2)
+
+    def _host_matrix(self, X1, X2):
+        A, B = np.asarray(X1), np.asarray(X2)
+        return np.multiply.outer(A, B) if A.ndim == 1 else A @ B.T
+
+    def _host_diag(self, X):
+        A = np.asarray(X)
+        return A * A if A.ndim == 1 else np.einsum("ij,ij->i", A, A)
+
+
+class Polynomial(Kernel):
+    """``[(x_i / l) . (x_j / l) + sigma^2]^P`` (reference ``base.py:231-256``); host-evaluated."""
+
+    def __init__(self, order, scale=1.0, sigma=0.0):
+        self.order, self.scale, self.sigma = order, scale, sigma
+
+    def evaluate(self, X1, X2):
+        a, b = np.asarray(X1) / self.scale, np.asarray(X2) / self.scale
+        dot = a * b if a.ndim == 0 else a @ b
+        return (dot + np.square(self.sigma)) ** self.order
+
+    def _host_matrix(self, X1, X2):
+        A, B = np.asarray(X1) / self.scale, np.asarray(X2) / self.scale
+        dot = np.multiply.outer(A, B) if A.ndim == 1 else A @ B.T
+        return (dot + np.square(self.sigma)) ** self.order
+
+    def _host_diag(self, X):
+        A = np.asarray(X) / self.scale
+        dot = A * A if A.ndim == 1 else np.einsum("ij,ij->i", A, A)
+        return (dot + np.square(self.sigma)) ** self.order
 
 
 class Conditioned(Kernel):

@@ -63,12 +63,11 @@ class DirectSolver(Solver):
             raise ValueError("the noise model must have one entry per data point")
         self._noise_diag = np.ascontiguousarray(noise_diag, dtype=dt)
 
-        if covariance is None and not isinstance(noise, Diagonal):
-            # e.g. noise.Dense: add on the host, ship through the covariance channel
+        if covariance is None and (self._prog is None or not isinstance(noise, Diagonal)):
+            # noise.Dense, or a host-evaluated kernel (Custom / DotProduct / Conditioned ...):
+            # K + noise is formed on the host exactly like reference direct.py:50-52 and
+            # shipped through the covariance channel; the factorisation runs on the device
             covariance = kernel(X, X) + noise
-        if covariance is None and self._prog is None:
-            raise NotImplementedError(
-                f"{type(kernel).__name__} cannot be assembled on the device; pass covariance=")
         if covariance is not None:
             covariance = np.ascontiguousarray(covariance, dtype=dt)
             if covariance.shape != (self.n, self.n):
@@ -89,23 +88,37 @@ class DirectSolver(Solver):
 
     # -- factorisation -------------------------------------------------------------
     def _set_kernel(self, kernel):
-        if kernel is not None:
-            self.kernel = kernel
-            try:
-                self._prog, Xdev = kernel._lower(self.X)
-                if not np.array_equal(_device.points(Xdev, self.dtype), self._P):
-                    raise ValueError("refactor() cannot change the kernel's input transform: the "
-                                     "transformed coordinates are resident on the device")
-            except NotImplementedError:
-                self._prog = None
-            self._covariance_value = None if self._prog is not None else self._covariance_value
+        """New hyper-parameters.  The host copy of ``K + noise`` (if any) belongs to the OLD
+        kernel: it is dropped when the device can re-assemble the matrix (device program +
+        diagonal noise) and REBUILT on the host otherwise (``noise.Dense``, host-evaluated
+        kernels), so that neither off-diagonal noise nor a stale matrix is ever factored."""
+        if kernel is None:
+            return
+        self.kernel = kernel
+        try:
+            prog, Xdev = kernel._lower(self.X)
+            if not np.array_equal(_device.points(Xdev, self.dtype), self._P):
+                raise ValueError("refactor() cannot change the kernel's input transform: the "
+                                 "transformed coordinates are resident on the device")
+        except NotImplementedError:
+            prog = None
+        self._prog = prog
+        if prog is not None and isinstance(self.noise, Diagonal):
+            self._covariance_value = None
+        else:
+            self._covariance_value = np.ascontiguousarray(kernel(self.X, self.X) + self.noise,
+                                                          dtype=self.dtype)
 
     def refactor(self, kernel=None, *, covariance=None) -> int:
         """(Re-)assemble and (re-)factor in place with new hyper-parameters (same X / noise):
         the optimiser / MCMC step of SURVEY 3.4 without re-uploading anything."""
         self._set_kernel(kernel)
-        if covariance is None:
-            covariance = self._covariance_value
+        if covariance is not None:  # trusted to equal kernel(X, X) + noise (direct.py:44-46)
+            covariance = np.ascontiguousarray(covariance, dtype=self.dtype)
+            if covariance.shape != (self.n, self.n):
+                raise ValueError("covariance must have shape (N, N)")
+            self._covariance_value = covariance
+        covariance = self._covariance_value
         kp, nops = _ffi.as_kprog(self._prog or [])
         info = C.c_int32(0)
         _ffi.check(_ffi.lib().tgp_solver_factor(self._handle, kp, nops if self._prog else 0,
@@ -231,9 +244,27 @@ class DirectSolver(Solver):
             out[:] = np.nan
         return out.reshape(y.shape)
 
+    def _cond_host_kernel(self, kernel, X_test, noise_diag, var_only: bool):
+        """``Kss + noise - A^T A`` for a kernel without a device program (``Conditioned`` --
+        conditioning a conditioned GP, reference gp.py:380-385 -- ``Custom``, ...): the cross
+        covariances come from the kernel's own ``__call__``, the N x M triangular solve runs
+        on the device (reference direct.py:87-95 line by line)."""
+        Xt = self.X if X_test is None else X_test
+        A = self.solve_triangular(np.asarray(kernel(self.X, Xt), dtype=self.dtype))
+        if var_only:
+            out = np.asarray(kernel(Xt), dtype=self.dtype) - np.sum(A * A, axis=0)
+            return out if noise_diag is None else out + noise_diag
+        out = np.asarray(kernel(Xt, Xt), dtype=self.dtype) - A.T @ A
+        if noise_diag is not None:
+            out[np.diag_indices(out.shape[0])] += noise_diag
+        return out
+
     def _cond(self, kernel, X_test, noise_diag, var_only: bool):
         self._ensure_factor()
-        prog = self._lower_like_resident(kernel)
+        try:
+            prog = self._lower_like_resident(kernel)
+        except NotImplementedError:
+            return self._cond_host_kernel(kernel, X_test, noise_diag, var_only)
         kp, nops = _ffi.as_kprog(prog)
         if X_test is None:
             Pt, m = None, self.n
@@ -340,10 +371,14 @@ class DirectSolver(Solver):
 
     def conditional_mean(self, kernel, X_test, alpha):
         """``K(X_test, X) @ alpha`` fused (reference ``gp.py:357`` via ``base.py:68-82``)."""
-        Pt = _device.points(kernel._lower(X_test)[1], self.dtype)
+        try:
+            prog = self._lower_like_resident(kernel)
+            Pt = _device.points(kernel._lower(X_test)[1], self.dtype)
+        except NotImplementedError:  # host-evaluated kernel: its own matmul (base.py:68-82)
+            return np.asarray(kernel.matmul(X_test, self.X, alpha), dtype=self.dtype)
         if Pt.shape[1] != self.d:
             raise ValueError("X_test must have the same number of input dimensions as X")
-        kp, nops = _ffi.as_kprog(self._lower_like_resident(kernel))
+        kp, nops = _ffi.as_kprog(prog)
         a = np.ascontiguousarray(alpha, dtype=self.dtype)
         out = np.empty(Pt.shape[0], dtype=self.dtype)
         if Pt.shape[0]:
