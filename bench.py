@@ -7,15 +7,24 @@ diag on the device, blocked Cholesky in place, forward triangular solve, reducti
 back on the host.  X, the noise diagonal and the residual are resident in HBM before the
 timed region starts.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c2|c1|c3|n<int>]
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c1|c3|c4|n<int>|ref<int>]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards as REPLICAS --
-each rank evaluates its own hyper-parameter point on its own GPU, no data-path collective
-("scaling": "weak"); the only collectives are the timing barrier and the MAX over ranks.
+N = 1 (default): BASELINE config 2 (ExpSquared, 1-D, N = 16 384, fp64) on one GPU through
+`GaussianProcess` / `DirectSolver`'s fused entry point.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): ONE N x N matrix, 1-D block-cyclic
+block columns over the N GPUs with an RCCL panel broadcast per step (BASELINE config 4,
+N = 131 072, "scaling": "strong") -- tinygp_amd/distributed.py.  `--workload` overrides the
+size; `--replicas` selects the other sharding of the path instead (every rank evaluates its
+own hyper-parameter point of config 2, no data-path collective, "scaling": "weak"), which is
+also reported as a secondary entry of the default N > 1 line.  `--distributed` runs the
+block-column path at N = 1 as well (RCCL self-broadcast).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the `roofline` of the
-dominant kernel (fp64 MFMA trailing update, gemm_nt_kernel<double, 0>) measured live with
-HIP events on the launching stream, and a `cpu_baseline` of the NumPy/SciPy oracle.
+dominant kernel (fp64 MFMA trailing update, gemm_nt_kernel<double, 0>) measured live with HIP
+events on the launching stream, `roofline_secondary` (assembly: HBM write; resident-factor
+triangular solve: HBM read) and a `cpu_baseline` of the NumPy/SciPy oracle measured at the
+workload's own N.
 """
 from __future__ import annotations
 
@@ -33,14 +42,14 @@ sys.path.insert(0, str(ROOT))
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet: FP64 matrix = FP64 vector = 78.6 TFLOP/s
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 # HBM bytes per trailing-update launch for workload c2 at the default nb_outer = 1024, from the
-# committed PMC passes (profiles/r01_h_pmc_hbm_traffic_nb1024.md: rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE in separate runs, KB units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM"
-# for wide coalesced reads): (2 x 55.090 GB + 12.634 GB) / 42 launches of gemm_nt_kernel<double,0>.
-# PMC collection serialises kernels, so it cannot run inside the timed region; other
-# configurations report null.
-PMC_TRAFFIC_BYTES_PER_LAUNCH_C2 = (2 * 55.090e9 + 12.634e9) / 42
-PMC_TRAFFIC_NB = 1024
+# committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, KB
+# units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM" for wide coalesced reads).  PMC
+# collection serialises kernels, so it cannot run inside the timed region; configurations
+# other than the one the passes were collected on report null.
+PMC_TRAFFIC = {"file": "profiles/r01_h_pmc_hbm_traffic_nb1024.md",
+               "bytes_per_launch": (2 * 55.090e9 + 12.634e9) / 42, "nb": 1024}
 
 
 def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles: int = 0,
@@ -80,6 +89,21 @@ def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles:
     return total, launches
 
 
+def dist_update_flops(n_pad: int, nb: int, world: int, rank: int):
+    """Algorithmic flops of one rank's trailing updates in the block-cyclic factorisation:
+    for every panel k and every owned block column j > k, the lower trapezoid
+    (rows >= j nb) x nb entries x 2 nb."""
+    nblk = n_pad // nb
+    total = 0.0
+    for k in range(nblk):
+        for j in range(k + 1, nblk):
+            if j % world != rank:
+                continue
+            m = n_pad - j * nb
+            total += 2.0 * nb * (m * nb - nb * (nb - 1) / 2.0)
+    return total
+
+
 def emit(obj):
     """Print the ONE JSON line last: flush C stdio first (RCCL's banner sits in libc's buffer)."""
     import ctypes
@@ -97,17 +121,21 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="c2", help="c1|c2|c3 (BASELINE configs) or n<int>[d<int>]")
+    p.add_argument("--workload", default=None,
+                   help="c1..c4 (BASELINE configs), n<int>[d<int>][f32], ref<int> (reference recipe, "
+                        "docs/benchmarks.ipynb:131-159); default c2 on one GPU, c4 on several")
     p.add_argument("--nb-outer", type=int, default=0, help="override the outer block (0 = default)")
     p.add_argument("--lookahead", type=int, default=-1)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-profile", action="store_true", help="disable per-launch HIP-event timing")
+    p.add_argument("--no-secondary", action="store_true", help="skip the secondary rooflines")
     p.add_argument("--stages", action="store_true", help="also print per-stage times to stderr")
     p.add_argument("--unfused", action="store_true", help="separate factor and solve passes")
     p.add_argument("--distributed", action="store_true",
-                   help="ONE matrix, 1-D block-cyclic columns over the N GPUs with RCCL panel "
-                        "broadcast (strong scaling; BASELINE config 4) instead of replicas")
-    p.add_argument("--nb-dist", type=int, default=1024, help="block-column width of --distributed")
+                   help="block-column path (RCCL panel broadcast) also at --gpus 1")
+    p.add_argument("--replicas", action="store_true",
+                   help="at --gpus N > 1: independent evaluations per rank instead of one matrix")
+    p.add_argument("--nb-dist", type=int, default=1024, help="block-column width of the distributed path")
     return p.parse_args()
 
 
@@ -118,6 +146,9 @@ def workload_spec(name: str):
         c = dict(synthetic.CONFIGS[name])
         c["name"] = name
         return c
+    if name.startswith("ref"):  # the reference's own benchmark recipe
+        return dict(name=name, n=int(name[3:]), d=1, dtype="float64", diag=0.01, kernel="matern32",
+                    inputs="reference")
     if name.startswith("n"):
         body = name[1:]
         dtype = "float64"
@@ -132,91 +163,210 @@ def workload_spec(name: str):
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(spec, rank):
-    """The oracle (SciPy/OpenBLAS LAPACK) on this box's host cores, on a bounded sample:
-    the same workload at N_s <= 8192, extrapolated stage by stage (assembly and trsv ~ N^2,
-    dpotrf ~ N^3) to the workload's N.  Reported, never the target."""
+def workload_text(spec):
+    from tinygp_amd import synthetic
+
+    fp = "fp64" if spec["dtype"] == "float64" else "fp32"
+    inputs = ("x in [0,10] (docs/benchmarks.ipynb:131-159)" if spec.get("inputs") == "reference"
+              else "constant-density synthetic inputs (SURVEY 8d)")
+    return (f"{spec['name']}: {synthetic.kernel_text(spec['kernel'])}, {spec['d']}-D X, N={spec['n']}, {fp}, "
+            f"diag={spec['diag']}, {inputs}")
+
+
+def make_inputs(spec):
+    from tinygp_amd import synthetic
+
+    if spec.get("inputs") == "reference":
+        return synthetic.make_reference_inputs(spec["n"])
+    return synthetic.make_inputs(spec["n"], spec["d"], spec["dtype"])
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(spec, budget_s=45.0):
+    """The oracle (SciPy/OpenBLAS LAPACK: the same library family jaxlib's CPU path calls) on this
+    box's host cores, MEASURED at the workload's own N when that fits the time budget: thread
+    sweep of dpotrf at N_s = min(N, 8192), then one full evaluation (assembly + dpotrf + dtrtrs +
+    reductions) at N with the fastest thread count, plus a 1-thread row at N = 2048 / 4096 to line
+    up with the reference's single-threaded published rows (docs/benchmarks.ipynb:82-85).
+    Reported, never the target."""
     import scipy.linalg as sla
 
     from oracle import tinygp_np as o
     from tinygp_amd import synthetic
 
-    n = spec["n"]
-    ns = min(n, 8192)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    # OpenBLAS with every core of a 2-socket box is far from its best: pick the thread count
-    # that factors a 4096 x 4096 probe fastest and use it for the sample (reported in `cores`).
-    threads, limiter = cores, None
     try:
         from threadpoolctl import threadpool_limits
-
-        rngp = np.random.default_rng(0)
-        Bp = rngp.normal(size=(4096, 512))
-        Kp = Bp @ Bp.T + 4096 * np.eye(4096)
-        best = None
-        for th in sorted({t for t in (8, 16, 32, 64, 128, cores) if t <= cores}):
-            with threadpool_limits(limits=th):
-                tq = time.perf_counter()
-                sla.cholesky(Kp, lower=True, check_finite=False)
-                tq = time.perf_counter() - tq
-            if best is None or tq < best[0]:
-                best = (tq, th)
-        threads = best[1]
-        limiter = threadpool_limits(limits=threads)
-    except Exception:
-        pass
-    X, y = synthetic.make_inputs(ns, spec["d"], spec["dtype"])
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    n = spec["n"]
+    cores = host_cores()
     kern = synthetic.config_kernel(o, spec["kernel"])
-    t0 = time.perf_counter()
-    K = kern(X, X)
-    K[np.diag_indices(ns)] += spec["diag"]
-    t1 = time.perf_counter()
-    L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
-    t2 = time.perf_counter()
-    alpha = sla.solve_triangular(L, y, lower=True, check_finite=False)
-    ll = -0.5 * float(alpha @ alpha) - float(np.sum(np.log(np.diag(L)))) - 0.5 * ns * np.log(2 * np.pi)
-    t3 = time.perf_counter()
-    if limiter is not None:
-        limiter.restore_original_limits()
-    f2, f3 = (n / ns) ** 2, (n / ns) ** 3
-    t_full = (t1 - t0) * f2 + (t2 - t1) * f3 + (t3 - t2) * f2
+    notes = []
+
+    def evaluate(nn, threads):
+        """one full evaluation at size nn; returns (stage seconds, loglik)"""
+        s = dict(spec, n=nn)
+        X, y = make_inputs(s)
+        X, y = X.astype(np.float64), y.astype(np.float64)
+        ctxm = threadpool_limits(limits=threads) if threadpool_limits else None
+        try:
+            t0 = time.perf_counter()
+            K = np.empty((nn, nn))
+            bs = 2048  # blocked assembly: bounded temporaries (the oracle's formulas per block)
+            for i0 in range(0, nn, bs):
+                K[i0:i0 + bs] = kern(X[i0:i0 + bs], X)
+            K[np.diag_indices(nn)] += spec["diag"]
+            t1 = time.perf_counter()
+            L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+            t2 = time.perf_counter()
+            alpha = sla.solve_triangular(L, y, lower=True, check_finite=False)
+            ll = -0.5 * float(alpha @ alpha) - float(np.sum(np.log(np.diag(L)))) - 0.5 * nn * np.log(2 * np.pi)
+            t3 = time.perf_counter()
+        finally:
+            if ctxm is not None:
+                ctxm.restore_original_limits()
+        return (t1 - t0, t2 - t1, t3 - t2), ll
+
+    # 1. thread sweep on dpotrf (OpenBLAS with every core of a big box is far from its best)
+    ns = min(n, 8192)
+    rngp = np.random.default_rng(0)
+    B = rngp.normal(size=(ns, 256))
+    Kp = B @ B.T + ns * np.eye(ns)
+    sweep = {}
+    t_start = time.perf_counter()
+    for th in sorted({t for t in (1, 8, 16, 32, 64, 128, cores) if t <= cores}):
+        if th == 1 and ns > 4096:
+            continue
+        if time.perf_counter() - t_start > 0.5 * budget_s:
+            break
+        lim = threadpool_limits(limits=th) if threadpool_limits else None
+        tq = time.perf_counter()
+        sla.cholesky(Kp, lower=True, check_finite=False)
+        tq = time.perf_counter() - tq
+        if lim is not None:
+            lim.restore_original_limits()
+        sweep[th] = (ns**3 / 3) / tq / 1e9
+    threads = max(sweep, key=sweep.get) if sweep else cores
+    # 2. one full evaluation at the workload's N if the sweep says it fits, else the largest N that does
+    est = (n**3 / 3) / (sweep.get(threads, 30.0) * 1e9) * 1.3 + 4e-9 * n * n
+    n_eval, extrap = n, False
+    while est > budget_s and n_eval > 4096:
+        n_eval //= 2
+        est /= 8
+        extrap = True
+    stages, ll = evaluate(n_eval, threads)
+    t_eval = sum(stages)
+    if extrap:
+        f2, f3 = (n / n_eval) ** 2, (n / n_eval) ** 3
+        t_full = stages[0] * f2 + stages[1] * f3 + stages[2] * f2
+        notes.append(f"N={n} does not fit the {budget_s:.0f} s budget: measured at N={n_eval} and extrapolated "
+                     f"(N^2 / N^3 per stage)")
+    else:
+        t_full = t_eval
+    # 3. the reference's published CPU rows are single-threaded: one measured row at small N
+    one = {}
+    for nn in (2048, 4096):
+        if nn <= n and time.perf_counter() - t_start < 1.6 * budget_s:
+            st, _ = evaluate(nn, 1)
+            one[str(nn)] = {"seconds": sum(st), "potrf_gflops": (nn**3 / 3) / st[1] / 1e9}
     return {
         "value": 1.0 / t_full, "unit": "evals/s", "cores": threads, "kind": "port",
-        "sample": (f"oracle/tinygp_np.py (SciPy dpotrf/dtrtrs, OpenBLAS, {threads} threads = the fastest of "
-                   f"8..{cores} on a 4096^2 dpotrf probe; box has {cores} cores) timed at "
-                   f"N={ns}: assembly {t1 - t0:.2f}s potrf {t2 - t1:.2f}s solve+reduce {t3 - t2:.3f}s"
-                   + ("" if ns == n else f"; extrapolated to N={n} (N^2 / N^3 per stage)")),
-        "potrf_gflops": (ns**3 / 3) / (t2 - t1) / 1e9,
+        "sample": (f"oracle/tinygp_np.py formulas + SciPy dpotrf/dtrtrs (OpenBLAS), one full evaluation "
+                   f"{'MEASURED' if not extrap else 'measured'} at N={n_eval} with {threads} threads (fastest of "
+                   f"{sorted(sweep)} on a {ns}^2 dpotrf sweep; box has {cores} cores): assembly "
+                   f"{stages[0]:.2f}s potrf {stages[1]:.2f}s solve+reduce {stages[2]:.3f}s"
+                   + ("; " + "; ".join(notes) if notes else "")),
+        "potrf_gflops": (n_eval**3 / 3) / stages[1] / 1e9,
+        "thread_sweep_potrf_gflops": {str(k): v for k, v in sweep.items()},
+        "one_thread": one,
         "loglik_sample": ll,
     }
 
 
-def run_distributed(args, spec, X, y, rank, local_rank, world, dist, torch):
-    """Strong scaling: one log_probability of ONE N x N matrix spread over all ranks."""
-    import torch.distributed as tdist
+def secondary_rooflines(ctx, solver, spec, kernel):
+    """Stand-alone timings (outside the timed region) of the two bandwidth-bound kernels of the
+    path against the HBM roofline: kernel-matrix assembly (bytes WRITTEN: s N(N+1)/2)
+    and the forward substitution on a resident factor (bytes READ: s N(N+1)/2)."""
+    import ctypes as C
 
+    from tinygp_amd import _ffi
+
+    lib = _ffi.lib()
+    n, es = spec["n"], np.dtype(spec["dtype"]).itemsize
+    npad = -(-n // 128) * 128
+    out = []
+    Ld, npd = C.c_void_p(), C.c_int64()
+    _ffi.check(lib.tgp_solver_device_factor(solver._handle, C.byref(Ld), C.byref(npd)), "device_factor")
+    # assembly into the solver's own matrix (it is re-factored below before anything reads it)
+    kp, nops = _ffi.as_kprog(kernel.program())
+    X, _ = make_inputs(spec)
+    P = np.ascontiguousarray(X.reshape(n, -1))
+    dX = ctx.upload(P)
+    ddiag = ctx.upload(np.full(n, spec["diag"], dtype=P.dtype))
+    try:
+        def asm():
+            _ffi.check(lib.tgp_kmat(ctx.handle, _ffi.dtype_code(P.dtype), kp, nops, n, n, P.shape[1],
+                                    C.c_void_p(dX), C.c_void_p(dX), C.c_void_p(ddiag), Ld, npad, npad, npad, 1),
+                       "tgp_kmat")
+        asm(); ctx.sync()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            asm()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        nbytes = es * n * (n + 1) / 2
+        out.append({"kernel": "kmat_kernel (assembly of the lower triangle)", "bound": "hbm",
+                    "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "ms": dt * 1e3,
+                    "algorithmic_bytes": nbytes, "note": "bytes written; host-timed over 5 launches"})
+    finally:
+        ctx.free(dX), ctx.free(ddiag)
+    # resident-factor log_probability = forward substitution + reductions
+    solver.refactor()
+    res = C.c_double()
+    _ffi.check(lib.tgp_solver_logprob(solver._handle, None, C.byref(res)), "tgp_solver_logprob")
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        _ffi.check(lib.tgp_solver_logprob(solver._handle, None, C.byref(res)), "tgp_solver_logprob")
+    dt = (time.perf_counter() - t0) / reps
+    nbytes = es * n * (n + 1) / 2
+    out.append({"kernel": "trsv (log_probability on a resident factor: forward substitution + reductions)",
+                "bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "ms": dt * 1e3, "algorithmic_bytes": nbytes,
+                "note": "bytes read; host-timed, includes the scalar D2H"})
+    return out
+
+
+def metric_name(spec):
+    fp = "fp64" if spec["dtype"] == "float64" else "fp32"
+    return f"GP log_probability evals/sec + Cholesky TFLOP/s ({fp}), N={spec['n']:,}"
+
+
+def run_distributed(args, spec, rank, local_rank, world, torch, tdist, replicas_value=None):
+    """Strong scaling: log_probability of ONE N x N matrix spread over all ranks."""
     from tinygp_amd import kernels, synthetic
     from tinygp_amd.distributed import BlockCyclicCholesky, HipBlockOps
 
-    if dist is None:  # single rank still goes through RCCL (self-broadcast)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    X, y = make_inputs(spec)
     n = spec["n"]
     dt = np.dtype(spec["dtype"])
     kern = synthetic.config_kernel(kernels, spec["kernel"])
-    solver = BlockCyclicCholesky(kern, X, np.full(n, spec["diag"], dtype=dt), nb=args.nb_dist,
+    nb = args.nb_dist
+    solver = BlockCyclicCholesky(kern, X, np.full(n, spec["diag"], dtype=dt), nb=nb,
                                  ops=HipBlockOps(local_rank), dist=tdist)
 
     def one_step(step):
         u = ((step * 7) % 11 - 5) / 5.0
-        solver.assemble(synthetic.config_kernel(kernels, spec["kernel"], amp=1.5 * (1 + 0.02 * u),
-                                                scale=2.5 * (1 + 0.03 * u)))
-        solver.factor()
-        ll = solver.log_probability(y)
+        ll = solver.log_probability(y, kernel=synthetic.config_kernel(
+            kernels, spec["kernel"], amp=1.5 * (1 + 0.02 * u), scale=2.5 * (1 + 0.03 * u)))
         if not np.isfinite(ll):
             raise SystemExit(f"numerical failure in the distributed bench step (info={solver.info})")
         return ll
@@ -237,51 +387,37 @@ def run_distributed(args, spec, X, y, rank, local_rank, world, dist, torch):
     elapsed = float(t.item())
     result = None
     if rank == 0:
-        flops = n**3 / 3.0
-        result = ({
-            "metric": f"GP log_probability evals/sec + Cholesky TFLOP/s ({'fp64' if dt == np.float64 else 'fp32'}), N={n:,}",
-            "value": args.steps / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64" if dt == np.float64 else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{spec['name']}: {spec['kernel']} kernel, {spec['d']}-D X, N={n}, "
-                                   "1-D block-cyclic column Cholesky, RCCL panel broadcast",
-                       "n": n, "nb": args.nb_dist, "parallelism": f"block-cyclic columns x{world}"},
-            "aggregate_cholesky_tflops": flops * args.steps / elapsed / 1e12,
-            "roofline": None, "cpu_baseline": None})
-    tdist.barrier()
-    tdist.destroy_process_group()
-    if result is not None:
-        emit(result)
+        peak = FP64_MFMA_PEAK_TFLOPS if dt == np.float64 else FP32_MFMA_PEAK_TFLOPS
+        per_eval = elapsed / args.steps
+        npad = solver.npad
+        upd = dist_update_flops(npad, nb, world, rank)
+        result = {
+            "metric": metric_name(spec), "value": args.steps / elapsed, "unit": "evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_eval * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if dt == np.float64 else "f32", "data": "synthetic",
+            "config": {"workload": workload_text(spec) + "; ONE matrix, 1-D block-cyclic block columns, "
+                                   "RCCL panel broadcast over xGMI, replicated forward solve",
+                       "n": n, "nb": nb, "parallelism": f"block-cyclic columns x{world}"},
+            "aggregate_cholesky_tflops": (n**3 / 3.0) / per_eval / 1e12,
+            # whole-evaluation rate of rank 0's share of the trailing updates against one GPU's peak:
+            # a lower bound of the update kernel's own rate (chains, broadcasts and the tail included)
+            "roofline": {"kernel": "gemm_nt_kernel (block-cyclic trailing update, rank 0's share)",
+                         "bound": "mfma", "achieved": upd / per_eval / 1e12, "peak": peak, "unit": "TFLOP/s",
+                         "frac": upd / per_eval / 1e12 / peak, "traffic": None,
+                         "note": "rank 0's algorithmic update flops / whole evaluation time (not kernel time)"},
+            "panel_broadcast_bytes_received_per_rank": solver.bytes_received,
+            "panel_broadcast_GBps_per_rank_avg": solver.bytes_received / per_eval / 1e9,
+            "replicas": replicas_value,
+            "cpu_baseline": None,
+        }
+    return result
 
 
-def main():
-    args = parse_args()
-    os.environ.setdefault("NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
-    import torch
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False "
-                         "(tinygp_amd has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
-
+def run_single(args, spec, rank, local_rank, world, torch, dist):
     from tinygp_amd import _ffi, kernels, noise, synthetic
     from tinygp_amd.solvers import DirectSolver
 
-    spec = workload_spec(args.workload)
     n, d = spec["n"], spec["d"]
     dt = np.dtype(spec["dtype"])
     ctx = _ffi.Ctx(device=local_rank)
@@ -290,19 +426,12 @@ def main():
     if args.lookahead >= 0:
         ctx.set_option("lookahead", args.lookahead)
     ctx.set_option("profile", 0 if args.no_profile else 1)
-    nb_used = ctx.set_option("nb_outer", 512)
-    ctx.set_option("nb_outer", nb_used)
-    la_used = ctx.set_option("lookahead", 1)
-    ctx.set_option("lookahead", la_used)
-    fst_used = ctx.set_option("first_small_tiles", 0)
-    ctx.set_option("first_small_tiles", fst_used)
-    fsp_used = ctx.set_option("first_split", 0)
-    ctx.set_option("first_split", fsp_used)
+    opt = {}
+    for key in ("nb_outer", "lookahead", "first_small_tiles", "first_split"):
+        opt[key] = ctx.set_option(key, 128 if key == "nb_outer" else 0)
+        ctx.set_option(key, opt[key])
 
-    X, y = synthetic.make_inputs(n, d, spec["dtype"])
-
-    if args.distributed:
-        return run_distributed(args, spec, X, y, rank, local_rank, world, dist, torch)
+    X, y = make_inputs(spec)
 
     def kernel_at(step):
         # a different hyper-parameter point per step and per rank (replicas), like an
@@ -355,62 +484,115 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * args.steps / elapsed
-        peak = FP64_MFMA_PEAK_TFLOPS if dt == np.float64 else FP32_MFMA_PEAK_TFLOPS
-        roofline = None
-        extra = {}
-        if not args.no_profile and acc["syrk_ms"] > 0:
-            n_pad = -(-n // 128) * 128
-            alg_bytes, alg_launches = trailing_update_bytes(n_pad, int(nb_used), np.dtype(dt).itemsize,
-                                                             int(fst_used), int(fsp_used))
-            achieved = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12
-            launches = max(acc["syrk_launches"], 1.0)
-            roofline = {
-                "kernel": f"gemm_nt_kernel<{'double' if dt == np.float64 else 'float'}, 0> (Cholesky trailing update)",
-                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak,
-                "traffic": (PMC_TRAFFIC_BYTES_PER_LAUNCH_C2
-                            if (args.workload == "c2" and nb_used == PMC_TRAFFIC_NB and world == 1
-                                and la_used == 1 and fst_used == 1100 and fsp_used == 5) else None),
-                "traffic_unit": "bytes/launch (PMC, profiles/r01_h_pmc_hbm_traffic_nb1024.md)",
-                "algorithmic_bytes_per_launch": alg_bytes / max(alg_launches, 1),
-                "avg_launch_ms": acc["syrk_ms"] / launches,
-                "flops_per_launch": acc["syrk_flops"] / launches,
-                "launches_per_step": launches / args.steps,
-            }
-            potrf_tf = (n**3 / 3.0) / (acc["potrf_ms"] / args.steps * 1e-3) / 1e12
-            extra = {"cholesky_tflops": potrf_tf,
-                     "stage_ms": {"assembly": acc["assembly_ms"] / args.steps,
-                                  "potrf": acc["potrf_ms"] / args.steps,
-                                  "trailing_update_kernels": acc["syrk_ms"] / args.steps,
-                                  "trsv+reduce": acc["trsv_ms"] / args.steps}}
-            if args.stages:
-                print(json.dumps(extra, indent=1), file=sys.stderr)
-        out = {
-            "metric": f"GP log_probability evals/sec + Cholesky TFLOP/s ({'fp64' if dt == np.float64 else 'fp32'}), N={n:,}",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if dt == np.float64 else "f32", "data": "synthetic",
-            "config": {"workload": (f"{spec['name']}: {spec['kernel']} kernel, {d}-D X, N={n}, "
-                                    f"{'fp64' if dt == np.float64 else 'fp32'}, dense Cholesky + tri-solve"),
-                       "n": n, "d": d, "diag": spec["diag"],
-                       "parallelism": f"replicas x{world} (one evaluation stream per GPU, no data-path collective)" if world > 1 else "single",
-                       "nb_outer": int(nb_used)},
-            "roofline": roofline,
+    if rank != 0:
+        return None
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+    peak = FP64_MFMA_PEAK_TFLOPS if dt == np.float64 else FP32_MFMA_PEAK_TFLOPS
+    roofline = None
+    extra = {}
+    if not args.no_profile and acc["syrk_ms"] > 0:
+        n_pad = -(-n // 128) * 128
+        alg_bytes, alg_launches = trailing_update_bytes(n_pad, int(opt["nb_outer"]), np.dtype(dt).itemsize,
+                                                         int(opt["first_small_tiles"]), int(opt["first_split"]))
+        achieved = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12
+        launches = max(acc["syrk_launches"], 1.0)
+        default_cfg = (spec["name"] == "c2" and opt["nb_outer"] == PMC_TRAFFIC["nb"] and world == 1
+                       and opt["lookahead"] == 1 and opt["first_small_tiles"] == 1100 and opt["first_split"] == 5)
+        roofline = {
+            "kernel": f"gemm_nt_kernel<{'double' if dt == np.float64 else 'float'}, 0> (Cholesky trailing update)",
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak,
+            "traffic": PMC_TRAFFIC["bytes_per_launch"] if default_cfg else None,
+            "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {PMC_TRAFFIC['file']})",
+            "algorithmic_bytes_per_launch": alg_bytes / max(alg_launches, 1),
+            "avg_launch_ms": acc["syrk_ms"] / launches,
+            "flops_per_launch": acc["syrk_flops"] / launches,
+            "launches_per_step": launches / args.steps,
         }
-        out.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, rank)
-        else:
-            out["cpu_baseline"] = None
+        potrf_tf = (n**3 / 3.0) / (acc["potrf_ms"] / args.steps * 1e-3) / 1e12
+        extra = {"cholesky_tflops": potrf_tf,
+                 "stage_ms": {"assembly": acc["assembly_ms"] / args.steps,
+                              "potrf": acc["potrf_ms"] / args.steps,
+                              "trailing_update_kernels": acc["syrk_ms"] / args.steps,
+                              "trsv+reduce": acc["trsv_ms"] / args.steps}}
+        if args.stages:
+            print(json.dumps(extra, indent=1), file=sys.stderr)
+    out = {
+        "metric": metric_name(spec),
+        "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64" if dt == np.float64 else "f32", "data": "synthetic",
+        "config": {"workload": workload_text(spec) + ", dense Cholesky + tri-solve",
+                   "n": n, "d": d, "diag": spec["diag"],
+                   "parallelism": (f"replicas x{world} (one evaluation stream per GPU, no data-path collective)"
+                                   if world > 1 else "single"),
+                   "nb_outer": int(opt["nb_outer"])},
+        "roofline": roofline,
+    }
+    out.update(extra)
+    if world == 1 and not args.no_secondary:
+        ctx.set_option("profile", 0)
+        try:
+            out["roofline_secondary"] = secondary_rooflines(ctx, solver, spec, kernel_at(-1))
+        except Exception as e:  # never lose the headline line to a secondary measurement
+            out["roofline_secondary"] = {"error": repr(e)}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(spec)
+    else:
+        out["cpu_baseline"] = None
+    return out
+
+
+def main():
+    args = parse_args()
+    os.environ.setdefault("NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False "
+                         "(tinygp_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    block_column = (world > 1 and not args.replicas) or args.distributed
+    dist = None
+    if world > 1 or block_column:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world > 1:
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:  # a single rank still goes through RCCL (self-broadcast)
+            dist_mod.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    out = None
+    if block_column:
+        replicas_value = None
+        if world > 1 and not args.workload:
+            # the other sharding of the path, as a secondary entry: config 2 replicas
+            a2 = argparse.Namespace(**vars(args))
+            a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_secondary = 5, 2, True, True
+            r = run_single(a2, workload_spec("c2"), rank, local_rank, world, torch, dist)
+            if r is not None:
+                replicas_value = {"value": r["value"], "unit": "evals/s", "scaling": "weak",
+                                  "workload": r["config"]["workload"], "ms_per_step": r["ms_per_step"]}
+        spec = workload_spec(args.workload or ("c4" if world > 1 else "c2"))
+        out = run_distributed(args, spec, rank, local_rank, world, torch, dist, replicas_value)
+    else:
+        spec = workload_spec(args.workload or "c2")
+        out = run_single(args, spec, rank, local_rank, world, torch, dist if world > 1 else None)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
+    if rank == 0 and out is not None:
         emit(out)
 
 

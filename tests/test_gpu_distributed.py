@@ -1,7 +1,8 @@
-"""The block-cyclic driver with the REAL block operations (HipBlockOps: torch CUDA buffers,
-C ABI on a torch stream, RCCL collectives) on the one GPU a test box has: world size 1, so
-every panel is 'broadcast' to itself.  Multi-rank schedule logic is covered on CPU under
-gloo (tests/test_distributed_cpu.py); 8-GPU runs are the driver's."""
+"""The block-cyclic driver with the REAL per-rank operations (HipBlockOps: csrc/dist.hip through
+the C ABI, torch CUDA buffers for the ring slots, RCCL collectives ordered against the driver's
+streams) on the one GPU a test box has: world size 1, so every panel is 'broadcast' to itself
+and every collective still goes through RCCL.  Multi-rank schedule logic is covered on CPU
+under gloo (tests/test_distributed_cpu.py); 8-GPU runs are the driver's."""
 import os
 
 import numpy as np
@@ -26,18 +27,90 @@ def pg():
     dist.destroy_process_group()
 
 
+def _k(mod):
+    return 1.5**2 * mod.ExpSquared(2.5) + 0.3 * mod.Matern32(1.2)
+
+
 @pytest.mark.parametrize("n,nb,dtype,rtol", [(2000, 256, np.float64, 1e-8), (3000, 512, np.float64, 1e-8),
-                                              (1500, 128, np.float32, 5e-4)])
+                                              (5000, 1024, np.float64, 1e-8), (1500, 128, np.float32, 5e-4)])
 def test_block_cyclic_hip_single_rank(pg, n, nb, dtype, rtol):
     from tinygp_amd import kernels
     from tinygp_amd.distributed import BlockCyclicCholesky
 
     X, y = _cases.synthetic.make_inputs(n, 1)
     diag = 0.01 if dtype == np.float64 else 0.1
-    k = 1.5**2 * kernels.ExpSquared(2.5) + 0.3 * kernels.Matern32(1.2)
-    s = BlockCyclicCholesky(k, X.astype(dtype), np.full(n, diag, dtype=dtype), nb=nb, dist=pg)
+    s = BlockCyclicCholesky(_k(kernels), X.astype(dtype), np.full(n, diag, dtype=dtype), nb=nb, dist=pg)
     got = s.log_probability(y.astype(dtype))
-    want = float(o.GaussianProcess(1.5**2 * o.ExpSquared(2.5) + 0.3 * o.Matern32(1.2), X,
-                                   diag=diag).log_probability(y))
+    ref = o.GaussianProcess(_k(o), X, diag=diag)
     assert s.info == 0
-    np.testing.assert_allclose(got, want, rtol=rtol)
+    np.testing.assert_allclose(got, float(ref.log_probability(y)), rtol=rtol)
+    # the factor itself, block column by block column (lower part), against LAPACK
+    if dtype == np.float64:
+        L = ref.solver.scale_tril
+        for l in range(len(s.owned)):
+            j0 = s.owned[l] * nb
+            col = s.ops.column(l, s.rows(s.owned[l]))  # (rows, nb)
+            rows = min(n - j0, col.shape[0])
+            cols = min(nb, n - j0)
+            idx = np.tril_indices(rows, 0, cols)
+            np.testing.assert_allclose(col[:rows, :cols][idx], L[j0:j0 + rows, j0:j0 + cols][idx],
+                                       rtol=1e-9, atol=1e-9)
+    # posterior mean at test points: backward solve + fused K(X*, X_owned) alpha + all-reduce
+    xt = np.linspace(X[0], X[-1], 53)
+    tol = dict(rtol=5e-7, atol=5e-7) if dtype == np.float64 else dict(rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(s.condition_mean(y.astype(dtype), xt.astype(dtype)), ref.predict(y, xt), **tol)
+    # the optimiser step: new hyper-parameters, same buffers
+    got2 = s.log_probability(y.astype(dtype), kernel=1.1 * _k(kernels))
+    np.testing.assert_allclose(got2, float(o.GaussianProcess(1.1 * _k(o), X, diag=diag).log_probability(y)), rtol=rtol)
+
+
+def test_block_cyclic_bad_pivot_and_determinism(pg):
+    from tinygp_amd import kernels
+    from tinygp_amd.distributed import BlockCyclicCholesky
+
+    n, nb = 4096, 512
+    X, y = _cases.synthetic.make_inputs(n, 1)
+    diag = np.full(n, 0.01)
+    s = BlockCyclicCholesky(_k(kernels), X, diag, nb=nb, dist=pg)
+    vals = {s.log_probability(y) for _ in range(5)}
+    assert len(vals) == 1  # fixed reduction orders, event-ordered streams: bit-identical
+    diag[3000] = -5.0
+    s = BlockCyclicCholesky(_k(kernels), X, diag, nb=nb, dist=pg)
+    assert s.log_probability(y) == -np.inf and s.info == 3001
+    assert np.all(np.isnan(s.condition_mean(y, X[:4])))
+
+
+def test_block_cyclic_matches_single_gpu_driver_n16384(pg):
+    """Same inputs through both drivers: the block-column path (nb = 1024, RCCL self-broadcast)
+    and the single-GPU fused path agree to 1e-10 relative at BASELINE config 2's size."""
+    from tinygp_amd import GaussianProcess, kernels
+    from tinygp_amd.distributed import BlockCyclicCholesky
+
+    X, y, c = _cases.data_config("c2")
+    k = _cases.synthetic.config_kernel(kernels, c["kernel"])
+    s = BlockCyclicCholesky(k, X, np.full(len(X), c["diag"]), nb=1024, dist=pg)
+    got = s.log_probability(y)
+    want = float(GaussianProcess(k, X, diag=c["diag"]).log_probability(y))
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    xt = np.linspace(X[0], X[-1], 200)
+    np.testing.assert_allclose(s.condition_mean(y, xt), GaussianProcess(k, X, diag=c["diag"]).predict(y, xt),
+                               rtol=5e-7, atol=5e-7)
+
+
+def test_config5_distributed_condition_mean_fp32(pg, golden_dir):
+    """BASELINE config 5 through the block-column path (world size 1 here): fp32, config 5's
+    kernel, N = 32 768, posterior mean at 4 096 test points vs the fp64 oracle at 5e-4."""
+    from tinygp_amd import kernels
+    from tinygp_amd.distributed import BlockCyclicCholesky
+
+    big = np.load(golden_dir / "large.npz")
+    n, m = 32768, 4096
+    X, y = _cases.synthetic.make_inputs(n, 1, "float32")
+    xt = np.linspace(0.0, n / 100.0, m).astype(np.float32)
+    s = BlockCyclicCholesky(_cases.synthetic.config_kernel(kernels, "sum"), X, np.full(n, 0.1, np.float32),
+                            nb=1024, dist=pg)
+    mean = s.condition_mean(y, xt)
+    assert s.info == 0 and mean.dtype == np.float32
+    np.testing.assert_allclose(mean, big[f"c5_n{n}__test_loc"], rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(-0.5 * s._sumsq - s._logdet - 0.5 * n * np.log(2 * np.pi),
+                               big[f"c5_n{n}__logp"], rtol=5e-4)

@@ -459,18 +459,44 @@ def test_sample_shapes_and_moments_like_test_gp():
     np.testing.assert_allclose(np.cov(y, rowvar=False), gp.covariance, atol=0.015)
 
 
-def test_config3_n65536_full_size_properties():
-    """BASELINE config 3 at full size (Matern-5/2, 3-D, N = 65 536, fp64; 34 GB factor): no
-    CPU oracle finishes in seconds here, so the factor is checked through the properties that
-    define it -- L^-T L^-1 (K z) = z with K z from the fused kernel mat-vec (never touches the
-    factor) -- plus finiteness of the fused log-probability."""
+def test_config3_n65536_full_size(golden_dir):
+    """BASELINE config 3 at full size (Matern-5/2 / L2, 3-D, N = 65 536, fp64; 34 GB factor):
+    the log-likelihood against the LAPACK oracle's value at the same size (computed once on the
+    host, tests/golden/make_golden_large.py; north-star tolerance 1e-8 relative), and the
+    properties that define the factor -- L^-T L^-1 (K z) = z with K z from the fused kernel
+    mat-vec, which never touches the factor."""
+    big = np.load(golden_dir / "large.npz")
     X, y, c = _cases.data_config("c3")
     k = _cases.synthetic.config_kernel(kernels, c["kernel"])
     gp = GaussianProcess(k, X, diag=c["diag"])
     ll = float(gp.log_probability(y))
     assert gp.solver.info == 0 and np.isfinite(ll)
+    np.testing.assert_allclose(ll, big["c3_n65536__logp"], rtol=LL_RTOL)
+    np.testing.assert_allclose(gp.solver.normalization(), big["c3_n65536__norm"], rtol=LL_RTOL)
     _factor_property_checks(gp, X, k, c["diag"], 3)
     assert abs(float(gp.solver.log_probability(y)) - ll) <= 1e-9 * abs(ll)  # fused == unfused
+    alpha = gp.solver.solve_triangular(y)
+    np.testing.assert_allclose(alpha[:16], big["c3_n65536__alpha_head"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(alpha[-16:], big["c3_n65536__alpha_tail"], rtol=1e-6, atol=1e-8)
+
+
+def test_config5_kernel_fp32_posterior_mean_n32768(golden_dir):
+    """BASELINE config 5's path at a single-GPU size: Sum(ExpSquared, Matern32), fp32,
+    N = 32 768, condition() posterior mean at M = 4 096 test points, against the fp64 LAPACK
+    oracle (tests/golden/make_golden_large.py) at the reference's fp32 tolerance 5e-4
+    (src/tinygp/test_utils.py:15)."""
+    big = np.load(golden_dir / "large.npz")
+    n, m = 32768, 4096
+    X, y = _cases.synthetic.make_inputs(n, 1, "float32")
+    xt = np.linspace(0.0, n / 100.0, m).astype(np.float32)
+    gp = GaussianProcess(_cases.synthetic.config_kernel(kernels, "sum"), X, diag=np.float32(0.1))
+    assert gp.dtype == np.float32
+    c = gp.condition(y, xt)
+    assert gp.solver.info == 0 and c.gp.loc.dtype == np.float32
+    np.testing.assert_allclose(c.gp.loc, big[f"c5_n{n}__test_loc"], rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(c.log_probability, big[f"c5_n{n}__logp"], rtol=5e-4)
+    v = c.gp.variance  # posterior variance without the M x M matrix (north-star parity list)
+    assert v.shape == (m,) and np.all(np.isfinite(v)) and np.all(v > 0) and np.all(v < 2.6)
 
 
 def test_transforms_like_test_transforms():

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["make_inputs", "CONFIGS", "config_kernel"]
+__all__ = ["make_inputs", "make_reference_inputs", "CONFIGS", "config_kernel", "kernel_text"]
 
 SEED = 49382  # the reference benchmark's seed (docs/benchmarks.ipynb:135)
 
@@ -34,6 +34,28 @@ def make_inputs(n: int, d: int = 1, dtype="float64", seed: int = SEED):
         x0 = X[:, 0]
     y = np.sin(x0) + 0.1 * rng.normal(0.0, 1.0, n)
     return X.astype(dtype), y.astype(dtype)
+
+
+def make_reference_inputs(n: int, seed: int = SEED):
+    """The reference's own benchmark recipe (docs/benchmarks.ipynb:131-159): 100 000 sorted points
+    in [0, 10], y = sin x + 0.1 N(0, 1), the first n of them; used with 1.5^2 Matern32(2.5),
+    diag = 0.01 (published rows: N <= 20 000)."""
+    rng = np.random.default_rng(seed)
+    x = np.sort(rng.uniform(0, 10, 100_000))
+    y = np.sin(x) + 0.1 * rng.normal(size=len(x))
+    return x[:n].copy(), y[:n].copy()
+
+
+def kernel_text(spec: str) -> str:
+    """Human-readable definition of a config kernel (goes into bench.py's `config.workload`)."""
+    return {
+        "expsq": "1.5^2 ExpSquared(2.5)",
+        "matern52": "1.5^2 Matern52(2.5, distance=L2Distance) [the reference's default L1 metric is "
+                    "indefinite in 3-D: DESIGN.md 5]",
+        "matern52_l1": "1.5^2 Matern52(2.5) [default L1 metric]",
+        "matern32": "1.5^2 Matern32(2.5)",
+        "sum": "1.5^2 ExpSquared(2.5) + 0.5^2 Matern32(1.0)",
+    }[spec]
 
 
 def config_kernel(kernels_module, spec: str, amp: float = 1.5, scale: float = 2.5):
