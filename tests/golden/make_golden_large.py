@@ -37,11 +37,22 @@ def assemble(kern, X, diag, bs=1024):
     return K
 
 
-def factor_inplace(K):
-    c, info = lapack.dpotrf(K, lower=1, overwrite_a=1, clean=0)
-    assert info == 0, info
-    assert np.shares_memory(c, K)
-    return c
+def factor_inplace(K, bs=4096):
+    """Right-looking blocked Cholesky in place (lower), LAPACK dpotrf on the diagonal blocks,
+    dtrsm / dgemm for the rest.  (One dpotrf call on the whole matrix segfaults inside the
+    bundled OpenBLAS at N = 32 768 in this container.)"""
+    n = K.shape[0]
+    for k0 in range(0, n, bs):
+        k1 = min(k0 + bs, n)
+        c, info = lapack.dpotrf(np.array(K[k0:k1, k0:k1], order="F"), lower=1, clean=1)
+        assert info == 0, (k0, info)
+        K[k0:k1, k0:k1] = c
+        if k1 < n:
+            K[k1:, k0:k1] = sla.solve_triangular(c, K[k1:, k0:k1].T, lower=True, check_finite=False).T
+            for j0 in range(k1, n, bs):
+                j1 = min(j0 + bs, n)
+                K[j0:, j0:j1] -= K[j0:, k0:k1] @ K[j0:j1, k0:k1].T
+    return K
 
 
 def config3():

@@ -112,7 +112,7 @@ int factor_and_pack(tgp_dist* h, int64_t k, bool head_done) {
   // the slot's previous panel) precedes the chain and the pack
   TGP_HIP_TRY(hipEventRecord(ctx->ev_a, S0));
   TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
-  const std::function<int()> no_mid = []() { return TGP_OK; };
+  const std::function<int(hipEvent_t)> no_mid = [](hipEvent_t) { return TGP_OK; };
   TGP_TRY(panel_chain<T>(ctx, S1, rows, Ap, ld, dk, k * h->nb, 0, h->nb, head_done, (T*)nullptr, 0, no_mid));
   T* slot = (T*)h->ring[k & 1];
   const int64_t nd = slot_dinv_elems(h);
