@@ -260,16 +260,16 @@ int tgp_solver_timings(tgp_solver* s, double* ms, int n);
  * is also where the order of calls per step is documented.  Every call is asynchronous on the
  * context's streams except tgp_dist_end / tgp_dist_cond_mean_partial / tgp_dist_get_column.
  *
- * ring0/ring1 (tgp_dist_slot_elems(n, nb) elements each) and x (n_pad = ceil(n/nb)*nb elements)
+ * ring0..ring2 (tgp_dist_slot_elems(n, nb) elements each) and x (n_pad = ceil(n/nb)*nb elements)
  * are device buffers of the CALLER (torch tensors, so that torch.distributed can send them):
- *   ring slot of panel k = ring[k & 1] = [(nb/128)*2048 inverse 16x16 diagonal blocks |
+ *   ring slot of panel k = ring[k % 3] = [(nb/128)*2048 inverse 16x16 diagonal blocks |
  *                                         (n_pad - k nb) x nb panel, column-major, ld = rows]
  *   x: the replicated right-hand side: residual -> L^-1 r (after tgp_dist_end) -> K^-1 r. */
 typedef struct tgp_dist tgp_dist;
 int64_t tgp_dist_slot_elems(int64_t n, int64_t nb);
 int tgp_dist_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X_host,
                     const void* noise_diag_host, int64_t nb, int32_t world, int32_t rank,
-                    void* ring0_dev, void* ring1_dev, void* x_dev, tgp_dist** out);
+                    void* ring0_dev, void* ring1_dev, void* ring2_dev, void* x_dev, tgp_dist** out);
 int tgp_dist_destroy(tgp_dist* h);
 /* hipStream_t of the context: which = 0 main (updates), 1 panel (chain + pack); the host makes
  * its RCCL calls wait on / be waited on by these */

@@ -26,7 +26,7 @@ class NumpyBlockOps:
         self.nloc = len(range(rank, self.nblk, world))
         self.nd = (nb // 128) * 2048
         tdt = torch.float64 if P.dtype == np.float64 else torch.float32
-        self.ring = [torch.zeros(self.nd + self.npad * nb, dtype=tdt) for _ in range(2)]
+        self.ring = [torch.zeros(self.nd + self.npad * nb, dtype=tdt) for _ in range(3)]
         self.x = torch.zeros(self.npad, dtype=tdt)
         self.xn = self.x.numpy()  # shares memory
         self.A = np.zeros((self.npad, max(self.nloc, 1) * nb), dtype=P.dtype, order="F")
@@ -36,7 +36,7 @@ class NumpyBlockOps:
         return contextlib.nullcontext()
 
     def slot(self, k, rows):
-        return self.ring[k & 1][: self.nd + rows * self.nb]
+        return self.ring[k % 3][: self.nd + rows * self.nb]
 
     def x_slice(self, k):
         return self.x[k * self.nb:(k + 1) * self.nb]
@@ -46,7 +46,7 @@ class NumpyBlockOps:
 
     def _panel_view(self, k):
         rows = self.npad - k * self.nb
-        return self.ring[k & 1].numpy()[self.nd: self.nd + rows * self.nb].reshape((rows, self.nb), order="F")
+        return self.ring[k % 3].numpy()[self.nd: self.nd + rows * self.nb].reshape((rows, self.nb), order="F")
 
     def _col(self, l):
         return self.A[:, l * self.nb:(l + 1) * self.nb]

@@ -176,3 +176,37 @@ def test_trsm_right_lt_vs_lapack():
         got = ll.trsm_right_lt(L, B)
         want = sla.solve_triangular(L, B.T, lower=True).T
         np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-10 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("n,dtype", [(100, np.float64), (300, np.float64), (1100, np.float64), (5000, np.float64),
+                                     (16384, np.float64), (3000, np.float32)])
+def test_streaming_forward_solve_matches_lapack_and_the_stepwise_path(n, dtype):
+    """The single-launch forward substitution (one workgroup per row block, data-tagged
+    hand-off of the solved blocks, explicit inverses of the 128 x 128 diagonal blocks) against
+    LAPACK dtrtrs and against the one-launch-pair-per-block path, and bit-reproducible."""
+    from tinygp_amd import GaussianProcess, _ffi
+
+    X, y = _cases.synthetic.make_inputs(n, 1)
+    k = _cases.synthetic.config_kernel(kernels, "expsq")
+    diag = 0.01 if dtype == np.float64 else 0.1
+    gp = GaussianProcess(k, X.astype(dtype), diag=dtype(diag))
+    s = gp.solver
+    L = s.scale_tril.astype(np.float64)
+    want = sla.solve_triangular(L, y.astype(dtype).astype(np.float64), lower=True, check_finite=False)
+    ctx = _ffi.default_ctx()
+    got = {}
+    for mode in (1, 0):
+        old = ctx.set_option("stream_trsv", mode)
+        try:
+            got[mode] = s.solve_triangular(y.astype(dtype))
+            lp = float(s.log_probability(y.astype(dtype)))
+            again = [s.solve_triangular(y.astype(dtype)) for _ in range(3)]
+        finally:
+            ctx.set_option("stream_trsv", old)
+        assert all(np.array_equal(a, got[mode]) for a in again)
+        tol = 1e-9 if dtype == np.float64 else 2e-3
+        scale = np.max(np.abs(want))
+        assert np.max(np.abs(got[mode] - want)) <= tol * scale, (mode, np.max(np.abs(got[mode] - want)) / scale)
+        ref = -0.5 * want @ want - np.sum(np.log(np.diag(L))) - 0.5 * n * np.log(2 * np.pi)
+        np.testing.assert_allclose(lp, ref, rtol=1e-9 if dtype == np.float64 else 5e-4)
+    np.testing.assert_allclose(got[1], got[0], rtol=0, atol=(1e-10 if dtype == np.float64 else 1e-3) * np.max(np.abs(want)))

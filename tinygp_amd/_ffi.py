@@ -99,7 +99,7 @@ SIGNATURES = {
     "tgp_trace_factor": [_i64, _i64, _i64, _i64, _i64, _i32, _pi64, _i64, _pi64],
     "tgp_trace_factor_ex": [_i64, _i64, _i64, _i64, _i64, _i32, _i64, _pi64, _i64, _pi64],
     "tgp_dist_slot_elems": [_i64, _i64],
-    "tgp_dist_create": [_vp, _int, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _pvp],
+    "tgp_dist_create": [_vp, _int, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _pvp],
     "tgp_dist_destroy": [_vp],
     "tgp_dist_stream": [_vp, _int, _pvp],
     "tgp_dist_assemble": [_vp, _pkop, _int],

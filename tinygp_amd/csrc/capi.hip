@@ -60,6 +60,8 @@ struct tgp_solver {
   void* scratch = nullptr;  // per-solver workspace (multi-RHS / conditional products)
   void* Minv = nullptr;     // L^-T (gradient path), npad x npad, allocated on first use
   void* Kinv = nullptr;     // K^-1 lower tiles (gradient path)
+  void* winv = nullptr;     // inverses of the 128 x 128 diagonal blocks (streaming forward solve), lazy
+  bool winv_valid = false;
   size_t scratch_bytes = 0;
   KProg kp{};
   bool has_prog = false, factored = false, has_resid = false;
@@ -105,6 +107,16 @@ static int assemble_lower(tgp_ctx* ctx, const tgp::KProg& kp, int64_t n, int d, 
     TGP_TRY(ev_record(ctx, ctx->ev_asm, ctx->asm_stream));
     ctx->asm_pending = true;
   }
+  return TGP_OK;
+}
+
+// W_b = L_bb^-1 of every diagonal block, once per factorisation, on first use
+template <typename T>
+static int ensure_winv(tgp_solver* s) {
+  if (s->winv_valid) return TGP_OK;
+  if (!s->winv) TGP_HIP_TRY(hipMalloc(&s->winv, size_t(s->npad / TILE) * 16384 * sizeof(T)));
+  TGP_TRY(compute_winv<T>(s->ctx, s->npad, (const T*)s->A, s->npad, (T*)s->winv));
+  s->winv_valid = true;
   return TGP_OK;
 }
 
@@ -218,6 +230,7 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "first_small_tiles")) slot = &ctx->first_small_tiles;
   else if (!strcmp(key, "keep_grad_buffers")) slot = &ctx->keep_grad_buffers;
   else if (!strcmp(key, "reserve_cus")) slot = &ctx->reserve_cus;
+  else if (!strcmp(key, "stream_trsv")) slot = &ctx->stream_trsv;
   else if (!strcmp(key, "trsm_split")) slot = &ctx->trsm_split;
   else if (!strcmp(key, "epi_atomic")) slot = &ctx->epi_atomic;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
@@ -454,7 +467,7 @@ int tgp_solver_destroy(tgp_solver* s) {
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
   }
-  void* bufs[] = {s->X, s->diag, s->A, s->dinv, s->vec, s->vec2, s->resid, s->scratch, s->Minv, s->Kinv};
+  void* bufs[] = {s->X, s->diag, s->A, s->dinv, s->vec, s->vec2, s->resid, s->scratch, s->Minv, s->Kinv, s->winv};
   for (void* b : bufs)
     if (b) hipFree(b);
   delete s;
@@ -515,6 +528,7 @@ static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void*
     s->has_prog = false;
   }
   TGP_ARG_CHECK(s->has_prog || cov_host != nullptr, "factor needs a kernel program or a covariance");
+  s->winv_valid = false;
   const size_t es = esize(s->dtype);
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   const bool prof = ctx->profile != 0;
@@ -614,7 +628,12 @@ int tgp_solver_solve_tri(tgp_solver* s, int transpose, int64_t nrhs, const void*
     const T* L = (const T*)s->A;
     if (nrhs == 1) {
       TGP_TRY(upload_vec(s, s->vec, y_host));
-      TGP_TRY(trsv<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, transpose, (T*)s->vec));
+      const T* winv = nullptr;
+      if (!transpose && ctx->stream_trsv != 0 && s->info == 0) {
+        TGP_TRY(ensure_winv<T>(s));
+        winv = (const T*)s->winv;
+      }
+      TGP_TRY(trsv<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, transpose, (T*)s->vec, winv));
       TGP_HIP_TRY(hipMemcpyAsync(x_host, s->vec, size_t(s->n) * es, hipMemcpyDeviceToHost, ctx->stream));
       TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
       return TGP_OK;
@@ -714,7 +733,12 @@ static int logprob_device(tgp_solver* s, const void* resid_host, double* out) {
   }
   TGP_TRY(dispatch(s->dtype, [&](auto tag) {
     using T = decltype(tag);
-    TGP_TRY(trsv<T>(ctx, s->npad, (const T*)s->A, s->npad, (const T*)s->dinv, 0, (T*)s->vec));
+    const T* winv = nullptr;
+    if (ctx->stream_trsv != 0 && s->info == 0) {
+      TGP_TRY(ensure_winv<T>(s));
+      winv = (const T*)s->winv;
+    }
+    TGP_TRY(trsv<T>(ctx, s->npad, (const T*)s->A, s->npad, (const T*)s->dinv, 0, (T*)s->vec, winv));
     return launch_sum_squares<T>(ctx, s->n, (const T*)s->vec, 0);
   }));
   if (prof) TGP_HIP_TRY(hipEventRecord(e1, ctx->stream));

@@ -404,6 +404,9 @@ template <typename T, bool FOLD>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) void potf2_solo_kernel(
     T* __restrict__ A, int64_t ld, T* __restrict__ dinv, int32_t* __restrict__ info,
     int32_t pivot_base, const T* __restrict__ Xp, int64_t ldx) {
+  // the body needs ~132 VGPRs; the allocation must be >= 144 so that two of these waves and a
+  // 240-VGPR GEMM wave do NOT fit in a SIMD's 512: naming v150 pins the count
+  asm volatile("; potf2_solo: register budget marker" ::: "v150");
   potf2_body<T, FOLD>(A, ld, dinv, info, pivot_base, Xp, ldx);
 }
 
@@ -517,26 +520,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
 // ---------------------------------------------------------------------------------------
 // trsv (single right-hand side): per 128-block, one diagonal solve + one panel update.
 // ---------------------------------------------------------------------------------------
-// forward: y_kb <- L_kk^-1 y_kb.  128 threads, thread r owns row r.
+// forward: y_kb <- L_kk^-1 y_kb.  128 threads, thread r owns row r.  The row's entries of the
+// 16-column strip that the NEXT sub-step needs are fetched while the current one runs (two 16-
+// entry buffers instead of the whole 112-entry row: ~110 VGPRs, so the kernel fits on a SIMD
+// beside a trailing-update wave -- with the whole row in registers it needed a CU without any
+// MFMA tile and waited milliseconds for one during large factorisations).
 template <typename T>
-__global__ __launch_bounds__(128, 1) void trsv_diag_fwd_kernel(const T* __restrict__ Lkk,
-                                                               int64_t ld,
-                                                               const T* __restrict__ dinv,
-                                                               T* __restrict__ y) {
+__global__ __launch_bounds__(128) void trsv_diag_fwd_kernel(const T* __restrict__ Lkk,
+                                                            int64_t ld,
+                                                            const T* __restrict__ dinv,
+                                                            T* __restrict__ y) {
   __shared__ T st[128];
   __shared__ T sx[16];
   const int r = threadIdx.x, rb = r >> 4, rl = r & 15;
-  T Lr[7][16];
-#pragma unroll
-  for (int jb = 0; jb < 7; ++jb)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) Lr[jb][q] = (rb > jb) ? Lkk[int64_t(jb * 16 + q) * ld + r] : T(0);
   T di[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) di[q] = dinv[rb * 256 + q * 16 + rl];
+  T cur[16], nxt[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) cur[q] = (rb > 0) ? Lkk[int64_t(q) * ld + r] : T(0);
   T t = y[r];
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
+    if (jb + 1 < 7) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        nxt[q] = (rb > jb + 1) ? Lkk[int64_t((jb + 1) * 16 + q) * ld + r] : T(0);
+    }
     st[r] = t;
     __syncthreads();
     if (rb == jb) {
@@ -550,8 +560,10 @@ __global__ __launch_bounds__(128, 1) void trsv_diag_fwd_kernel(const T* __restri
     if (jb < 7) {
       if (rb > jb) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t -= Lr[jb][q] * sx[q];
+        for (int q = 0; q < 16; ++q) t -= cur[q] * sx[q];
       }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
     }
   }
   y[r] = t;
@@ -646,6 +658,190 @@ __global__ __launch_bounds__(256) void trsv_update_bwd_kernel(int64_t ncols,
   acc += __shfl_xor(acc, 2);
   acc += __shfl_xor(acc, 4);
   if (part == 0 && c0 + cl < ncols) y[c0 + cl] -= acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// Forward substitution on a resident factor in ONE launch (replaces nblk x 2 dependent launches).
+//
+// Workgroup (ticket) b owns row block b: it streams the tiles (b, 0..b-1) of L -- every load of
+// a wave is 1 KiB of one column, 32 in flight per lane, double-buffered over tiles, none of
+// them depending on the solution -- and multiplies them with the solved blocks x_c as those
+// appear.  x is its own "ready" signal: the output vector starts filled with a sentinel NaN
+// and every entry is published with ONE naturally aligned device-scope (sc1) store and polled
+// with device-scope loads (MI355X_MICROARCH.md, "data-tagged granule"): no flag, no fence.
+// Tickets are handed out in dispatch order, so a workgroup only ever waits for workgroups that
+// are already running.  The diagonal block is applied as W_b = L_bb^-1 (winv_kernel) -- two
+// 128 x 128 matrix-vector products on the critical path per block instead of eight dependent
+// 16-column sub-steps.  All reductions have a fixed order: bit-reproducible.
+// ---------------------------------------------------------------------------------------
+template <typename T> struct Sent;
+template <> struct Sent<double> {
+  using bits_t = unsigned long long;
+  static constexpr bits_t value = 0xFFF8DEADBEEF5A5AULL;  // a quiet NaN no computation produces
+};
+template <> struct Sent<float> {
+  using bits_t = unsigned int;
+  static constexpr bits_t value = 0xFFC5A5A5u;
+};
+template <typename T>
+__device__ __forceinline__ typename Sent<T>::bits_t load_x_bits(const T* p) {
+  return __hip_atomic_load(reinterpret_cast<const typename Sent<T>::bits_t*>(p), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T bits_to(typename Sent<T>::bits_t b) {
+  T v;
+  __builtin_memcpy(&v, &b, sizeof(T));
+  return v;
+}
+
+// tmp <- y, y <- sentinel, ticket <- 0
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_prep_kernel(int64_t n, T* __restrict__ y, T* __restrict__ tmp,
+                                                        int32_t* __restrict__ ticket) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i == 0) *ticket = 0;
+  if (i < n) {
+    tmp[i] = y[i];
+    y[i] = bits_to<T>(Sent<T>::value);
+  }
+}
+
+// W_b = L_bb^-1 for every 128 x 128 diagonal block (column-major 128 x 128 each, zeros above the
+// diagonal): column c of W by forward substitution, one thread per column, L and W packed in LDS.
+template <typename T>
+__global__ __launch_bounds__(128) void winv_kernel(const T* __restrict__ L, int64_t ld, T* __restrict__ winv) {
+  __shared__ T Lp[8256];
+  __shared__ T Wp[8256];
+  const int c = threadIdx.x;
+  const T* Lb = L + int64_t(blockIdx.x) * 128 * ld + int64_t(blockIdx.x) * 128;
+  for (int k = 0; k < 128; ++k)  // column k of the block: rows k..127, coalesced
+    if (c >= k) Lp[c * (c + 1) / 2 + k] = Lb[int64_t(k) * ld + c];
+  __syncthreads();
+  for (int i = 0; i < 128; ++i) {
+    if (i >= c) {
+      T sum = (i == c) ? T(1) : T(0);
+      const int row = i * (i + 1) / 2;
+      for (int k = c; k < i; ++k) sum -= Lp[row + k] * Wp[k * (k + 1) / 2 + c];
+      Wp[row + c] = sum / Lp[row + i];
+    }
+  }
+  T* out = winv + int64_t(blockIdx.x) * 16384 + int64_t(c) * 128;
+  for (int i = 0; i < 128; ++i) out[i] = (i >= c) ? Wp[i * (i + 1) / 2 + c] : T(0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T* __restrict__ L, int64_t ld,
+                                                              const T* __restrict__ winv,
+                                                              const T* __restrict__ yin, T* __restrict__ x,
+                                                              int32_t* __restrict__ ticket) {
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  using bits_t = typename Sent<T>::bits_t;
+  // 256 threads = one wave per SIMD (up to 512 VGPRs each): lane = 2 rows, wave = 32 columns;
+  // per tile a lane has 32 16-byte loads in flight, 128 KiB per workgroup
+  constexpr int NC = 32, NG = 4;
+  __shared__ int sb;
+  __shared__ T sx[2][128];
+  __shared__ T red[NG][128];
+  __shared__ T sr[128];
+  const int tid = threadIdx.x, rq = tid & 63;
+  const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar address math
+  if (tid == 0) sb = atomicAdd(ticket, 1);
+  __syncthreads();
+  const int b = __builtin_amdgcn_readfirstlane(sb);
+  if (b >= nblk) return;
+  // uniform (SGPR) base + one 32-bit lane offset per load: no per-load address registers
+  const T* Lrow = L + int64_t(b) * 128 + int64_t(NC * cg) * ld;  // + (c*128 + j) * ld + 2 rq
+  T acc0 = 0, acc1 = 0;
+  T2 bufA[NC], bufB[NC];  // tile double buffer; the idle one takes W_b during the last step
+  auto load_tile = [&](T2 (&buf)[NC], int c) {
+    const T* p = Lrow + int64_t(c) * 128 * ld;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) buf[j] = *reinterpret_cast<const T2*>(p + int64_t(j) * ld + 2 * rq);
+  };
+  // the diagonal block's inverse: this lane's 2 rows x NC columns
+  auto load_w = [&](T2 (&buf)[NC]) {
+    const T* wb = winv + int64_t(b) * 16384 + int64_t(NC * cg) * 128;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) buf[j] = *reinterpret_cast<const T2*>(wb + j * 128 + 2 * rq);
+  };
+  bits_t xb = Sent<T>::value;
+  // next: 0 nothing, 1 tile c+1, 2 W_b -- always issued BEFORE waiting for x_c
+  auto step = [&](int c, T2 (&cur)[NC], T2 (&nxt)[NC], int next) {
+    if (next == 1) load_tile(nxt, c + 1);
+    if (next == 2) load_w(nxt);
+    if (tid < 128) {
+      // bounded: a lost producer must end in a NaN, never in a hung GPU
+      for (long spin = 0; xb == Sent<T>::value && spin < (1L << 26); ++spin) {
+        if (spin) __builtin_amdgcn_s_sleep(1);
+        xb = load_x_bits<T>(x + int64_t(c) * 128 + tid);
+      }
+      sx[c & 1][tid] = bits_to<T>(xb);
+    }
+    __syncthreads();
+    if (tid < 128) xb = (next == 1) ? load_x_bits<T>(x + int64_t(c + 1) * 128 + tid) : Sent<T>::value;
+    const T* xc = &sx[c & 1][NC * cg];
+#pragma unroll
+    for (int j0 = 0; j0 < NC; j0 += 8) {
+#pragma unroll
+      for (int j = j0; j < j0 + 8; ++j) {
+        acc0 += cur[j].x * xc[j];
+        acc1 += cur[j].y * xc[j];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the LDS operand reads in chunks (register pressure)
+    }
+  };
+  // r = y_b - sum over the four column groups (fixed order), then x_b = W_b r, then publish
+  auto finish = [&](T2 (&wf)[NC]) {
+    red[cg][2 * rq] = acc0;
+    red[cg][2 * rq + 1] = acc1;
+    __syncthreads();
+    if (tid < 128)
+      sr[tid] = yin[int64_t(b) * 128 + tid] - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    __syncthreads();
+    T p0 = 0, p1 = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < NC; j0 += 8) {
+#pragma unroll
+      for (int j = j0; j < j0 + 8; ++j) {
+        const T rj = sr[NC * cg + j];
+        p0 += wf[j].x * rj;
+        p1 += wf[j].y * rj;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    red[cg][2 * rq] = p0;
+    red[cg][2 * rq + 1] = p1;
+    __syncthreads();
+    if (tid < 128) {
+      const T xv = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      bits_t out;
+      __builtin_memcpy(&out, &xv, sizeof(T));
+      if (out == Sent<T>::value) out ^= 1;  // cannot happen for a computed value; keeps the protocol total
+      __hip_atomic_store(reinterpret_cast<bits_t*>(x + int64_t(b) * 128 + tid), out, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if (b == 0) {
+    load_w(bufA);
+    finish(bufA);
+    return;
+  }
+  load_tile(bufA, 0);
+  int c = 0;
+  for (; c + 2 < b; c += 2) {
+    step(c, bufA, bufB, 1);
+    step(c + 1, bufB, bufA, 1);
+  }
+  if (b - c == 2) {
+    step(c, bufA, bufB, 1);
+    step(c + 1, bufB, bufA, 2);
+    finish(bufA);
+  } else {
+    step(c, bufA, bufB, 2);
+    finish(bufB);
+  }
 }
 
 }  // namespace
@@ -1015,10 +1211,29 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
 }
 
 template <typename T>
-int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int transpose, T* y) {
+int compute_winv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* winv) {
+  if (n == 0) return TGP_OK;
+  hipLaunchKernelGGL((winv_kernel<T>), dim3((unsigned)(n / TILE)), dim3(128), 0, ctx->stream, L, ld, winv);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+template <typename T>
+int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int transpose, T* y,
+         const T* winv) {
   TGP_ARG_CHECK(n % TILE == 0, "trsv: n must be a multiple of %d", TILE);
   hipStream_t st = ctx->stream;
   const int64_t nb = n / TILE;
+  if (!transpose && winv != nullptr && n > 0) {  // one streaming launch (trsv_fwd_stream_kernel)
+    TGP_TRY(ensure_work(ctx, size_t(n) * sizeof(T) + 256));
+    T* tmp = static_cast<T*>(ctx->d_work);
+    int32_t* ticket = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->d_work) + size_t(n) * sizeof(T) + 64);
+    hipLaunchKernelGGL((trsv_prep_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, y, tmp, ticket);
+    hipLaunchKernelGGL((trsv_fwd_stream_kernel<T>), dim3((unsigned)nb), dim3(256), 0, st, (int)nb, L, ld, winv,
+                       (const T*)tmp, y, ticket);
+    TGP_HIP_TRY(hipGetLastError());
+    return TGP_OK;
+  }
   if (!transpose) {
     for (int64_t kb = 0; kb < nb; ++kb) {
       const int64_t j0 = kb * TILE;
@@ -1131,7 +1346,8 @@ int tri_inverse_t(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* din
   template int panel_chain<T>(tgp_ctx*, hipStream_t, int64_t, T*, int64_t, T*, int64_t, int64_t, \
                               int64_t, bool, T*, int64_t, const std::function<int(hipEvent_t)>&); \
   template int potrf<T>(tgp_ctx*, int64_t, T*, int64_t, T*, int32_t*, T*);                           \
-  template int trsv<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, int, T*);                 \
+  template int trsv<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, int, T*, const T*);       \
+  template int compute_winv<T>(tgp_ctx*, int64_t, const T*, int64_t, T*);                        \
   template int gemv_sub<T>(tgp_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*);                          \
   template int trsm_right_lt<T>(tgp_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*,     \
                                 int64_t);

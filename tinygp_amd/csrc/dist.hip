@@ -35,7 +35,10 @@ struct tgp_dist {
   void* diag = nullptr;    // (n,)
   void* A = nullptr;       // n_pad x nloc*nb, ld = n_pad
   void* dinv = nullptr;    // (n_pad/128) * 2048 (only the owned panels' entries are written)
-  void* ring[2] = {nullptr, nullptr};  // caller-owned broadcast slots
+  static constexpr int NSLOT = 3;
+  void* ring[3] = {nullptr, nullptr, nullptr};  // caller-owned broadcast slots (panel k in slot k mod 3)
+  hipEvent_t ev_solve[3] = {nullptr, nullptr, nullptr};  // forward step that read the slot has finished
+  bool ev_solve_set[3] = {false, false, false};
   void* x = nullptr;       // caller-owned replicated vector (n_pad): residual -> L^-1 r -> K^-1 r
   void* Xown = nullptr;    // coordinates of the owned columns, compacted (cond-mean partial)
   void* aown = nullptr;    // alpha at the owned columns, compacted
@@ -114,7 +117,7 @@ int factor_and_pack(tgp_dist* h, int64_t k, bool head_done) {
   TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
   const std::function<int(hipEvent_t)> no_mid = [](hipEvent_t) { return TGP_OK; };
   TGP_TRY(panel_chain<T>(ctx, S1, rows, Ap, ld, dk, k * h->nb, 0, h->nb, head_done, (T*)nullptr, 0, no_mid));
-  T* slot = (T*)h->ring[k & 1];
+  T* slot = (T*)h->ring[k % tgp_dist::NSLOT];
   const int64_t nd = slot_dinv_elems(h);
   TGP_HIP_TRY(hipMemcpyAsync(slot, dk, size_t(nd) * sizeof(T), hipMemcpyDeviceToDevice, S1));
   unsigned gx = (unsigned)((rows / (16 / sizeof(T)) + 255) / 256);
@@ -148,7 +151,7 @@ int64_t tgp_dist_slot_elems(int64_t n, int64_t nb) {
 
 int tgp_dist_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X_host,
                     const void* noise_diag_host, int64_t nb, int32_t world, int32_t rank,
-                    void* ring0_dev, void* ring1_dev, void* x_dev, tgp_dist** out) {
+                    void* ring0_dev, void* ring1_dev, void* ring2_dev, void* x_dev, tgp_dist** out) {
   TGP_ARG_CHECK(ctx != nullptr && out != nullptr, "null argument");
   std::unique_lock<std::recursive_mutex> lk(ctx->mu);
   TGP_HIP_TRY(hipSetDevice(ctx->device));
@@ -156,7 +159,7 @@ int tgp_dist_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X
   TGP_ARG_CHECK(n >= 1 && d >= 1 && d <= TGP_MAX_DIM, "bad problem size");
   TGP_ARG_CHECK(nb >= TILE && nb % TILE == 0, "nb must be a positive multiple of %d", TILE);
   TGP_ARG_CHECK(world >= 1 && rank >= 0 && rank < world, "bad rank / world size");
-  TGP_ARG_CHECK(X_host && noise_diag_host && ring0_dev && ring1_dev && x_dev, "null buffer");
+  TGP_ARG_CHECK(X_host && noise_diag_host && ring0_dev && ring1_dev && ring2_dev && x_dev, "null buffer");
   TGP_ARG_CHECK(ctx->panel_stream != nullptr, "the context has no panel stream");
   tgp_dist* h = new tgp_dist();
   h->ctx = ctx; h->dtype = dtype; h->n = n; h->d = d; h->nb = nb; h->G = world; h->rank = rank;
@@ -164,7 +167,7 @@ int tgp_dist_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X
   h->npad = h->nblk * nb;
   h->nloc = (h->nblk - rank + world - 1) / world;
   if (h->nloc < 0) h->nloc = 0;
-  h->ring[0] = ring0_dev; h->ring[1] = ring1_dev; h->x = x_dev;
+  h->ring[0] = ring0_dev; h->ring[1] = ring1_dev; h->ring[2] = ring2_dev; h->x = x_dev;
   const size_t es = esz(dtype);
   auto fail = [&](int code) { tgp_dist_destroy(h); return code; };
 #define D_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) {                    \
@@ -175,6 +178,7 @@ int tgp_dist_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X
   D_TRY(hipMalloc(&h->A, std::max<size_t>(size_t(h->npad) * size_t(h->nloc * nb) * es, 8)));
   D_TRY(hipMalloc(&h->dinv, size_t(h->npad / TILE) * 2048 * es));
   D_TRY(hipMalloc((void**)&h->d_logdet, size_t(h->nblk + 1) * sizeof(double)));
+  for (auto& e : h->ev_solve) D_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   D_TRY(hipMemcpyAsync(h->X, X_host, size_t(n) * d * es, hipMemcpyHostToDevice, ctx->stream));
   D_TRY(hipMemcpyAsync(h->diag, noise_diag_host, size_t(n) * es, hipMemcpyHostToDevice, ctx->stream));
   // compacted coordinates of the owned columns (for the conditional-mean partial products)
@@ -207,6 +211,8 @@ int tgp_dist_destroy(tgp_dist* h) {
   void* bufs[] = {h->X, h->diag, h->A, h->dinv, h->Xown, h->aown, (void*)h->d_logdet};
   for (void* b : bufs)
     if (b) hipFree(b);
+  for (auto e : h->ev_solve)
+    if (e) hipEventDestroy(e);
   delete h;
   return TGP_OK;
 }
@@ -264,7 +270,8 @@ int tgp_dist_begin(tgp_dist* h, const void* resid_host) {
     if (h->npad > h->n)
       TGP_HIP_TRY(hipMemsetAsync((char*)h->x + size_t(h->n) * es, 0, size_t(h->npad - h->n) * es, ctx->stream));
   }
-  TGP_HIP_TRY(hipEventRecord(ctx->ev_c, ctx->stream));  // "solve stream is idle" marker
+  for (bool& b : h->ev_solve_set) b = false;
+  TGP_TRY(reserve_cus(ctx));  // no-op unless the context option is set; released by tgp_dist_end
   return TGP_OK;
 }
 
@@ -290,11 +297,13 @@ int tgp_dist_after_recv(tgp_dist* h, int64_t k) {
   return ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
     const int64_t rows = rows_of(h, k), nb = h->nb, nd = slot_dinv_elems(h);
-    const T* slot = (const T*)h->ring[k & 1];
+    const int sl = int(k % tgp_dist::NSLOT), sl_next = int((k + 1) % tgp_dist::NSLOT);
+    const T* slot = (const T*)h->ring[sl];
     const T* P = slot + nd;  // rows x nb, ld = rows, row 0 = global row k*nb
-    // the solve stream's step k-1 read the OTHER slot, step k-2 this one: it must be done
-    // before anything later on the main stream lets the slot be overwritten
-    TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_c, 0));
+    // The slot panel k+1 will be written into (by the owner's pack or by RCCL, both ordered
+    // behind the main stream from here on) was last read by the forward step of panel k-2:
+    // two panels of slack for the solve stream, which shares the chip with the updates.
+    if (h->ev_solve_set[sl_next]) TGP_HIP_TRY(hipStreamWaitEvent(S0, h->ev_solve[sl_next], 0));
     TGP_HIP_TRY(hipEventRecord(ctx->ev_b, S0));
     TGP_HIP_TRY(hipStreamWaitEvent(S2, ctx->ev_b, 0));
     if (h->solving) {
@@ -304,7 +313,8 @@ int tgp_dist_after_recv(tgp_dist* h, int64_t k) {
                                         slot + (j / TILE) * 2048, xk + j));
     }
     TGP_TRY(launch_sum_log_diag_at<T>(ctx, S2, nb, P, rows, h->d_logdet + k));
-    TGP_HIP_TRY(hipEventRecord(ctx->ev_c, S2));
+    TGP_HIP_TRY(hipEventRecord(h->ev_solve[sl], S2));
+    h->ev_solve_set[sl] = true;
     const int64_t k1 = k + 1;
     if (k1 < h->nblk && owner_of(h, k1) == h->rank) {
       TGP_TRY(join_assembly<T>(h));
@@ -331,7 +341,7 @@ int tgp_dist_rest(tgp_dist* h, int64_t k) {
   return ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
     const int64_t rows = rows_of(h, k), nb = h->nb;
-    const T* P = (const T*)h->ring[k & 1] + slot_dinv_elems(h);
+    const T* P = (const T*)h->ring[k % tgp_dist::NSLOT] + slot_dinv_elems(h);
     // first owned block column j = l*G + rank with j > k, skipping k+1 (look-ahead)
     int64_t l0 = (k + 1 - h->rank + h->G - 1) / h->G;
     if (l0 < 0) l0 = 0;
@@ -352,7 +362,9 @@ int tgp_dist_end(tgp_dist* h, int32_t* info, double* sumsq, double* logdet_half)
   DIST_GUARD(h);
   tgp_ctx* ctx = h->ctx;
   hipStream_t S0 = ctx->stream;
-  TGP_HIP_TRY(hipStreamWaitEvent(S0, ctx->ev_c, 0));
+  for (int i = 0; i < tgp_dist::NSLOT; ++i)
+    if (h->ev_solve_set[i]) TGP_HIP_TRY(hipStreamWaitEvent(S0, h->ev_solve[i], 0));
+  release_cus(ctx);
   TGP_TRY(ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
     if (h->solving) TGP_TRY(launch_sum_squares_at<T>(ctx, S0, h->npad, (const T*)h->x, h->d_logdet + h->nblk));

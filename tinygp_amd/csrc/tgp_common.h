@@ -101,6 +101,7 @@ struct tgp_ctx {
   // below it (bulk work) follow on `bulk_stream`.  `epi_atomic`: the trailing update writes
   // C -= acc with one no-return fp64 atomic per element instead of a read-modify-write.
   int64_t reserve_cus = 0, trsm_split = 0, epi_atomic = 0;
+  int64_t stream_trsv = 1;  // forward solves on a resident factor: one streaming launch (0: one launch pair per block)
   int64_t keep_grad_buffers = 0;  // tgp_solver_grad keeps its two N^2 work matrices between calls
   int64_t first_small_tiles = 1100;  // look-ahead block-column updates up to this many tiles use 64x64 tiles
   // small device scratch: scal[0..15] doubles, info int
@@ -231,8 +232,13 @@ int launch_trsv_fwd_step(tgp_ctx* ctx, hipStream_t st, int64_t m_below, const T*
                          const T* dj, T* yj);
 template <typename T>
 int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host, T* y = nullptr);
+// winv != NULL (inverses of the 128 x 128 diagonal blocks, compute_winv) and transpose == 0: the
+// single-launch streaming solve; otherwise one pair of launches per 128-block
 template <typename T>
-int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int transpose, T* y);
+int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int transpose, T* y,
+         const T* winv = nullptr);
+template <typename T>
+int compute_winv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* winv);
 template <typename T>
 int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, const T* dinv,
                   T* B, int64_t ldb);

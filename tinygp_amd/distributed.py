@@ -13,7 +13,8 @@ The reference has no multi-device code at all; this is new design for MI355X + R
   over all of them;
 * look-ahead: the owner of panel ``k+1`` updates that block column first and runs its chain
   beside the big update of step ``k``; the broadcast of panel ``k+1`` is enqueued BEFORE that
-  update, so the transfer hides under it as well (two ring slots);
+  update, so the transfer hides under it as well (three ring slots: the replicated forward
+  solve may lag two panels behind the updates);
 * ``log_probability`` needs no other exchange: every rank receives every panel, so the forward
   substitution of the (replicated) right-hand side and ``sum log L_ii`` run redundantly on each
   rank straight from the received panels, on a side stream, under the updates;
@@ -71,7 +72,7 @@ class HipBlockOps:
         nslot = lib.tgp_dist_slot_elems(n, nb)
         self.nd = (nb // 128) * 2048
         self.npad = -(-n // nb) * nb
-        self.ring = [torch.empty(nslot, dtype=tdt, device=self.device) for _ in range(2)]
+        self.ring = [torch.empty(nslot, dtype=tdt, device=self.device) for _ in range(3)]
         self.x = torch.zeros(self.npad, dtype=tdt, device=self.device)
         torch.cuda.synchronize(self.device)
         h = C.c_void_p()
@@ -79,6 +80,7 @@ class HipBlockOps:
                                        _ffi.ptr(noise_diag), nb, world, rank,
                                        C.c_void_p(self.ring[0].data_ptr()),
                                        C.c_void_p(self.ring[1].data_ptr()),
+                                       C.c_void_p(self.ring[2].data_ptr()),
                                        C.c_void_p(self.x.data_ptr()), C.byref(h)), "tgp_dist_create")
         self.h = h
         self.streams = []
@@ -93,7 +95,7 @@ class HipBlockOps:
 
     def slot(self, k: int, rows: int):
         """The broadcast buffer of panel k: [dinv | rows x nb panel]."""
-        return self.ring[k & 1][: self.nd + rows * self.nb]
+        return self.ring[k % 3][: self.nd + rows * self.nb]
 
     def x_slice(self, k: int):
         return self.x[k * self.nb:(k + 1) * self.nb]
@@ -279,9 +281,9 @@ class BlockCyclicCholesky:
             raise ValueError("X_test must have the same number of input dimensions as X")
         prog = self.prog if kernel is None else kernel.program()
         part = self.ops.cond_mean_partial(prog, Pt)
-        with self.ops.stream(MAIN):
+        with self.ops.stream(MAIN):  # the copy to the host must follow the all-reduce on ITS stream
             self.dist.all_reduce(part, group=self.group)
-        out = part.cpu().numpy()
+            out = part.cpu().numpy()
         if self.info:
             out = np.full_like(out, np.nan)
         return out
