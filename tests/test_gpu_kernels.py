@@ -180,8 +180,8 @@ def test_trsm_right_lt_vs_lapack():
 
 @pytest.mark.parametrize("n,dtype", [(100, np.float64), (300, np.float64), (1100, np.float64), (5000, np.float64),
                                      (16384, np.float64), (3000, np.float32)])
-def test_streaming_forward_solve_matches_lapack_and_the_stepwise_path(n, dtype):
-    """The single-launch forward substitution (one workgroup per row block, data-tagged
+def test_streaming_solves_match_lapack_and_the_stepwise_path(n, dtype):
+    """The single-launch forward and backward substitutions (one workgroup per block, data-tagged
     hand-off of the solved blocks, explicit inverses of the 128 x 128 diagonal blocks) against
     LAPACK dtrtrs and against the one-launch-pair-per-block path, and bit-reproducible."""
     from tinygp_amd import GaussianProcess, _ffi
@@ -193,20 +193,30 @@ def test_streaming_forward_solve_matches_lapack_and_the_stepwise_path(n, dtype):
     s = gp.solver
     L = s.scale_tril.astype(np.float64)
     want = sla.solve_triangular(L, y.astype(dtype).astype(np.float64), lower=True, check_finite=False)
+    want_t = sla.solve_triangular(L, y.astype(dtype).astype(np.float64), lower=True, trans=1, check_finite=False)
+    Y3 = np.stack([y, np.cos(X), np.ones(n)], axis=1).astype(dtype)
+    want_t3 = sla.solve_triangular(L, Y3.astype(np.float64), lower=True, trans=1, check_finite=False)
     ctx = _ffi.default_ctx()
-    got = {}
+    got, got_t = {}, {}
     for mode in (1, 0):
         old = ctx.set_option("stream_trsv", mode)
         try:
             got[mode] = s.solve_triangular(y.astype(dtype))
             lp = float(s.log_probability(y.astype(dtype)))
             again = [s.solve_triangular(y.astype(dtype)) for _ in range(3)]
+            got_t[mode] = s.solve_triangular(y.astype(dtype), transpose=True)
+            again_t = [s.solve_triangular(y.astype(dtype), transpose=True) for _ in range(3)]
+            t3 = s.solve_triangular(Y3, transpose=True)
         finally:
             ctx.set_option("stream_trsv", old)
         assert all(np.array_equal(a, got[mode]) for a in again)
+        assert all(np.array_equal(a, got_t[mode]) for a in again_t)
         tol = 1e-9 if dtype == np.float64 else 2e-3
         scale = np.max(np.abs(want))
         assert np.max(np.abs(got[mode] - want)) <= tol * scale, (mode, np.max(np.abs(got[mode] - want)) / scale)
+        assert np.max(np.abs(got_t[mode] - want_t)) <= tol * np.max(np.abs(want_t)), mode
+        assert np.max(np.abs(t3 - want_t3)) <= tol * np.max(np.abs(want_t3)), mode
         ref = -0.5 * want @ want - np.sum(np.log(np.diag(L))) - 0.5 * n * np.log(2 * np.pi)
         np.testing.assert_allclose(lp, ref, rtol=1e-9 if dtype == np.float64 else 5e-4)
     np.testing.assert_allclose(got[1], got[0], rtol=0, atol=(1e-10 if dtype == np.float64 else 1e-3) * np.max(np.abs(want)))
+    np.testing.assert_allclose(got_t[1], got_t[0], rtol=0, atol=(1e-10 if dtype == np.float64 else 1e-3) * np.max(np.abs(want_t)))

@@ -114,7 +114,7 @@ static int assemble_lower(tgp_ctx* ctx, const tgp::KProg& kp, int64_t n, int d, 
 template <typename T>
 static int ensure_winv(tgp_solver* s) {
   if (s->winv_valid) return TGP_OK;
-  if (!s->winv) TGP_HIP_TRY(hipMalloc(&s->winv, size_t(s->npad / TILE) * 16384 * sizeof(T)));
+  if (!s->winv) TGP_HIP_TRY(hipMalloc(&s->winv, 2 * size_t(s->npad / TILE) * 16384 * sizeof(T)));  // W and W^T
   TGP_TRY(compute_winv<T>(s->ctx, s->npad, (const T*)s->A, s->npad, (T*)s->winv));
   s->winv_valid = true;
   return TGP_OK;
@@ -629,7 +629,7 @@ int tgp_solver_solve_tri(tgp_solver* s, int transpose, int64_t nrhs, const void*
     if (nrhs == 1) {
       TGP_TRY(upload_vec(s, s->vec, y_host));
       const T* winv = nullptr;
-      if (!transpose && ctx->stream_trsv != 0 && s->info == 0) {
+      if (ctx->stream_trsv != 0 && s->info == 0) {
         TGP_TRY(ensure_winv<T>(s));
         winv = (const T*)s->winv;
       }
@@ -652,11 +652,16 @@ int tgp_solver_solve_tri(tgp_solver* s, int transpose, int64_t nrhs, const void*
       return TGP_OK;
     }
     // L^T X = Y with several right-hand sides: one backward sweep per column
+    const T* winv_t = nullptr;
+    if (ctx->stream_trsv != 0 && s->info == 0) {
+      TGP_TRY(ensure_winv<T>(s));
+      winv_t = (const T*)s->winv;
+    }
     for (int64_t r = 0; r < nrhs; ++r) {
       TGP_HIP_TRY(hipMemsetAsync(s->vec, 0, size_t(s->npad) * es, ctx->stream));
       TGP_HIP_TRY(hipMemcpy2DAsync(s->vec, es, (const char*)y_host + r * es, size_t(nrhs) * es, es,
                                    size_t(s->n), hipMemcpyHostToDevice, ctx->stream));
-      TGP_TRY(trsv<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, 1, (T*)s->vec));
+      TGP_TRY(trsv<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, 1, (T*)s->vec, winv_t));
       TGP_HIP_TRY(hipMemcpy2DAsync((char*)x_host + r * es, size_t(nrhs) * es, s->vec, es, es,
                                    size_t(s->n), hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -771,7 +776,8 @@ int tgp_solver_alpha(tgp_solver* s, const void* resid_host, void* alpha_host, do
   tgp_ctx* ctx = s->ctx;
   TGP_TRY(dispatch(s->dtype, [&](auto tag) {
     using T = decltype(tag);
-    return trsv<T>(ctx, s->npad, (const T*)s->A, s->npad, (const T*)s->dinv, 1, (T*)s->vec);
+    const T* winv = (ctx->stream_trsv != 0 && s->info == 0 && s->winv_valid) ? (const T*)s->winv : nullptr;
+    return trsv<T>(ctx, s->npad, (const T*)s->A, s->npad, (const T*)s->dinv, 1, (T*)s->vec, winv);
   }));
   TGP_HIP_TRY(hipMemcpyAsync(alpha_host, s->vec, size_t(s->n) * esize(s->dtype),
                              hipMemcpyDeviceToHost, ctx->stream));
@@ -827,7 +833,8 @@ int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, doub
     using T = decltype(tag);
     const T* L = (const T*)s->A;
     T* alpha = (T*)s->vec;
-    TGP_TRY(trsv<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, 1, alpha));  // alpha = K^-1 r
+    TGP_TRY(trsv<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, 1, alpha,
+                    (ctx->stream_trsv != 0 && s->info == 0 && s->winv_valid) ? (const T*)s->winv : (const T*)nullptr));  // alpha = K^-1 r
     TGP_TRY(tri_inverse_t<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, (T*)s->Minv, s->npad));
     // K^-1 = L^-T L^-1 = M M^T, lower tiles, k-loop from the row tile (M upper triangular)
     TGP_TRY(launch_gemm_nt<T>(ctx, ctx->stream, s->npad, s->npad, s->npad, (const T*)s->Minv, s->npad,

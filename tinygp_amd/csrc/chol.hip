@@ -710,7 +710,8 @@ __global__ __launch_bounds__(256) void trsv_prep_kernel(int64_t n, T* __restrict
 // W_b = L_bb^-1 for every 128 x 128 diagonal block (column-major 128 x 128 each, zeros above the
 // diagonal): column c of W by forward substitution, one thread per column, L and W packed in LDS.
 template <typename T>
-__global__ __launch_bounds__(128) void winv_kernel(const T* __restrict__ L, int64_t ld, T* __restrict__ winv) {
+__global__ __launch_bounds__(128) void winv_kernel(const T* __restrict__ L, int64_t ld, T* __restrict__ winv,
+                                                   T* __restrict__ winvT) {
   __shared__ T Lp[8256];
   __shared__ T Wp[8256];
   const int c = threadIdx.x;
@@ -727,7 +728,12 @@ __global__ __launch_bounds__(128) void winv_kernel(const T* __restrict__ L, int6
     }
   }
   T* out = winv + int64_t(blockIdx.x) * 16384 + int64_t(c) * 128;
-  for (int i = 0; i < 128; ++i) out[i] = (i >= c) ? Wp[i * (i + 1) / 2 + c] : T(0);
+  T* outT = winvT + int64_t(blockIdx.x) * 16384 + c;  // W^T (column-major): element (c, i) at i * 128 + c
+  for (int i = 0; i < 128; ++i) {
+    const T v = (i >= c) ? Wp[i * (i + 1) / 2 + c] : T(0);
+    out[i] = v;
+    outT[int64_t(i) * 128] = v;
+  }
 }
 
 template <typename T>
@@ -837,6 +843,131 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
   if (b - c == 2) {
     step(c, bufA, bufB, 1);
     step(c + 1, bufB, bufA, 2);
+    finish(bufA);
+  } else {
+    step(c, bufA, bufB, 2);
+    finish(bufB);
+  }
+}
+
+// Backward substitution L^T x = z in one launch: workgroup (ticket) t owns block b = nblk-1-t, i.e.
+// the 128 COLUMNS b of L, and streams the tiles (c, b), c = nblk-1 .. b+1, as the solved blocks
+// x_c appear from the bottom up.  Output j of the block is a dot product ALONG a column of L --
+// contiguous memory -- so a lane keeps, for each of its wave's 32 columns, the partial sum over
+// its own two rows across ALL tiles, and the cross-lane reduction happens once per block (LDS
+// transpose, fixed order).  The diagonal block is applied as W_b^T (stored transposed by
+// winv_kernel, so the product is the forward kernel's).  Same hand-off protocol as above.
+template <typename T>
+__global__ __launch_bounds__(512) void trsv_bwd_stream_kernel(int nblk, const T* __restrict__ L, int64_t ld,
+                                                              const T* __restrict__ winvT,
+                                                              const T* __restrict__ zin, T* __restrict__ x,
+                                                              int32_t* __restrict__ ticket) {
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  using bits_t = typename Sent<T>::bits_t;
+  constexpr int NC = 16, NG = 8, PAD = 65;  // 8 waves (two per SIMD, <= 256 VGPRs each) x 16 columns
+  __shared__ int sb;
+  __shared__ T sx[2][128];
+  __shared__ T redT[NG][NC][PAD];  // per-lane partial sums, lane-contiguous (padded: conflict-free column sums)
+  __shared__ T red[NG][128];
+  __shared__ T sr[128];
+  const int tid = threadIdx.x, rq = tid & 63;
+  const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) sb = atomicAdd(ticket, 1);
+  __syncthreads();
+  const int t = __builtin_amdgcn_readfirstlane(sb);
+  if (t >= nblk) return;
+  const int b = nblk - 1 - t;
+  const T* Lcol = L + (int64_t(b) * 128 + NC * cg) * ld;  // + j * ld + c * 128 + 2 rq
+  T acc[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) acc[j] = 0;
+  T2 bufA[NC], bufB[NC];
+  auto load_tile = [&](T2 (&buf)[NC], int c) {
+    const T* p = Lcol + int64_t(c) * 128;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) buf[j] = *reinterpret_cast<const T2*>(p + int64_t(j) * ld + 2 * rq);
+  };
+  auto load_w = [&](T2 (&buf)[NC]) {
+    const T* wb = winvT + int64_t(b) * 16384 + int64_t(NC * cg) * 128;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) buf[j] = *reinterpret_cast<const T2*>(wb + j * 128 + 2 * rq);
+  };
+  bits_t xb = Sent<T>::value;
+  // tiles are visited in DEcreasing c; next: 0 nothing, 1 tile c-1, 2 W_b^T
+  auto step = [&](int c, T2 (&cur)[NC], T2 (&nxt)[NC], int next) {
+    if (next == 1) load_tile(nxt, c - 1);
+    if (next == 2) load_w(nxt);
+    if (tid < 128) {
+      for (long spin = 0; xb == Sent<T>::value && spin < (1L << 26); ++spin) {
+        if (spin) __builtin_amdgcn_s_sleep(1);
+        xb = load_x_bits<T>(x + int64_t(c) * 128 + tid);
+      }
+      sx[c & 1][tid] = bits_to<T>(xb);
+    }
+    __syncthreads();
+    if (tid < 128) xb = (next == 1) ? load_x_bits<T>(x + int64_t(c - 1) * 128 + tid) : Sent<T>::value;
+    const T x0 = sx[c & 1][2 * rq], x1 = sx[c & 1][2 * rq + 1];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) acc[j] += cur[j].x * x0 + cur[j].y * x1;
+  };
+  auto finish = [&](T2 (&wf)[NC]) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) redT[cg][j][rq] = acc[j];
+    __syncthreads();
+    {  // column jj of the block: 64 lane partials, four threads x 16 lanes, fixed order
+      const int jj = tid >> 2, h = tid & 3;
+      const T* src = &redT[jj / NC][jj % NC][16 * h];
+      T s0 = 0, s1 = 0;
+#pragma unroll
+      for (int l = 0; l < 16; l += 2) {
+        s0 += src[l];
+        s1 += src[l + 1];
+      }
+      red[h][jj] = s0 + s1;
+    }
+    __syncthreads();
+    if (tid < 128) sr[tid] = zin[int64_t(b) * 128 + tid] - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    __syncthreads();
+    T p0 = 0, p1 = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < NC; j0 += 8) {
+#pragma unroll
+      for (int j = j0; j < j0 + 8; ++j) {
+        const T rj = sr[NC * cg + j];
+        p0 += wf[j].x * rj;
+        p1 += wf[j].y * rj;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    red[cg][2 * rq] = p0;
+    red[cg][2 * rq + 1] = p1;
+    __syncthreads();
+    if (tid < 128) {
+      const T xv = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) +
+                   ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
+      bits_t out;
+      __builtin_memcpy(&out, &xv, sizeof(T));
+      if (out == Sent<T>::value) out ^= 1;
+      __hip_atomic_store(reinterpret_cast<bits_t*>(x + int64_t(b) * 128 + tid), out, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  const int ntiles = nblk - 1 - b;  // tiles c = nblk-1 .. b+1
+  if (ntiles == 0) {
+    load_w(bufA);
+    finish(bufA);
+    return;
+  }
+  load_tile(bufA, nblk - 1);
+  int c = nblk - 1;
+  for (; c - 2 > b; c -= 2) {
+    step(c, bufA, bufB, 1);
+    step(c - 1, bufB, bufA, 1);
+  }
+  if (c - b == 2) {
+    step(c, bufA, bufB, 1);
+    step(c - 1, bufB, bufA, 2);
     finish(bufA);
   } else {
     step(c, bufA, bufB, 2);
@@ -1210,10 +1341,12 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   return info > 0 ? info : TGP_OK;
 }
 
+// winv: [W_b, b = 0..n/128) | W_b^T, b = 0..n/128)], 128 x 128 column-major each
 template <typename T>
 int compute_winv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* winv) {
   if (n == 0) return TGP_OK;
-  hipLaunchKernelGGL((winv_kernel<T>), dim3((unsigned)(n / TILE)), dim3(128), 0, ctx->stream, L, ld, winv);
+  hipLaunchKernelGGL((winv_kernel<T>), dim3((unsigned)(n / TILE)), dim3(128), 0, ctx->stream, L, ld, winv,
+                     winv + (n / TILE) * 16384);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -1224,13 +1357,17 @@ int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int tra
   TGP_ARG_CHECK(n % TILE == 0, "trsv: n must be a multiple of %d", TILE);
   hipStream_t st = ctx->stream;
   const int64_t nb = n / TILE;
-  if (!transpose && winv != nullptr && n > 0) {  // one streaming launch (trsv_fwd_stream_kernel)
+  if (winv != nullptr && n > 0) {  // one streaming launch (trsv_fwd_stream_kernel / trsv_bwd_stream_kernel)
     TGP_TRY(ensure_work(ctx, size_t(n) * sizeof(T) + 256));
     T* tmp = static_cast<T*>(ctx->d_work);
     int32_t* ticket = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->d_work) + size_t(n) * sizeof(T) + 64);
     hipLaunchKernelGGL((trsv_prep_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, y, tmp, ticket);
-    hipLaunchKernelGGL((trsv_fwd_stream_kernel<T>), dim3((unsigned)nb), dim3(256), 0, st, (int)nb, L, ld, winv,
-                       (const T*)tmp, y, ticket);
+    if (!transpose)
+      hipLaunchKernelGGL((trsv_fwd_stream_kernel<T>), dim3((unsigned)nb), dim3(256), 0, st, (int)nb, L, ld, winv,
+                         (const T*)tmp, y, ticket);
+    else
+      hipLaunchKernelGGL((trsv_bwd_stream_kernel<T>), dim3((unsigned)nb), dim3(512), 0, st, (int)nb, L, ld,
+                         winv + nb * 16384, (const T*)tmp, y, ticket);
     TGP_HIP_TRY(hipGetLastError());
     return TGP_OK;
   }
