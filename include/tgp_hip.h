@@ -98,12 +98,10 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "first_split"       blocks of a panel after which its share of the next block-column
  *                       update is issued early, beside the panel's last blocks (default 5; 0 off)
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
- *   "reserve_cus"       R > 0: R one-wave holder workgroups with 86 KiB of LDS are parked for the
- *                       duration of a factorisation; trailing-update tiles (padded to 78 KiB) do
- *                       not fit beside them, potf2 does -- R CUs stay free for the panel chain
- *   "trsm_split"        1: the chain carries only the rows of the panel's own diagonal block,
- *                       the rows below follow on a bulk stream
- *   "epi_atomic"        1: trailing update writes C with no-return fp64 atomics (no C load)
+ *   "inpanel_big_min_tiles"  in-panel updates (K = 128) of at least this many 128x128 tiles use
+ *                       the 128x128-tile kernel instead of 64x64 tiles (0: never)
+ *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming
+ *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block
  *   "keep_grad_buffers" 1: tgp_solver_grad keeps its two N^2 work matrices between calls */
 int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* old);
 /* name (<=255 chars), CU count, memory bytes, clock kHz of the ctx's device */
@@ -318,11 +316,6 @@ int tgp_dist_get_column(tgp_dist* h, int64_t l, void* out_host);
 int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t first_split,
                      int64_t first_small_tiles, int32_t fused, int64_t* out, int64_t cap_records,
                      int64_t* n_records);
-/* the same with schedule options: bit 0 = "trsm_split" (stream 5 = bulk: the rows below a panel's
- * diagonal block; events 6 / 7 = tail of a block column final / tail pipeline drained) */
-int tgp_trace_factor_ex(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t first_split,
-                        int64_t first_small_tiles, int32_t fused, int64_t options, int64_t* out,
-                        int64_t cap_records, int64_t* n_records);
 
 #ifdef __cplusplus
 }

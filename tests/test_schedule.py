@@ -15,18 +15,18 @@ import pytest
 
 from tinygp_amd import _ffi
 
-NSTREAMS = 6  # main, panel, solve, update, assembly, bulk (split chain)
+NSTREAMS = 5
 KIND = {1: "potf2", 2: "trsm", 3: "gemm", 4: "trsv_step", 5: "record", 6: "wait", 7: "assembly",
         8: "residual_copy", 9: "reductions"}
 
 
-def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1, options=0):
+def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1):
     lib = _ffi.load_library()
-    cap = 60 * (n_pad // 128) + 256
+    cap = 40 * (n_pad // 128) + 256
     out = np.zeros(cap * 10, dtype=np.int64)
     n = C.c_int64()
-    st = lib.tgp_trace_factor_ex(n_pad, nb, lookahead, first_split, first_small, fused, options,
-                                 out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n))
+    st = lib.tgp_trace_factor(n_pad, nb, lookahead, first_split, first_small, fused,
+                              out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n))
     assert st == 0, lib.tgp_last_error()
     return out[: n.value * 10].reshape(-1, 10).tolist()
 
@@ -71,7 +71,7 @@ def accesses(rec, T):
             for ti in range(m):
                 if lower and ti < tj:
                     continue
-                if role == 3 and ti == 0 and tj == 0:
+                if role in (3, 5) and ti == 0 and tj == 0:
                     continue  # folded into the next potf2
                 R.add(("A", cr + ti, cc + tj)); W.add(("A", cr + ti, cc + tj))
         R |= {("A", ar + ti, ac + kk) for ti in range(m) for kk in range(k)}
@@ -146,21 +146,10 @@ CONFIGS = [
     (5120, 512, 1, 3, 1100, 1),
     (4096, 2048, 1, 5, 1100, 1),
     (16384, 1024, 1, 5, 1100, 1),
-    # split chain (option bit 0): head on the panel stream, tails on the bulk stream
-    (1152, 1024, 1, 5, 1100, 1, 1),
-    (2560, 1024, 1, 5, 1100, 1, 1),
-    (2560, 1024, 1, 5, 1100, 0, 1),
-    (3456, 1024, 1, 0, 1100, 1, 1),
-    (5120, 1024, 1, 5, 1100, 1, 1),
-    (5120, 1024, 0, 5, 1100, 1, 1),
-    (5120, 512, 1, 3, 1100, 1, 1),
-    (5120, 1024, 1, 7, 0, 1, 1),
-    (16384, 1024, 1, 5, 1100, 1, 1),
 ]
 
 
-@pytest.mark.parametrize("cfg", CONFIGS, ids=[f"n{c[0]}-nb{c[1]}-la{c[2]}-fs{c[3]}-st{c[4]}-f{c[5]}" + ("-split" if len(c) > 6 else "")
-                              for c in CONFIGS])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[f"n{c[0]}-nb{c[1]}-la{c[2]}-fs{c[3]}-st{c[4]}-f{c[5]}" for c in CONFIGS])
 def test_schedule_has_no_data_race(cfg):
     n_pad = cfg[0]
     recs = trace(*cfg)
@@ -187,20 +176,6 @@ def test_checker_sees_a_missing_dependency():
     no_chain_wait = [r for r in recs if not (r[0] == 6 and r[1] == 0 and r[2] == 1)]  # main waits ev_b
     assert len(no_chain_wait) < len(recs)
     assert find_races(no_chain_wait, T)
-
-
-def test_checker_sees_missing_dependencies_of_the_split_chain():
-    """Same for the split chain (option bit 0): the bulk stream must wait for the head of each
-    block (ev_d), the next head trsm for the head update (ev_e), the panel stream for the drained
-    tail pipeline (ev_g), and the fused forward step / early share for the block column's tail
-    (ev_f)."""
-    recs = trace(3456, options=1)
-    T = 3456 // 128
-    assert any(r[1] == 5 for r in recs)  # the bulk stream is in use
-    for stream, event in ((5, 3), (1, 4), (1, 7), (2, 6), (0, 6)):
-        cut = [r for r in recs if not (r[0] == 6 and r[1] == stream and r[2] == event)]
-        assert len(cut) < len(recs), (stream, event)
-        assert find_races(cut, T), (stream, event)
 
 
 @pytest.mark.parametrize("n_pad,nb,split,small", [(16384, 1024, 5, 1100), (32768, 1024, 5, 1100),

@@ -150,12 +150,6 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->solve_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->update_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->asm_stream, hipStreamNonBlocking, lo));
-  TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->bulk_stream, hipStreamNonBlocking, lo));
-  TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->hold_stream, hipStreamNonBlocking, hi));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_f, hipEventDisableTiming));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_g, hipEventDisableTiming));
-  TGP_HIP_TRY(hipMalloc((void**)&ctx->d_hold, sizeof(int32_t)));
-  TGP_HIP_TRY(hipMemset(ctx->d_hold, 0, sizeof(int32_t)));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_e, hipEventDisableTiming));
@@ -189,15 +183,6 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
     hipStreamSynchronize(ctx->asm_stream);
     hipStreamDestroy(ctx->asm_stream);
   }
-  tgp::release_cus(ctx);
-  for (hipStream_t* q : {&ctx->bulk_stream, &ctx->hold_stream})
-    if (*q) {
-      hipStreamSynchronize(*q);
-      hipStreamDestroy(*q);
-    }
-  if (ctx->ev_f) hipEventDestroy(ctx->ev_f);
-  if (ctx->ev_g) hipEventDestroy(ctx->ev_g);
-  if (ctx->d_hold) hipFree(ctx->d_hold);
   if (ctx->ev_asm) hipEventDestroy(ctx->ev_asm);
   if (ctx->ev_d) hipEventDestroy(ctx->ev_d);
   if (ctx->ev_e) hipEventDestroy(ctx->ev_e);
@@ -229,14 +214,11 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "first_split")) slot = &ctx->first_split;
   else if (!strcmp(key, "first_small_tiles")) slot = &ctx->first_small_tiles;
   else if (!strcmp(key, "keep_grad_buffers")) slot = &ctx->keep_grad_buffers;
-  else if (!strcmp(key, "reserve_cus")) slot = &ctx->reserve_cus;
   else if (!strcmp(key, "stream_trsv")) slot = &ctx->stream_trsv;
-  else if (!strcmp(key, "trsm_split")) slot = &ctx->trsm_split;
-  else if (!strcmp(key, "epi_atomic")) slot = &ctx->epi_atomic;
+  else if (!strcmp(key, "inpanel_big_min_tiles")) slot = &ctx->inpanel_big_min_tiles;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)
     TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);
-  if (slot == &ctx->reserve_cus) TGP_ARG_CHECK(value >= 0 && value <= 64, "reserve_cus must be 0..64");
   if (old) *old = *slot;
   *slot = value;
   return TGP_OK;
@@ -509,9 +491,8 @@ static int factor_impl(tgp_solver* s, const tgp_kop* prog, int nops, const void*
     ctx->asm_pending = false;
     ctx->ev_used = 0;
     s->factored = false;
-    tgp::release_cus(ctx);
     for (hipStream_t q : {ctx->asm_stream, ctx->panel_stream, ctx->update_stream, ctx->solve_stream,
-                          ctx->bulk_stream, ctx->hold_stream, ctx->stream})
+                          ctx->stream})
       if (q) (void)hipStreamSynchronize(q);
     (void)hipGetLastError();
   }
@@ -1024,20 +1005,9 @@ int tgp_solver_timings(tgp_solver* s, double* ms, int n) {
 // Dry run of tgp_solver_factor / tgp_solver_factor_logprob: the sequence of kernel launches and
 // event operations the five streams would receive for an n_pad x n_pad problem, without a GPU
 // (no HIP call is made).  Ten int64 per record: kind, stream, v[0..7] (tgp_trace_rec).
-int tgp_trace_factor_ex(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t first_split,
-                        int64_t first_small_tiles, int32_t fused, int64_t options, int64_t* out,
-                        int64_t cap_records, int64_t* n_records);
-
 int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t first_split,
                      int64_t first_small_tiles, int32_t fused, int64_t* out, int64_t cap_records,
                      int64_t* n_records) {
-  return tgp_trace_factor_ex(n_pad, nb_outer, lookahead, first_split, first_small_tiles, fused, 0, out,
-                             cap_records, n_records);
-}
-
-int tgp_trace_factor_ex(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t first_split,
-                        int64_t first_small_tiles, int32_t fused, int64_t options, int64_t* out,
-                        int64_t cap_records, int64_t* n_records) {
   using namespace tgp;
   TGP_ARG_CHECK(n_pad > 0 && n_pad % 128 == 0 && out != nullptr && n_records != nullptr,
                 "trace: n_pad must be a positive multiple of 128");
@@ -1048,10 +1018,6 @@ int tgp_trace_factor_ex(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int6
   ctx.solve_stream = (hipStream_t)fake(0x30);
   ctx.update_stream = (hipStream_t)fake(0x40);
   ctx.asm_stream = (hipStream_t)fake(0x50);
-  ctx.bulk_stream = (hipStream_t)fake(0x60);
-  ctx.ev_f = (hipEvent_t)fake(0x160);
-  ctx.ev_g = (hipEvent_t)fake(0x170);
-  ctx.trsm_split = (options & 1) ? 1 : 0;
   ctx.ev_a = (hipEvent_t)fake(0x100);
   ctx.ev_b = (hipEvent_t)fake(0x110);
   ctx.ev_c = (hipEvent_t)fake(0x120);

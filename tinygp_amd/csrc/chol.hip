@@ -107,15 +107,10 @@ __device__ long long g_potf2_stamps[64];
 #define POTF2_STAMP(i) do {} while (0)
 #endif
 
-// The body is shared by two kernels that differ only in their register budget:
-//   potf2_kernel     waves_per_eu(4): at most 128 VGPRs, so that two potf2 waves fit on a SIMD
-//                    beside one wave of the trailing-update GEMM (238 VGPRs) -- otherwise potf2
-//                    waits for the whole update to drain;
-//   potf2_solo_kernel  (reserve_cus > 0) waves_per_eu(3): 136..168 VGPRs, i.e. two of its waves
-//                    do NOT fit beside a GEMM wave (2 x 144 + 240 > 512): it can only start on a
-//                    CU without MFMA tiles -- the CUs the holders keep free -- and runs there alone.
+// waves_per_eu(4): at most 128 VGPRs, so that two potf2 waves fit on a SIMD beside one wave of the
+// trailing-update GEMM (238 VGPRs) -- otherwise potf2 waits for the whole update to drain.
 template <typename T, bool FOLD>
-__device__ __forceinline__ void potf2_body(T* __restrict__ A, int64_t ld,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void potf2_kernel(T* __restrict__ A, int64_t ld,
                                                     T* __restrict__ dinv,
                                                     int32_t* __restrict__ info,
                                                     int32_t pivot_base,
@@ -392,41 +387,6 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, int64_t ld,
   // column blocks 0..6 went out while later steps ran; the last one now, a slice per wave
   store_strip(7, 4 * w, 4 * w + 4);
   POTF2_STAMP(34);
-}
-
-template <typename T, bool FOLD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void potf2_kernel(
-    T* __restrict__ A, int64_t ld, T* __restrict__ dinv, int32_t* __restrict__ info,
-    int32_t pivot_base, const T* __restrict__ Xp, int64_t ldx) {
-  potf2_body<T, FOLD>(A, ld, dinv, info, pivot_base, Xp, ldx);
-}
-template <typename T, bool FOLD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) void potf2_solo_kernel(
-    T* __restrict__ A, int64_t ld, T* __restrict__ dinv, int32_t* __restrict__ info,
-    int32_t pivot_base, const T* __restrict__ Xp, int64_t ldx) {
-  // the body needs ~132 VGPRs; the allocation must be >= 144 so that two of these waves and a
-  // 240-VGPR GEMM wave do NOT fit in a SIMD's 512: naming v150 pins the count
-  asm volatile("; potf2_solo: register budget marker" ::: "v150");
-  potf2_body<T, FOLD>(A, ld, dinv, info, pivot_base, Xp, ldx);
-}
-
-// One wave that does nothing but own 86 KiB of LDS until it is released (or a time-out: a lost
-// release must never wedge the GPU).  See tgp_ctx::reserve_cus.
-__global__ __launch_bounds__(64) void cu_holder_kernel(const int32_t* __restrict__ flag, int32_t epoch,
-                                                       long long max_ticks) {
-  extern __shared__ __attribute__((aligned(16))) char held[];
-  const long long t0 = wall_clock64();
-  if (threadIdx.x == 0) {
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-      __builtin_amdgcn_s_sleep(127);
-      __builtin_amdgcn_s_sleep(127);
-      if (wall_clock64() - t0 > max_ticks) break;
-    }
-    if (epoch == -12345) held[0] = 1;  // never true: keeps the allocation referenced
-  }
-}
-__global__ void set_word_kernel(int32_t* p, int32_t v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // dinv for an existing factor: one thread per (16-block, column)
@@ -985,22 +945,12 @@ int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_
     trace_push(ctx, 1, st, trace_off(ctx, A), trace_off(ctx, Xp), ld);
     return TGP_OK;
   }
-  const bool solo = ctx->hold_active && sizeof(T) == 8;
-  if (Xp != nullptr) {
-    if (solo)
-      hipLaunchKernelGGL((potf2_solo_kernel<T, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                         pivot_base, Xp, ldx);
-    else
-      hipLaunchKernelGGL((potf2_kernel<T, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                         pivot_base, Xp, ldx);
-  } else {
-    if (solo)
-      hipLaunchKernelGGL((potf2_solo_kernel<T, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                         pivot_base, Xp, ldx);
-    else
-      hipLaunchKernelGGL((potf2_kernel<T, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                         pivot_base, Xp, ldx);
-  }
+  if (Xp != nullptr)
+    hipLaunchKernelGGL((potf2_kernel<T, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
+                       pivot_base, Xp, ldx);
+  else
+    hipLaunchKernelGGL((potf2_kernel<T, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
+                       pivot_base, Xp, ldx);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -1018,25 +968,6 @@ int launch_trsm(tgp_ctx* ctx, hipStream_t st, int64_t m, const T* L, int64_t ldl
                      ldl, dinv, B, ldb);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
-}
-
-int reserve_cus(tgp_ctx* ctx) {
-  if (ctx->trace || ctx->reserve_cus <= 0 || ctx->hold_stream == nullptr || ctx->hold_active) return TGP_OK;
-  ctx->hold_epoch += 1;
-  // 100 MHz wall clock: 30 s is far beyond any factorisation this library can hold in memory
-  hipLaunchKernelGGL(cu_holder_kernel, dim3((unsigned)ctx->reserve_cus), dim3(64), HOLDER_LDS, ctx->hold_stream,
-                     ctx->d_hold, ctx->hold_epoch, 3000000000LL);
-  TGP_HIP_TRY(hipGetLastError());
-  ctx->hold_active = true;
-  return TGP_OK;
-}
-
-// Asynchronous (on the main stream, behind everything queued so far); safe to call twice.
-void release_cus(tgp_ctx* ctx) {
-  if (!ctx->hold_active) return;
-  hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_hold, ctx->hold_epoch);
-  (void)hipGetLastError();
-  ctx->hold_active = false;
 }
 
 template <typename T>
@@ -1105,47 +1036,6 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
                 int64_t pivot_off, int64_t k0, int64_t kb, bool head_done, T* y,
                 int64_t after_blocks, const std::function<int(hipEvent_t)>& mid) {
   hipStream_t S2 = ctx->solve_stream, S3 = ctx->update_stream;
-  const int64_t pe = k0 + kb, tb = n - pe;  // panel end; rows below the panel's diagonal block
-  if (ctx->trsm_split != 0 && tb > 0 && ctx->bulk_stream != nullptr) {
-    // Split chain.  HEAD = the panel's own kb x kb diagonal block: potf2 -> trsm of the head rows
-    // -> head update, a few workgroups each, nothing in it waits for bulk work.  TAIL = the tb rows
-    // below: trsm + update of block column j follow on the bulk stream as soon as the head of
-    // block j is final, and never gate the next potf2.
-    hipStream_t S5 = ctx->bulk_stream;
-    for (int64_t j0 = k0; j0 < pe; j0 += TILE) {
-      T* Ljj = A + j0 * ld + j0;
-      T* dj = dinv + (j0 / TILE) * 2048;
-      const bool pend = j0 > k0;
-      if (pend || !head_done) TGP_TRY(panel_potf2<T>(ctx, st, A, ld, dinv, pivot_off, j0, pend));
-      if (pend) TGP_TRY(st_wait(ctx, st, ctx->ev_e));  // head update of block column j0-128
-      const int64_t hb = pe - (j0 + TILE);             // head rows below = columns right of block j0
-      if (hb > 0) TGP_TRY(launch_trsm<T>(ctx, st, hb, Ljj, ld, dj, Ljj + TILE, ld));
-      TGP_TRY(ev_record(ctx, ctx->ev_d, st));          // potf2 + head trsm of block j0 done
-      if (hb > 0) {
-        TGP_TRY(st_wait(ctx, S3, ctx->ev_d));
-        TGP_TRY(launch_gemm_nt<T>(ctx, S3, hb, hb, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
-                                  A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, 3));
-        TGP_TRY(ev_record(ctx, ctx->ev_e, S3));
-      }
-      TGP_TRY(st_wait(ctx, S5, ctx->ev_d));
-      T* Xt = A + j0 * ld + pe;  // tail rows of block column j0
-      TGP_TRY(launch_trsm<T>(ctx, S5, tb, Ljj, ld, dj, Xt, ld));
-      TGP_TRY(ev_record(ctx, ctx->ev_f, S5));          // block column j0 final on every row
-      if (hb > 0)  // tail rows of the columns to the right: X_tail (tb x 128) * L[head rows, block j0]^T
-        TGP_TRY(launch_gemm_nt<T>(ctx, S5, tb, hb, TILE, Xt, ld, Ljj + TILE, ld, A + (j0 + TILE) * ld + pe, ld,
-                                  0, 0, 1));
-      if (y != nullptr) {
-        TGP_TRY(st_wait(ctx, S2, ctx->ev_f));
-        TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, n - (j0 + TILE), Ljj, ld, dj, y + j0));
-      }
-      if (after_blocks > 0 && hb > 0 && j0 + TILE == k0 + after_blocks * TILE) {
-        TGP_TRY(mid(ctx->ev_f));  // the early share reads whole block columns: it waits for their tails
-      }
-    }
-    TGP_TRY(ev_record(ctx, ctx->ev_g, S5));
-    TGP_TRY(st_wait(ctx, st, ctx->ev_g));  // the panel is complete when `st` says so
-    return TGP_OK;
-  }
   for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
     T* Ljj = A + j0 * ld + j0;
     T* dj = dinv + (j0 / TILE) * 2048;
@@ -1161,8 +1051,12 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
     if (y != nullptr || upd) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
     if (upd) {
       TGP_TRY(st_wait(ctx, S3, ctx->ev_d));
+      // 64x64 tiles spread a short update over the chip; with several hundred 128x128 tiles the
+      // big-tile kernel (one round, 8 k-steps) is the faster of the two
+      const int64_t big_tiles = (mb / TILE) * (nc / TILE) - (nc / TILE) * (nc / TILE - 1) / 2;
+      const int urole = (ctx->inpanel_big_min_tiles > 0 && big_tiles >= ctx->inpanel_big_min_tiles) ? 5 : 3;
       TGP_TRY(launch_gemm_nt<T>(ctx, S3, mb, nc, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
-                                A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, 3));
+                                A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, urole));
       TGP_TRY(ev_record(ctx, ctx->ev_e, S3));
     }
     if (y != nullptr) {
@@ -1192,11 +1086,6 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   if (NB < TILE) NB = TILE;
   NB = NB / TILE * TILE;
   if (!ctx->trace) TGP_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int32_t), S0));
-  if (n > NB) TGP_TRY(reserve_cus(ctx));  // no-op unless the option is set (a caller may have parked them already)
-  struct HoldGuard {  // every exit path releases the holders
-    tgp_ctx* c;
-    ~HoldGuard() { release_cus(c); }
-  } hold_guard{ctx};
   const bool prof_on = ctx->profile != 0 && !ctx->trace;
   std::vector<ProfSpan> spans;
   ctx->ev_used = 0;
@@ -1321,7 +1210,6 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     TGP_TRY(st_wait(ctx, S0, ctx->ev_c));
   }
   int32_t info = 0;
-  release_cus(ctx);
   if (!ctx->trace) {
     TGP_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, S0));
     TGP_HIP_TRY(hipStreamSynchronize(S0));

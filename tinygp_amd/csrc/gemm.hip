@@ -67,8 +67,6 @@ struct GemmArgs {
   // l*dG + dr they are; rows of A / B / C are GLOBAL, tm = global row tiles, and local column
   // tile tj updates rows >= its global column tile only (lower trapezoid per column tile).
   int dG, dr, dl0, dnbt;
-  int epi;     // mode 0 epilogue: 0 = batched read-modify-write, 1 = one no-return fp64 atomic add per
-               // element (no C load on the wave's critical path; same rounding: C + (-acc))
 };
 
 // Linear workgroup id -> (ti, tj).  Tiles are enumerated column by column (tj major) so
@@ -137,6 +135,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     decode_tile(bid, g.tm, g.tn, g.lower, ti, tj);
     gt = tj;
   }
+
+  if (g.skip00 && ti == 0 && tj == 0) return;  // that tile's update is folded into the next potf2
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1;
@@ -222,16 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     }
     // epilogue.  The read-modify-write is batched: 32 independent loads in flight, then 32
     // stores, twice (element by element it is 64 dependent HBM round trips per lane).
-    if (g.mode == 0 && g.epi != 0) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        T* col = Cb + int64_t(a * 16 + 4 * lq + lk) * g.ldc;
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) unsafeAtomicAdd(&col[b * 16 + rot[t]], -acc[a][b][t]);
-      }
-    } else if (g.mode == 0) {
+    if (g.mode == 0) {
 #pragma unroll
       for (int ap = 0; ap < 4; ap += 2) {
         T* col[2];
@@ -559,8 +550,8 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   GemmArgs<T> g;
   g.skip00 = 0;
   g.dG = g.dr = g.dl0 = g.dnbt = 0;
-  g.epi = (ctx->epi_atomic != 0 && sizeof(T) == 8 && role == 0) ? 1 : 0;
   TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");
+  TGP_ARG_CHECK(role != 5 || (mode == 0 && lower != 0), "role 5 is a lower in-panel update");
   // short-K updates, and (role 4) a latency-bound update with too few big tiles to fill the chip
   if ((((role == 1 || role == 3) && k <= 256) || role == 4) && (mode == 0 || mode == 1)) {
     g.skip00 = (role == 3);
@@ -588,13 +579,11 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   } else {
     g.nblk = g.tm * g.tn;
   }
-  // with CUs reserved for the panel chain the tile's LDS is padded to 78 KiB: two still fit on a
-  // CU, none fits beside a holder (tgp_ctx::reserve_cus)
-  const size_t lds_pad = (ctx->hold_active && sizeof(T) == 8) ? UPDATE_LDS - 4 * BK * LDS_LD * sizeof(T) : 0;
+  g.skip00 = (role == 5);
   if (role == 0)
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), lds_pad, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3((unsigned)g.nblk), dim3(256), lds_pad, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -618,8 +607,6 @@ int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb
   g.tm = int(n_rows / BM); g.tn = int(nloc * (nb / BN));
   g.k = int(k); g.lower = 1; g.mode = 0;
   g.dG = G; g.dr = rank; g.dl0 = int(l0); g.dnbt = int(nb / BN);
-  g.epi = (ctx->epi_atomic != 0 && sizeof(T) == 8) ? 1 : 0;
-  const size_t lds_pad = (ctx->hold_active && sizeof(T) == 8) ? UPDATE_LDS - 4 * BK * LDS_LD * sizeof(T) : 0;
   int64_t total = 0;
   for (int64_t q = 0; q < nloc; ++q) {
     const int64_t g0 = ((l0 + q) * G + rank) * g.dnbt;
@@ -628,7 +615,7 @@ int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb
   }
   TGP_ARG_CHECK(total < (int64_t(1) << 31), "gemm_nt_dist: too many tiles");
   g.nblk = int(total);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), lds_pad, st, g);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }

@@ -63,7 +63,7 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 struct tgp_trace_rec {
   int64_t kind;    // 1 potf2, 2 trsm, 3 gemm, 4 forward-substitution step, 5 event record,
                    // 6 stream wait, 7 assembly of column tiles
-  int64_t stream;  // 0 main, 1 panel, 2 solve, 3 update, 4 assembly, 5 bulk
+  int64_t stream;  // 0 main, 1 panel, 2 solve, 3 update, 4 assembly
   int64_t v[8];    // operands as element offsets from the matrix base (see capi.hip)
 };
 
@@ -80,12 +80,7 @@ struct tgp_ctx {
   hipStream_t solve_stream = nullptr;  // forward substitution overlapped with the factorisation
   hipStream_t update_stream = nullptr;  // in-panel updates beside the next potf2
   hipStream_t asm_stream = nullptr;     // assembly of the columns right of the first panel
-  hipStream_t bulk_stream = nullptr;    // split chain: trsm / in-panel updates of the rows BELOW the panel's diagonal block
-  hipStream_t hold_stream = nullptr;    // the CU-holder kernel (reserve_cus)
-  hipEvent_t ev_f = nullptr, ev_g = nullptr;  // split chain: tail of a block column final / tail pipeline drained
-  int32_t* d_hold = nullptr;            // holder release word
-  int32_t hold_epoch = 0;
-  bool hold_active = false;
+
   hipEvent_t ev_asm = nullptr;          // ... finished (potrf waits before its first update)
   bool asm_pending = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_e = nullptr;
@@ -93,14 +88,7 @@ struct tgp_ctx {
   int64_t lookahead = 1;
   int64_t profile = 0;
   int64_t first_split = 5;  // blocks of a panel after which its share of the next block-column update is issued early (0: off)
-  // Chain protection (chol.hip): `reserve_cus` > 0 parks that many one-wave "holder" workgroups
-  // with 86 KiB of LDS for the duration of a factorisation.  A trailing-update workgroup (padded to
-  // 78 KiB) does not fit beside a holder, potf2 (72 KiB) does: those CUs stay free of MFMA tiles,
-  // so the latency-critical kernels of the panel chain start at once and run alone.
-  // `trsm_split`: the chain only carries the rows of the panel's own diagonal block; the rows
-  // below it (bulk work) follow on `bulk_stream`.  `epi_atomic`: the trailing update writes
-  // C -= acc with one no-return fp64 atomic per element instead of a read-modify-write.
-  int64_t reserve_cus = 0, trsm_split = 0, epi_atomic = 0;
+  int64_t inpanel_big_min_tiles = 0;  // in-panel updates with at least this many 128x128 tiles run on the big-tile kernel (0: never)
   int64_t stream_trsv = 1;  // forward solves on a resident factor: one streaming launch (0: one launch pair per block)
   int64_t keep_grad_buffers = 0;  // tgp_solver_grad keeps its two N^2 work matrices between calls
   int64_t first_small_tiles = 1100;  // look-ahead block-column updates up to this many tiles use 64x64 tiles
@@ -131,7 +119,6 @@ inline int64_t trace_stream_id(const tgp_ctx* ctx, hipStream_t st) {
   if (st == ctx->solve_stream) return 2;
   if (st == ctx->update_stream) return 3;
   if (st == ctx->asm_stream) return 4;
-  if (st == ctx->bulk_stream) return 5;
   return -1;
 }
 inline int64_t trace_event_id(const tgp_ctx* ctx, hipEvent_t ev) {
@@ -141,8 +128,6 @@ inline int64_t trace_event_id(const tgp_ctx* ctx, hipEvent_t ev) {
   if (ev == ctx->ev_d) return 3;
   if (ev == ctx->ev_e) return 4;
   if (ev == ctx->ev_asm) return 5;
-  if (ev == ctx->ev_f) return 6;
-  if (ev == ctx->ev_g) return 7;
   return -1;
 }
 template <typename T>
@@ -173,11 +158,6 @@ inline int st_wait(tgp_ctx* ctx, hipStream_t st, hipEvent_t ev) {
 }
 
 int ensure_dinv(tgp_ctx* ctx, size_t bytes);
-// CU reservation for the panel chain (chol.hip): park / release the holder workgroups
-int reserve_cus(tgp_ctx* ctx);
-void release_cus(tgp_ctx* ctx);
-constexpr size_t HOLDER_LDS = 86 * 1024;    // holder + 78 KiB update tile > 160 KiB; + potf2 (72.3 KiB) fits
-constexpr size_t UPDATE_LDS = 78 * 1024;    // trailing-update workgroup's LDS when CUs are reserved (2 x 78 <= 160)
 int ensure_work(tgp_ctx* ctx, size_t bytes);
 
 // ---- launchers (all async on the given stream) -------------------------------------
@@ -202,7 +182,8 @@ int launch_kmat_gemv(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int 
 // C (m x n) = beta*C + alpha*A*B^T ; mode 0: C -= A B^T ; mode 1: C = A B^T.
 // role: 0 = trailing update (profiled as the dominant kernel), 1 = everything else (64x64
 // tiles when k <= 256), 3 = in-panel update that skips the first 128x128 diagonal tile (potf2
-// folds it in), 4 = 64x64 tiles at any k (latency-bound look-ahead block-column update).
+// folds it in), 4 = 64x64 tiles at any k (latency-bound look-ahead block-column update),
+// 5 = role 3 on 128x128 tiles (an in-panel update with enough tiles to fill the chip).
 template <typename T>
 int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k, const T* A,
                    int64_t lda, const T* B, int64_t ldb, T* C, int64_t ldc, int lower, int mode,
