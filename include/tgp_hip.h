@@ -171,7 +171,7 @@ int tgp_sum_log_diag(tgp_ctx* ctx, int dtype, int64_t n, const void* L, int64_t 
 int tgp_sum_squares(tgp_ctx* ctx, int dtype, int64_t n, const void* y, double* out_host);
 
 /* f64/f32 MFMA issue-rate microbenchmark: returns measured TFLOP/s of
- * v_mfma_f64_16x16x4_f64 (dtype F64) / v_mfma_f32_32x32x2_f32 (F32) over all CUs. */
+ * v_mfma_f64_16x16x4_f64 (dtype F64) / v_mfma_f32_16x16x4_f32 (F32) over all CUs. */
 int tgp_ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops_out);
 /* general form: kind 0 = MFMA f64 16x16x4, 1 = MFMA f32 16x16x4, 2 = VALU v_fma_f64,
  * 3 = MFMA f64 + 4 VALU f64 FMA interleaved per wave, 4 = MFMA f64 4x4x4(4b);

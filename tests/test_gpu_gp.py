@@ -313,6 +313,30 @@ def test_default_jitter_and_fp32():
     np.testing.assert_allclose(c.gp.variance, ref64.condition(y, t).gp.variance, rtol=5e-4, atol=5e-4)
 
 
+def test_ill_conditioned_default_jitter_n4096():
+    """Worst-case conditioning the API allows by default: ExpSquared(2.5) on 4 096 points at
+    100 points per unit length with the DEFAULT jitter sqrt(eps) (gp.py:388-393), cond(K) ~ 1e11,
+    smallest pivot 1.3e-4.  The factorisation's pivot path uses Newton-refined rcp / rsq instead
+    of IEEE division (chol.hip: fast_rcp / fast_rsqrt); this bounds it against LAPACK.  Two
+    LAPACK-based factorisations with different blockings differ by 2e-8 (log-likelihood) and
+    7e-8 (pivots) on this matrix, so the bars are 50x that; the backward error
+    |K - L L^T| / |K| is conditioning-independent and must stay at the rounding level."""
+    n = 4096
+    X, y = _cases.synthetic.make_inputs(n, 1)
+    gp = GaussianProcess(kernels.ExpSquared(2.5), X)
+    ref = o.GaussianProcess(o.ExpSquared(2.5), X)
+    assert gp.solver.info == 0
+    L, Lr = gp.solver.scale_tril, ref.solver.scale_tril
+    K = ref.covariance
+    assert np.linalg.norm(K - L @ L.T) / np.linalg.norm(K) < 1e-14
+    np.testing.assert_allclose(np.diag(L), np.diag(Lr), rtol=5e-6)
+    assert np.min(np.diag(L)) > 1e-4
+    np.testing.assert_allclose(gp.log_probability(y), ref.log_probability(y), rtol=1e-6)
+    z = np.random.default_rng(0).normal(size=n)
+    back = L @ gp.solver.solve_triangular(z)  # L (L^-1 z) = z to the solve's backward error
+    assert np.linalg.norm(back - z) / np.linalg.norm(z) < 1e-10
+
+
 def test_refactor_is_the_optimizer_step():
     X, y = _cases.synthetic.make_inputs(1024, 1)
     gp = GaussianProcess(1.5**2 * kernels.ExpSquared(2.5), X, diag=0.01)

@@ -565,7 +565,9 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
     } else {
       g.nblk = g.tm * g.tn;
     }
-    hipLaunchKernelGGL((gemm_nt_small_kernel<T>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
+    // holders parked (tgp_ctx::reserve_cus): padded so that no tile workgroup fits beside one
+    const size_t pad_s = (ctx->hold_active && sizeof(T) == 8) ? UPDATE_LDS - 4 * BK * S_LD * sizeof(T) : 0;
+    hipLaunchKernelGGL((gemm_nt_small_kernel<T>), dim3((unsigned)g.nblk), dim3(256), pad_s, st, g);
     TGP_HIP_TRY(hipGetLastError());
     return TGP_OK;
   }
@@ -580,10 +582,11 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
     g.nblk = g.tm * g.tn;
   }
   g.skip00 = (role == 5);
+  const size_t pad = (ctx->hold_active && sizeof(T) == 8) ? UPDATE_LDS - 4 * BK * LDS_LD * sizeof(T) : 0;
   if (role == 0)
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), pad, st, g);
   else
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3((unsigned)g.nblk), dim3(256), pad, st, g);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
