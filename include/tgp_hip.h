@@ -98,8 +98,6 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "first_split"       blocks of a panel after which its share of the next block-column
  *                       update is issued early, beside the panel's last blocks (default 5; 0 off)
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
- *   "inpanel_big_min_tiles"  in-panel updates (K = 128) of at least this many 128x128 tiles use
- *                       the 128x128-tile kernel instead of 64x64 tiles (0: never)
  *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming
  *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block
  *   "keep_grad_buffers" 1: tgp_solver_grad keeps its two N^2 work matrices between calls */

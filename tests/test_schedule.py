@@ -71,7 +71,7 @@ def accesses(rec, T):
             for ti in range(m):
                 if lower and ti < tj:
                     continue
-                if role in (3, 5) and ti == 0 and tj == 0:
+                if role == 3 and ti == 0 and tj == 0:
                     continue  # folded into the next potf2
                 R.add(("A", cr + ti, cc + tj)); W.add(("A", cr + ti, cc + tj))
         R |= {("A", ar + ti, ac + kk) for ti in range(m) for kk in range(k)}

@@ -150,9 +150,6 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->solve_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->update_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->asm_stream, hipStreamNonBlocking, lo));
-  TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->hold_stream, hipStreamNonBlocking, hi));
-  TGP_HIP_TRY(hipMalloc((void**)&ctx->d_hold, sizeof(int32_t)));
-  TGP_HIP_TRY(hipMemset(ctx->d_hold, 0, sizeof(int32_t)));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_e, hipEventDisableTiming));
@@ -186,13 +183,6 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
     hipStreamSynchronize(ctx->asm_stream);
     hipStreamDestroy(ctx->asm_stream);
   }
-  tgp::release_cus(ctx);
-  hipStreamSynchronize(ctx->stream);
-  if (ctx->hold_stream) {
-    hipStreamSynchronize(ctx->hold_stream);
-    hipStreamDestroy(ctx->hold_stream);
-  }
-  if (ctx->d_hold) hipFree(ctx->d_hold);
   if (ctx->ev_asm) hipEventDestroy(ctx->ev_asm);
   if (ctx->ev_d) hipEventDestroy(ctx->ev_d);
   if (ctx->ev_e) hipEventDestroy(ctx->ev_e);
@@ -225,8 +215,6 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "first_small_tiles")) slot = &ctx->first_small_tiles;
   else if (!strcmp(key, "keep_grad_buffers")) slot = &ctx->keep_grad_buffers;
   else if (!strcmp(key, "stream_trsv")) slot = &ctx->stream_trsv;
-  else if (!strcmp(key, "reserve_cus")) slot = &ctx->reserve_cus;
-  else if (!strcmp(key, "inpanel_big_min_tiles")) slot = &ctx->inpanel_big_min_tiles;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)
     TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);
@@ -502,7 +490,6 @@ static int factor_impl(tgp_solver* s, const tgp_kop* prog, int nops, const void*
     ctx->asm_pending = false;
     ctx->ev_used = 0;
     s->factored = false;
-    tgp::release_cus(ctx);
     for (hipStream_t q : {ctx->asm_stream, ctx->panel_stream, ctx->update_stream, ctx->solve_stream,
                           ctx->stream})
       if (q) (void)hipStreamSynchronize(q);

@@ -109,15 +109,10 @@ __device__ long long g_potf2_stamps[64];
 #define POTF2_STAMP(i) do {} while (0)
 #endif
 
-// The body is shared by two kernels that differ only in their register budget:
-//   potf2_kernel       waves_per_eu(4): at most 128 VGPRs, so that two potf2 waves fit on a SIMD
-//                      beside one wave of the trailing-update GEMM (238 VGPRs) -- otherwise potf2
-//                      waits for the whole update to drain;
-//   potf2_solo_kernel  (reserve_cus > 0) pinned to 152 VGPRs: two of its waves do NOT fit beside a
-//                      GEMM wave (2 x 152 + 240 > 512), so it can only start on a CU without MFMA
-//                      tiles -- the CUs the holders keep free -- and runs there alone.
+// waves_per_eu(4): at most 128 VGPRs, so that two potf2 waves fit on a SIMD beside one wave of the
+// trailing-update GEMM (238 VGPRs) -- otherwise potf2 waits for the whole update to drain.
 template <typename T, bool FOLD>
-__device__ __forceinline__ void potf2_body(T* __restrict__ A, int64_t ld,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void potf2_kernel(T* __restrict__ A, int64_t ld,
                                                     T* __restrict__ dinv,
                                                     int32_t* __restrict__ info,
                                                     int32_t pivot_base,
@@ -394,39 +389,6 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, int64_t ld,
   // column blocks 0..6 went out while later steps ran; the last one now, a slice per wave
   store_strip(7, 4 * w, 4 * w + 4);
   POTF2_STAMP(34);
-}
-
-template <typename T, bool FOLD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void potf2_kernel(
-    T* __restrict__ A, int64_t ld, T* __restrict__ dinv, int32_t* __restrict__ info,
-    int32_t pivot_base, const T* __restrict__ Xp, int64_t ldx) {
-  potf2_body<T, FOLD>(A, ld, dinv, info, pivot_base, Xp, ldx);
-}
-template <typename T, bool FOLD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) void potf2_solo_kernel(
-    T* __restrict__ A, int64_t ld, T* __restrict__ dinv, int32_t* __restrict__ info,
-    int32_t pivot_base, const T* __restrict__ Xp, int64_t ldx) {
-  asm volatile("; potf2_solo: register budget marker" ::: "v150");  // allocation >= 152
-  potf2_body<T, FOLD>(A, ld, dinv, info, pivot_base, Xp, ldx);
-}
-
-// One wave that does nothing but own 86 KiB of LDS until it is released (or a time-out: a lost
-// release must never wedge the GPU).
-__global__ __launch_bounds__(64) void cu_holder_kernel(const int32_t* __restrict__ flag, int32_t epoch,
-                                                       long long max_ticks) {
-  extern __shared__ __attribute__((aligned(16))) char held[];
-  const long long t0 = wall_clock64();
-  if (threadIdx.x == 0) {
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-      __builtin_amdgcn_s_sleep(127);
-      __builtin_amdgcn_s_sleep(127);
-      if (wall_clock64() - t0 > max_ticks) break;
-    }
-    if (epoch == -12345) held[0] = 1;  // never true: keeps the allocation referenced
-  }
-}
-__global__ void set_word_kernel(int32_t* p, int32_t v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // dinv for an existing factor: one thread per (16-block, column)
@@ -985,22 +947,12 @@ int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_
     trace_push(ctx, 1, st, trace_off(ctx, A), trace_off(ctx, Xp), ld);
     return TGP_OK;
   }
-  const bool solo = ctx->hold_active && sizeof(T) == 8;
-  if (Xp != nullptr) {
-    if (solo)
-      hipLaunchKernelGGL((potf2_solo_kernel<T, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                         pivot_base, Xp, ldx);
-    else
-      hipLaunchKernelGGL((potf2_kernel<T, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                         pivot_base, Xp, ldx);
-  } else {
-    if (solo)
-      hipLaunchKernelGGL((potf2_solo_kernel<T, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                         pivot_base, Xp, ldx);
-    else
-      hipLaunchKernelGGL((potf2_kernel<T, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                         pivot_base, Xp, ldx);
-  }
+  if (Xp != nullptr)
+    hipLaunchKernelGGL((potf2_kernel<T, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
+                       pivot_base, Xp, ldx);
+  else
+    hipLaunchKernelGGL((potf2_kernel<T, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
+                       pivot_base, Xp, ldx);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -1018,24 +970,6 @@ int launch_trsm(tgp_ctx* ctx, hipStream_t st, int64_t m, const T* L, int64_t ldl
                      ldl, dinv, B, ldb);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
-}
-
-int reserve_cus(tgp_ctx* ctx) {
-  if (ctx->trace || ctx->reserve_cus <= 0 || ctx->hold_stream == nullptr || ctx->hold_active) return TGP_OK;
-  ctx->hold_epoch += 1;
-  // 100 MHz wall clock: 30 s is far beyond any factorisation this library can hold in memory
-  hipLaunchKernelGGL(cu_holder_kernel, dim3((unsigned)ctx->reserve_cus), dim3(64), HOLDER_LDS, ctx->hold_stream,
-                     ctx->d_hold, ctx->hold_epoch, 3000000000LL);
-  TGP_HIP_TRY(hipGetLastError());
-  ctx->hold_active = true;
-  return TGP_OK;
-}
-
-void release_cus(tgp_ctx* ctx) {
-  if (!ctx->hold_active) return;
-  hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_hold, ctx->hold_epoch);
-  (void)hipGetLastError();
-  ctx->hold_active = false;
 }
 
 template <typename T>
@@ -1119,12 +1053,8 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
     if (y != nullptr || upd) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
     if (upd) {
       TGP_TRY(st_wait(ctx, S3, ctx->ev_d));
-      // 64x64 tiles spread a short update over the chip; with several hundred 128x128 tiles the
-      // big-tile kernel (one round, 8 k-steps) is the faster of the two
-      const int64_t big_tiles = (mb / TILE) * (nc / TILE) - (nc / TILE) * (nc / TILE - 1) / 2;
-      const int urole = (ctx->inpanel_big_min_tiles > 0 && big_tiles >= ctx->inpanel_big_min_tiles) ? 5 : 3;
       TGP_TRY(launch_gemm_nt<T>(ctx, S3, mb, nc, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
-                                A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, urole));
+                                A + (j0 + TILE) * ld + j0 + TILE, ld, 1, 0, 3));
       TGP_TRY(ev_record(ctx, ctx->ev_e, S3));
     }
     if (y != nullptr) {
@@ -1154,11 +1084,6 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   if (NB < TILE) NB = TILE;
   NB = NB / TILE * TILE;
   if (!ctx->trace) TGP_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int32_t), S0));
-  if (n > NB) TGP_TRY(reserve_cus(ctx));
-  struct HoldGuard {  // every exit path releases the holders
-    tgp_ctx* c;
-    ~HoldGuard() { release_cus(c); }
-  } hold_guard{ctx};
   const bool prof_on = ctx->profile != 0 && !ctx->trace;
   std::vector<ProfSpan> spans;
   ctx->ev_used = 0;
@@ -1283,7 +1208,6 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     TGP_TRY(st_wait(ctx, S0, ctx->ev_c));
   }
   int32_t info = 0;
-  release_cus(ctx);
   if (!ctx->trace) {
     TGP_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, S0));
     TGP_HIP_TRY(hipStreamSynchronize(S0));

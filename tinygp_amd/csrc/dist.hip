@@ -271,7 +271,6 @@ int tgp_dist_begin(tgp_dist* h, const void* resid_host) {
       TGP_HIP_TRY(hipMemsetAsync((char*)h->x + size_t(h->n) * es, 0, size_t(h->npad - h->n) * es, ctx->stream));
   }
   for (bool& b : h->ev_solve_set) b = false;
-  TGP_TRY(reserve_cus(ctx));  // no-op unless the context option is set; released by tgp_dist_end
   return TGP_OK;
 }
 
@@ -364,7 +363,6 @@ int tgp_dist_end(tgp_dist* h, int32_t* info, double* sumsq, double* logdet_half)
   hipStream_t S0 = ctx->stream;
   for (int i = 0; i < tgp_dist::NSLOT; ++i)
     if (h->ev_solve_set[i]) TGP_HIP_TRY(hipStreamWaitEvent(S0, h->ev_solve[i], 0));
-  release_cus(ctx);
   TGP_TRY(ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
     if (h->solving) TGP_TRY(launch_sum_squares_at<T>(ctx, S0, h->npad, (const T*)h->x, h->d_logdet + h->nblk));

@@ -136,8 +136,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     gt = tj;
   }
 
-  if (g.skip00 && ti == 0 && tj == 0) return;  // that tile's update is folded into the next potf2
-
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1;
   const int64_t i0 = int64_t(ti) * BM, j0 = int64_t(tj) * BN;
@@ -551,7 +549,6 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   g.skip00 = 0;
   g.dG = g.dr = g.dl0 = g.dnbt = 0;
   TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");
-  TGP_ARG_CHECK(role != 5 || (mode == 0 && lower != 0), "role 5 is a lower in-panel update");
   // short-K updates, and (role 4) a latency-bound update with too few big tiles to fill the chip
   if ((((role == 1 || role == 3) && k <= 256) || role == 4) && (mode == 0 || mode == 1)) {
     g.skip00 = (role == 3);
@@ -565,9 +562,7 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
     } else {
       g.nblk = g.tm * g.tn;
     }
-    // holders parked (tgp_ctx::reserve_cus): padded so that no tile workgroup fits beside one
-    const size_t pad_s = (ctx->hold_active && sizeof(T) == 8) ? UPDATE_LDS - 4 * BK * S_LD * sizeof(T) : 0;
-    hipLaunchKernelGGL((gemm_nt_small_kernel<T>), dim3((unsigned)g.nblk), dim3(256), pad_s, st, g);
+    hipLaunchKernelGGL((gemm_nt_small_kernel<T>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
     TGP_HIP_TRY(hipGetLastError());
     return TGP_OK;
   }
@@ -581,12 +576,10 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   } else {
     g.nblk = g.tm * g.tn;
   }
-  g.skip00 = (role == 5);
-  const size_t pad = (ctx->hold_active && sizeof(T) == 8) ? UPDATE_LDS - 4 * BK * LDS_LD * sizeof(T) : 0;
   if (role == 0)
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), pad, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3((unsigned)g.nblk), dim3(256), pad, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }

@@ -80,10 +80,6 @@ struct tgp_ctx {
   hipStream_t solve_stream = nullptr;  // forward substitution overlapped with the factorisation
   hipStream_t update_stream = nullptr;  // in-panel updates beside the next potf2
   hipStream_t asm_stream = nullptr;     // assembly of the columns right of the first panel
-  hipStream_t hold_stream = nullptr;    // the CU-holder kernel (option reserve_cus)
-  int32_t* d_hold = nullptr;            // holder release word
-  int32_t hold_epoch = 0;
-  bool hold_active = false;
 
   hipEvent_t ev_asm = nullptr;          // ... finished (potrf waits before its first update)
   bool asm_pending = false;
@@ -92,13 +88,6 @@ struct tgp_ctx {
   int64_t lookahead = 1;
   int64_t profile = 0;
   int64_t first_split = 5;  // blocks of a panel after which its share of the next block-column update is issued early (0: off)
-  // `reserve_cus` = R > 0 parks R one-wave "holder" workgroups with 86 KiB of LDS for the duration
-  // of a factorisation.  While they are parked every MFMA tile kernel is launched with its LDS
-  // padded to 78 KiB (two still fit on a CU, none fits beside a holder) and potf2 in a build
-  // whose two waves per SIMD do not fit beside a 240-VGPR GEMM wave: R CUs carry no MFMA tiles,
-  // potf2 (72 KiB) starts there at once and runs alone.
-  int64_t reserve_cus = 0;
-  int64_t inpanel_big_min_tiles = 0;  // in-panel updates with at least this many 128x128 tiles run on the big-tile kernel (0: never)
   int64_t stream_trsv = 1;  // forward solves on a resident factor: one streaming launch (0: one launch pair per block)
   int64_t keep_grad_buffers = 0;  // tgp_solver_grad keeps its two N^2 work matrices between calls
   int64_t first_small_tiles = 1100;  // look-ahead block-column updates up to this many tiles use 64x64 tiles
@@ -169,10 +158,6 @@ inline int st_wait(tgp_ctx* ctx, hipStream_t st, hipEvent_t ev) {
 
 int ensure_dinv(tgp_ctx* ctx, size_t bytes);
 int ensure_work(tgp_ctx* ctx, size_t bytes);
-int reserve_cus(tgp_ctx* ctx);    // park the holders (no-op unless the option is set)
-void release_cus(tgp_ctx* ctx);   // asynchronous, on the main stream behind everything queued; idempotent
-constexpr size_t HOLDER_LDS = 86 * 1024;
-constexpr size_t UPDATE_LDS = 78 * 1024;
 
 // ---- launchers (all async on the given stream) -------------------------------------
 template <typename T>
@@ -196,8 +181,7 @@ int launch_kmat_gemv(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int 
 // C (m x n) = beta*C + alpha*A*B^T ; mode 0: C -= A B^T ; mode 1: C = A B^T.
 // role: 0 = trailing update (profiled as the dominant kernel), 1 = everything else (64x64
 // tiles when k <= 256), 3 = in-panel update that skips the first 128x128 diagonal tile (potf2
-// folds it in), 4 = 64x64 tiles at any k (latency-bound look-ahead block-column update),
-// 5 = role 3 on 128x128 tiles (an in-panel update with enough tiles to fill the chip).
+// folds it in), 4 = 64x64 tiles at any k (latency-bound look-ahead block-column update).
 template <typename T>
 int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k, const T* A,
                    int64_t lda, const T* B, int64_t ldb, T* C, int64_t ldc, int lower, int mode,
