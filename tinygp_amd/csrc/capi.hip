@@ -1,5 +1,6 @@
 // capi.hip -- the extern "C" boundary of libtgp_hip.so (include/tgp_hip.h).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -150,12 +151,19 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->solve_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->update_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->asm_stream, hipStreamNonBlocking, lo));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_e, hipEventDisableTiming));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+  // The events only order kernels of THIS device against each other: a device-scope release is
+  // enough (the default is a system-scope release -- an L2 write-back per record -- between every
+  // two kernels of the panel chain).  TGP_EVENT_SCOPE=system restores the default.
+  unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
+  if (const char* e = getenv("TGP_EVENT_SCOPE"))
+    if (!strcmp(e, "system")) evf = hipEventDisableTiming;
+  ctx->event_flags = evf;
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_asm, evf));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_d, evf));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_e, evf));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, evf));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, evf));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_b, evf));
   TGP_HIP_TRY(hipMalloc(&ctx->d_scal, 16 * sizeof(double)));
   TGP_HIP_TRY(hipMalloc(&ctx->d_info, sizeof(int32_t)));
   hipDeviceProp_t prop;

@@ -83,6 +83,7 @@ struct tgp_ctx {
 
   hipEvent_t ev_asm = nullptr;          // ... finished (potrf waits before its first update)
   bool asm_pending = false;
+  unsigned event_flags = hipEventDisableTiming;  // flags of every inter-stream event (capi.hip)
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_e = nullptr;
   int64_t nb_outer = 1024;  // measured best for N = 4k .. 32k (profiles/r01_f_nb_sweep.txt)
   int64_t lookahead = 1;
