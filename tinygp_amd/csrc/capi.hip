@@ -151,19 +151,12 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->solve_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->update_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->asm_stream, hipStreamNonBlocking, lo));
-  // The events only order kernels of THIS device against each other: a device-scope release is
-  // enough (the default is a system-scope release -- an L2 write-back per record -- between every
-  // two kernels of the panel chain).  TGP_EVENT_SCOPE=system restores the default.
-  unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
-  if (const char* e = getenv("TGP_EVENT_SCOPE"))
-    if (!strcmp(e, "system")) evf = hipEventDisableTiming;
-  ctx->event_flags = evf;
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_asm, evf));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_d, evf));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_e, evf));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, evf));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, evf));
-  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_b, evf));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_e, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
   TGP_HIP_TRY(hipMalloc(&ctx->d_scal, 16 * sizeof(double)));
   TGP_HIP_TRY(hipMalloc(&ctx->d_info, sizeof(int32_t)));
   hipDeviceProp_t prop;
@@ -223,6 +216,7 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "first_small_tiles")) slot = &ctx->first_small_tiles;
   else if (!strcmp(key, "keep_grad_buffers")) slot = &ctx->keep_grad_buffers;
   else if (!strcmp(key, "stream_trsv")) slot = &ctx->stream_trsv;
+  else if (!strcmp(key, "gemm8")) slot = &ctx->gemm8;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)
     TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);

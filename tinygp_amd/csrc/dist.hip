@@ -178,7 +178,7 @@ int tgp_dist_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X
   D_TRY(hipMalloc(&h->A, std::max<size_t>(size_t(h->npad) * size_t(h->nloc * nb) * es, 8)));
   D_TRY(hipMalloc(&h->dinv, size_t(h->npad / TILE) * 2048 * es));
   D_TRY(hipMalloc((void**)&h->d_logdet, size_t(h->nblk + 1) * sizeof(double)));
-  for (auto& e : h->ev_solve) D_TRY(hipEventCreateWithFlags(&e, ctx->event_flags));
+  for (auto& e : h->ev_solve) D_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   D_TRY(hipMemcpyAsync(h->X, X_host, size_t(n) * d * es, hipMemcpyHostToDevice, ctx->stream));
   D_TRY(hipMemcpyAsync(h->diag, noise_diag_host, size_t(n) * es, hipMemcpyHostToDevice, ctx->stream));
   // compacted coordinates of the owned columns (for the conditional-mean partial products)
