@@ -216,7 +216,6 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "first_small_tiles")) slot = &ctx->first_small_tiles;
   else if (!strcmp(key, "keep_grad_buffers")) slot = &ctx->keep_grad_buffers;
   else if (!strcmp(key, "stream_trsv")) slot = &ctx->stream_trsv;
-  else if (!strcmp(key, "gemm8")) slot = &ctx->gemm8;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)
     TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);

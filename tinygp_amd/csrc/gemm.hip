@@ -307,116 +307,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
   }
 }
 
-// ---- eight-wave variant of the fp64 trailing update -----------------------------------------
-// Same 128 x 128 x 16 tile, same LDS images and MFMA instruction, but EIGHT waves of 32 rows x 64
-// columns (64 accumulator VGPRs instead of 128) under a 128-VGPR cap: two workgroups per CU put
-// FOUR waves on every SIMD.  While one workgroup sits in its epilogue (the C read-modify-write,
-// ~10 % of a K = 1024 tile and pure memory latency) the other workgroup's two waves per SIMD
-// still cover each other's LDS latencies and keep the matrix pipe fed; with the four-wave
-// kernel above the lone remaining wave per SIMD cannot, and the epilogue time is simply lost
-// (measured: t = 0.92 ms + 3.94 ms K/512 on a 16384^2 update, profiles/r01_b).
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt8_kernel(GemmArgs<double> g) {
-  using T = double;
-  using v2_t = double __attribute__((ext_vector_type(2)));
-  __shared__ __attribute__((aligned(16))) T sA[2][BK * LDS_LD];
-  __shared__ __attribute__((aligned(16))) T sB[2][BK * LDS_LD];
-  int bid = blockIdx.x;
-  {
-    const int nx = 8, q = g.nblk / nx, r = g.nblk % nx;
-    const int xcd = bid % nx, idx = bid / nx;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int ti, tj, gt;
-  if (g.dG > 0) {
-    decode_tile_dist<T>(bid, g, ti, tj, gt);
-  } else {
-    decode_tile(bid, g.tm, g.tn, g.lower, ti, tj);
-    gt = tj;
-  }
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 1, wc = w & 1;  // 4 x 2 waves: rows [32 wr, +32), columns [64 wc, +64)
-  const int64_t i0 = int64_t(ti) * BM, j0 = int64_t(tj) * BN;
-  // staging: wave w loads k-rows {w, w + 8}; a lane loads 2 consecutive rows
-  const T* Ag = g.A + i0 + lane * 2;
-  const T* Bg = g.B + int64_t(gt) * BN + lane * 2;
-  v2_t ra[2], rb[2];
-  auto load_global = [&](int kt) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int64_t kk = int64_t(kt) * BK + w + 8 * r;
-      ra[r] = *reinterpret_cast<const v2_t*>(Ag + kk * g.lda);
-      rb[r] = *reinterpret_cast<const v2_t*>(Bg + kk * g.ldb);
-    }
-  };
-  auto store_lds = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int kk = w + 8 * r;
-      *reinterpret_cast<v2_t*>(&sA[buf][kk * LDS_LD + lane * 2]) = ra[r];
-      *reinterpret_cast<v2_t*>(&sB[buf][kk * LDS_LD + lane * 2]) = rb[r];
-    }
-  };
-  const int nkt = g.k / BK;
-  const int lrow = lane & 15, lk = lane >> 4;
-  const int lq = (lane >> 2) & 3, lj = lane & 3;
-  T* Cb = g.C + (j0 + wc * 64) * g.ldc + i0 + wr * 32;
-  // acc[a][b][t], lane (i, q, j): C[row = b*16 + 4((q+t)&3) + j][col = a*16 + 4q + i] of the wave's 32 x 64
-  double acc[4][2][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[a][b][t] = 0.0;
-  int rot[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) rot[t] = 4 * ((lq + t) & 3) + lj;
-
-  load_global(0);
-  store_lds(0);
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_global(kt + 1);
-    const T* pa = &sB[buf][lk * LDS_LD + wc * 64 + lrow];
-    const T* pb = &sA[buf][lk * LDS_LD + wr * 32];
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      double aop[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * LDS_LD + a * 16];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        double bop[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bop[t] = pb[ks * 4 * LDS_LD + b * 16 + rot[t]];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[a][b][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aop[a], bop[t], acc[a][b][t], 0, 0, 0);
-      }
-    }
-    if (kt + 1 < nkt) store_lds(buf ^ 1);
-    __syncthreads();
-  }
-  // epilogue: C -= acc, four batches of 8 independent loads (the register budget is 128)
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    T* col = Cb + int64_t(a * 16 + 4 * lq + lk) * g.ldc;
-    double c[2][4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) c[b][t] = col[b * 16 + rot[t]];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) col[b * 16 + rot[t]] = c[b][t] - acc[a][b][t];
-  }
-}
-
 // ---- small-tile variant -----------------------------------------------------------------
 // 64 x 64 x 16 tiles, 4 waves of 32 x 32.  For the short-K updates on the factorisation's
 // critical path (in-panel updates, K = 128): a 128 x 128 tile there is ONE long serial
@@ -686,13 +576,6 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   } else {
     g.nblk = g.tm * g.tn;
   }
-  if constexpr (sizeof(T) == 8) {
-    if (role == 0 && mode == 0 && ctx->gemm8 != 0) {
-      hipLaunchKernelGGL(gemm_nt8_kernel, dim3((unsigned)g.nblk), dim3(512), 0, st, g);
-      TGP_HIP_TRY(hipGetLastError());
-      return TGP_OK;
-    }
-  }
   if (role == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
   else
@@ -728,13 +611,6 @@ int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb
   }
   TGP_ARG_CHECK(total < (int64_t(1) << 31), "gemm_nt_dist: too many tiles");
   g.nblk = int(total);
-  if constexpr (sizeof(T) == 8) {
-    if (ctx->gemm8 != 0) {
-      hipLaunchKernelGGL(gemm_nt8_kernel, dim3((unsigned)g.nblk), dim3(512), 0, st, g);
-      TGP_HIP_TRY(hipGetLastError());
-      return TGP_OK;
-    }
-  }
   hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;

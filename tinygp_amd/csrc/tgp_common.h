@@ -88,7 +88,6 @@ struct tgp_ctx {
   int64_t lookahead = 1;
   int64_t profile = 0;
   int64_t first_split = 5;  // blocks of a panel after which its share of the next block-column update is issued early (0: off)
-  int64_t gemm8 = 0;  // fp64 trailing update on the eight-wave kernel (gemm.hip, gemm_nt8_kernel)
   int64_t stream_trsv = 1;  // forward solves on a resident factor: one streaming launch (0: one launch pair per block)
   int64_t keep_grad_buffers = 0;  // tgp_solver_grad keeps its two N^2 work matrices between calls
   int64_t first_small_tiles = 1100;  // look-ahead block-column updates up to this many tiles use 64x64 tiles
