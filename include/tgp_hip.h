@@ -132,6 +132,11 @@ int tgp_kdiag(tgp_ctx* ctx, int dtype, const tgp_kop* prog, int nops, int64_t n,
  * Replaces Kernel.matmul (kernels/base.py:68-82) as used by gp.py:357. */
 int tgp_kmat_gemv(tgp_ctx* ctx, int dtype, const tgp_kop* prog, int nops, int64_t n1, int64_t n2,
                   int32_t d, const void* X1, const void* X2, const void* v, void* out);
+/* the same for nv right-hand sides at once (Kernel.matmul with a 2-D y, kernels/base.py:82):
+ * V (nv, n2) and out (nv, n1) row-major device arrays; every kernel value is evaluated once per
+ * group of 8 columns */
+int tgp_kmat_gemv_multi(tgp_ctx* ctx, int dtype, const tgp_kop* prog, int nops, int64_t n1, int64_t n2,
+                        int32_t d, const void* X1, const void* X2, const void* V, int64_t nv, void* out);
 
 /* K4: in-place lower Cholesky of the column-major n x n matrix A (n % TGP_TILE == 0);
  * replaces jax.scipy.linalg.cholesky(K, lower=True) at solvers/direct.py:53.

@@ -79,6 +79,14 @@ def test_kernel_scalar_protocol_and_matmul():
     np.testing.assert_allclose(k.matmul(x1, x2, y), ko(x1, x2) @ y, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(k.matmul(x1, y[:, 0]), ko(x1, x1) @ y[:, 0], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(k.matmul(x1, y=y[:, 1]), ko(x1, x1) @ y[:, 1], rtol=1e-12, atol=1e-12)
+    # more right-hand sides than one pass of the fused kernel carries (8), ragged sizes, 3-D y
+    rng = np.random.default_rng(11)
+    a, b = rng.normal(size=(300, 2)), rng.normal(size=(517, 2))
+    Y = rng.normal(size=(517, 11))
+    k2, k2o = kernels.Matern52(0.9) + 0.3 * kernels.ExpSquared(1.7), o.Matern52(0.9) + 0.3 * o.ExpSquared(1.7)
+    np.testing.assert_allclose(k2.matmul(a, b, Y), k2o(a, b) @ Y, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(k2.matmul(a, b, Y.reshape(517, 11, 1)), (k2o(a, b) @ Y).reshape(300, 11, 1),
+                               rtol=1e-12, atol=1e-12)
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 2e-5)])

@@ -102,19 +102,17 @@ def kmat_gemv(prog, X1, X2, v, *, ctx=None) -> np.ndarray:
         raise ValueError("dimension mismatch between X2 and y in Kernel.matmul")
     n1, n2, d = P1.shape[0], P2.shape[0], P1.shape[1]
     cols = np.ascontiguousarray(v.reshape(n2, -1).T, dtype=dt)  # (R, n2)
-    res = np.empty((cols.shape[0], n1), dtype=dt)
+    nv = cols.shape[0]
+    if n1 == 0 or nv == 0:
+        return np.zeros((n1,) + v.shape[1:], dtype=dt)
     kp, nops = _ffi.as_kprog(prog)
-    d1, d2 = ctx.upload(P1), ctx.upload(P2)
-    dv, do = ctx.malloc(n2 * dt.itemsize), ctx.malloc(n1 * dt.itemsize)
-    lib = _ffi.lib()
-    try:
-        for r in range(cols.shape[0]):
-            _ffi.check(lib.tgp_memcpy_h2d(ctx.handle, C.c_void_p(dv), _ffi.ptr(cols[r]),
-                                          cols[r].nbytes), "tgp_memcpy_h2d")
-            _ffi.check(lib.tgp_kmat_gemv(ctx.handle, _ffi.dtype_code(dt), kp, nops, n1, n2, d,
-                                         C.c_void_p(d1), C.c_void_p(d2), C.c_void_p(dv),
-                                         C.c_void_p(do)), "tgp_kmat_gemv")
-            res[r] = ctx.download(do, (n1,), dt)
+    d1, d2, dv = ctx.upload(P1), ctx.upload(P2), ctx.upload(cols)
+    do = ctx.malloc(nv * n1 * dt.itemsize)
+    try:  # all R columns in one call: every kernel value is evaluated once per group of 8 columns
+        _ffi.check(_ffi.lib().tgp_kmat_gemv_multi(ctx.handle, _ffi.dtype_code(dt), kp, nops, n1, n2, d,
+                                                  C.c_void_p(d1), C.c_void_p(d2), C.c_void_p(dv), nv,
+                                                  C.c_void_p(do)), "tgp_kmat_gemv_multi")
+        res = ctx.download(do, (nv, n1), dt)
     finally:
         ctx.free(d1), ctx.free(d2), ctx.free(dv), ctx.free(do)
     return res.T.reshape((n1,) + v.shape[1:])

@@ -68,6 +68,7 @@ SIGNATURES = {
     "tgp_kmat": [_vp, _int, _pkop, _int, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int],
     "tgp_kdiag": [_vp, _int, _pkop, _int, _i64, _i32, _vp, _vp],
     "tgp_kmat_gemv": [_vp, _int, _pkop, _int, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
+    "tgp_kmat_gemv_multi": [_vp, _int, _pkop, _int, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp],
     "tgp_potrf": [_vp, _int, _i64, _vp, _i64, _pi32],
     "tgp_trsv": [_vp, _int, _i64, _vp, _i64, _int, _vp],
     "tgp_trsm_right_lt": [_vp, _int, _i64, _i64, _vp, _i64, _vp, _i64],

@@ -308,6 +308,18 @@ int tgp_kmat_gemv(tgp_ctx* ctx, int dtype, const tgp_kop* prog, int nops, int64_
   });
 }
 
+int tgp_kmat_gemv_multi(tgp_ctx* ctx, int dtype, const tgp_kop* prog, int nops, int64_t n1, int64_t n2,
+                        int32_t d, const void* X1, const void* X2, const void* V, int64_t nv, void* out) {
+  CTX_GUARD(ctx);
+  KProg kp;
+  TGP_TRY(make_kprog(prog, nops, &kp));
+  TGP_ARG_CHECK(nv >= 1 && X1 && X2 && V && out, "kmat_gemv_multi: bad argument");
+  return dispatch(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_kmat_gemv_multi<T>(ctx, kp, n1, n2, d, (const T*)X1, (const T*)X2, (const T*)V, nv, (T*)out);
+  });
+}
+
 int tgp_potrf(tgp_ctx* ctx, int dtype, int64_t n, void* A, int64_t ld, int32_t* info) {
   CTX_GUARD(ctx);
   TGP_ARG_CHECK(A != nullptr && n >= 0, "potrf: null matrix");

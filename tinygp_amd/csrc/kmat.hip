@@ -8,6 +8,8 @@
 // Built with -ffp-contract=off: the scalar formulas below keep the reference's operation
 // order (kernels/stationary.py:76-235, kernels/distance.py:41-59) so entries agree with a
 // NumPy evaluation to the last ulp or two (libm-vs-ocml exp is the only difference).
+#include <algorithm>
+
 #include "tgp_common.h"
 
 namespace tgp {
@@ -290,30 +292,37 @@ __global__ __launch_bounds__(256) void kdiag_kernel(KProg kp, int64_t n, const T
   out[i] = v;
 }
 
-// Fused K9: partial[chunk][i] = sum_{j in chunk} k(X1[i], X2[j]) v[j].  One lane per row i,
-// X2/v chunks staged through LDS and broadcast-read.
-constexpr int GV_ROWS = 256, GV_JB = 256;
+// Fused K9: partial[chunk][r][i] = sum_{j in chunk} k(X1[i], X2[j]) v[r][j] for up to GV_NV
+// right-hand sides at once (every kernel value is evaluated ONCE per pass, whatever the number
+// of columns of `y` in Kernel.matmul).  One lane per row i, X2 / v chunks staged through LDS and
+// broadcast-read.
+constexpr int GV_ROWS = 256, GV_JB = 256, GV_NV = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void kmat_gemv_kernel(KProg kp, int64_t n1, int64_t n2, int d,
                                                         const T* __restrict__ X1,
                                                         const T* __restrict__ X2,
-                                                        const T* __restrict__ v,
+                                                        const T* __restrict__ v, int nv,
                                                         T* __restrict__ partial, int64_t jchunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sx = reinterpret_cast<T*>(smem);  // [GV_JB][d]
-  T* sv = sx + GV_JB * d;              // [GV_JB]
+  T* sv = sx + GV_JB * d;              // [GV_JB][GV_NV]
   const int64_t i = int64_t(blockIdx.x) * GV_ROWS + threadIdx.x;
   const int64_t j0 = int64_t(blockIdx.y) * jchunk;
   const int64_t j1 = (j0 + jchunk < n2) ? j0 + jchunk : n2;
   T xi[TGP_MAX_DIM];
 #pragma unroll
   for (int t = 0; t < TGP_MAX_DIM; ++t) xi[t] = (t < d && i < n1) ? X1[i * d + t] : T(0);
-  T acc = 0;
+  T acc[GV_NV];
+#pragma unroll
+  for (int r = 0; r < GV_NV; ++r) acc[r] = 0;
   for (int64_t jb = j0; jb < j1; jb += GV_JB) {
     const int cnt = int((j1 - jb < GV_JB) ? (j1 - jb) : GV_JB);
     __syncthreads();
     for (int t = threadIdx.x; t < cnt * d; t += 256) sx[t] = X2[jb * d + t];
-    for (int t = threadIdx.x; t < cnt; t += 256) sv[t] = v[jb + t];
+    for (int t = threadIdx.x; t < cnt * GV_NV; t += 256) {
+      const int jj = t / GV_NV, r = t % GV_NV;
+      sv[t] = (r < nv) ? v[int64_t(r) * n2 + jb + jj] : T(0);
+    }
     __syncthreads();
     for (int jj = 0; jj < cnt; ++jj) {
       T r1 = 0, r2 = 0;
@@ -325,21 +334,26 @@ __global__ __launch_bounds__(256) void kmat_gemv_kernel(KProg kp, int64_t n1, in
           r2 += dx * dx;
         }
       }
-      acc += eval_kprog<T>(kp, r1, r2) * sv[jj];
+      const T kv = eval_kprog<T>(kp, r1, r2);
+#pragma unroll
+      for (int r = 0; r < GV_NV; ++r) acc[r] += kv * sv[jj * GV_NV + r];
     }
   }
-  if (i < n1) partial[int64_t(blockIdx.y) * n1 + i] = acc;
+  if (i < n1)
+    for (int r = 0; r < nv; ++r) partial[(int64_t(blockIdx.y) * nv + r) * n1 + i] = acc[r];
 }
 
+// out[r][i] = sum over chunks, fixed order
 template <typename T>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t n1, int nchunks,
+__global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t n1, int nchunks, int nv,
                                                               const T* __restrict__ partial,
                                                               T* __restrict__ out) {
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int r = blockIdx.y;
   if (i >= n1) return;
   T acc = 0;
-  for (int c = 0; c < nchunks; ++c) acc += partial[int64_t(c) * n1 + i];
-  out[i] = acc;
+  for (int c = 0; c < nchunks; ++c) acc += partial[(int64_t(c) * nv + r) * n1 + i];
+  out[int64_t(r) * n1 + i] = acc;
 }
 
 }  // namespace
@@ -419,11 +433,12 @@ int launch_kdiag(tgp_ctx* ctx, const KProg& kp, int64_t n, int d, const T* X, co
   return TGP_OK;
 }
 
+// out (nv x n1, row-major) = [K(X1, X2) v_r]_r for the nv vectors v (nv x n2, row-major)
 template <typename T>
-int launch_kmat_gemv(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
-                     const T* X2, const T* v, T* out) {
+int launch_kmat_gemv_multi(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
+                           const T* X2, const T* v, int64_t nv_total, T* out) {
   TGP_ARG_CHECK(d >= 1 && d <= TGP_MAX_DIM, "input dimension must be 1..%d (got %d)", TGP_MAX_DIM, d);
-  if (n1 == 0) return TGP_OK;
+  if (n1 == 0 || nv_total == 0) return TGP_OK;
   const int64_t rb = (n1 + GV_ROWS - 1) / GV_ROWS;
   // enough column chunks to fill the chip when there are few rows of test points
   int64_t nch = (2048 + rb - 1) / rb;
@@ -435,15 +450,24 @@ int launch_kmat_gemv(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int 
   if (jchunk < GV_JB) jchunk = GV_JB;
   nch = (n2 + jchunk - 1) / jchunk;
   if (nch < 1) nch = 1;
-  TGP_TRY(ensure_work(ctx, size_t(nch) * n1 * sizeof(T)));
+  TGP_TRY(ensure_work(ctx, size_t(nch) * GV_NV * n1 * sizeof(T)));
   T* partial = static_cast<T*>(ctx->d_work);
-  const size_t shmem = size_t(GV_JB) * (d + 1) * sizeof(T);
-  hipLaunchKernelGGL((kmat_gemv_kernel<T>), dim3((unsigned)rb, (unsigned)nch), dim3(256), shmem,
-                     ctx->stream, kp, n1, n2, d, X1, X2, v, partial, jchunk);
-  hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0,
-                     ctx->stream, n1, (int)nch, partial, out);
+  const size_t shmem = size_t(GV_JB) * (d + GV_NV) * sizeof(T);
+  for (int64_t r0 = 0; r0 < nv_total; r0 += GV_NV) {
+    const int nv = int(std::min<int64_t>(GV_NV, nv_total - r0));
+    hipLaunchKernelGGL((kmat_gemv_kernel<T>), dim3((unsigned)rb, (unsigned)nch), dim3(256), shmem,
+                       ctx->stream, kp, n1, n2, d, X1, X2, v + r0 * n2, nv, partial, jchunk);
+    hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((n1 + 255) / 256), (unsigned)nv), dim3(256), 0,
+                       ctx->stream, n1, (int)nch, nv, partial, out + r0 * n1);
+  }
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
+}
+
+template <typename T>
+int launch_kmat_gemv(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
+                     const T* X2, const T* v, T* out) {
+  return launch_kmat_gemv_multi<T>(ctx, kp, n1, n2, d, X1, X2, v, 1, out);
 }
 
 template <typename T>
@@ -481,7 +505,9 @@ int launch_noise_grad(tgp_ctx* ctx, int64_t n, const T* alpha, const T* Kinv, in
                                    int, int64_t, int64_t);                                        \
   template int launch_kdiag<T>(tgp_ctx*, const KProg&, int64_t, int, const T*, const T*, T*);     \
   template int launch_kmat_gemv<T>(tgp_ctx*, const KProg&, int64_t, int64_t, int, const T*,       \
-                                   const T*, const T*, T*);
+                                   const T*, const T*, T*);                                       \
+  template int launch_kmat_gemv_multi<T>(tgp_ctx*, const KProg&, int64_t, int64_t, int, const T*, \
+                                         const T*, const T*, int64_t, T*);
 TGP_INST(float)
 TGP_INST(double)
 #undef TGP_INST

@@ -177,6 +177,9 @@ int launch_kdiag(tgp_ctx* ctx, const KProg& kp, int64_t n, int d, const T* X, co
 template <typename T>
 int launch_kmat_gemv(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
                      const T* X2, const T* v, T* out);
+template <typename T>
+int launch_kmat_gemv_multi(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2, int d, const T* X1,
+                           const T* X2, const T* v, int64_t nv, T* out);
 
 // C (m x n) = beta*C + alpha*A*B^T ; mode 0: C -= A B^T ; mode 1: C = A B^T.
 // role: 0 = trailing update (profiled as the dominant kernel), 1 = everything else (64x64
