@@ -1,46 +1,29 @@
 #!/bin/bash
-# round 2, batch 7: final evidence of the round (tests, bench lines, rocprofv3 kernel stats, PMC traffic, timelines)
+# round 2, batch 8: helper-workgroup split of the streaming solves, Kernel.matmul in one pass
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 O=$R/gpurun_out
-B="--no-cpu-baseline --no-secondary"
 {
-echo "== pytest -m gpu"; date
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8
-echo "== smoke"; date
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-echo "== bench default"; date
-timeout 600 python bench.py 2>$O/bench_c2.err | tail -1 > $O/bench_c2.json; cut -c1-400 $O/bench_c2.json
-echo "== torchrun launch line, one process"; date
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 5 --warmup 2 $B 2>/dev/null | tail -1 | cut -c1-300
-echo "== other sizes"; date
-for w in c1 n4096 n8192 n32768 c3; do timeout 300 python bench.py $B --workload $w --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_$w.json; cut -c1-260 $O/bench_$w.json; done
-echo "== block-column path at world size 1 (c2, n65536, c4)"; date
-timeout 300 python bench.py --distributed --workload c2 --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/dist_c2.json; cut -c1-300 $O/dist_c2.json
-timeout 300 python bench.py --distributed --workload n65536 --steps 2 --warmup 1 2>/dev/null | tail -1 > $O/dist_n65536.json; cut -c1-300 $O/dist_n65536.json
-timeout 600 python bench.py --distributed --workload c4 --steps 1 --warmup 1 2>$O/dist_c4.err | tail -1 > $O/dist_c4.json; cut -c1-400 $O/dist_c4.json; tail -2 $O/dist_c4.err
-echo "== adjacent paths"; date
-timeout 200 python scripts/time_paths.py 16384 4096
-echo "== rocprofv3 kernel stats (final code)"; date
+echo "== pytest -m gpu (stream_trsv=1 auto)"; date
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8
+echo "== pytest solves with the split forced"; date
+TGP_HIP_OPTIONS=stream_trsv=2 timeout 900 python -m pytest tests/test_gpu_gp.py tests/test_gpu_kernels.py -m gpu -q -x 2>&1 | tail -4
+for v in 3 2 1; do
+echo "== adjacent paths, stream_trsv=$v"; date
+TGP_HIP_OPTIONS=stream_trsv=$v timeout 200 python scripts/time_paths.py 16384 4096 | grep -E "resident|predict mean at"
+TGP_HIP_OPTIONS=stream_trsv=$v timeout 200 python scripts/time_paths.py 65536 4096 2>&1 | grep -E "resident|predict mean at"
+done
+echo "== kernel times"; date
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c2_final -o bench -- python $R/bench.py --steps 3 --warmup 1 $B > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_n65536_final -o bench -- python $R/bench.py --workload n65536 --steps 1 --warmup 1 $B > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_solves -o bench -- python $R/scripts/time_paths.py 16384 4096 > /dev/null 2>&1
-cd $R
-for d in prof_c2_final prof_n65536_final; do echo "-- $d"; python scripts/prof_top.py $(ls $O/$d/*.db | head -1) 12; done
-echo "-- prof_solves (scripts/time_paths.py 16384 4096)"; python scripts/prof_top.py $(ls $O/prof_solves/*.db | head -1) 30 | grep -E "stream|winv|prep|kmat_gemv|trsv"
-python scripts/timeline.py $(ls $O/prof_c2_final/*.db | head -1) /tmp/tl.csv 2500 > /dev/null; python scripts/timeline_panels.py /tmp/tl.csv | tail -28
-echo "== PMC: fabric traffic of the trailing update (separate passes)"; date
-cd /tmp
-for cn in FETCH_SIZE WRITE_SIZE; do
-timeout 300 rocprofv3 --pmc $cn --kernel-trace -d $O/pmc_$cn -o bench -- python $R/bench.py --steps 2 --warmup 1 $B --no-profile > /dev/null 2>&1
+for v in 3 2; do
+TGP_HIP_OPTIONS=stream_trsv=$v timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_solves_$v -o bench -- python $R/scripts/time_paths.py 16384 4096 > /dev/null 2>&1
+echo "-- stream_trsv=$v"; python $R/scripts/prof_top.py $(ls $O/prof_solves_$v/*.db | head -1) 30 | grep -E "stream|winv|prep|kmat_gemv|trsv"
 done
 cd $R
-for cn in FETCH_SIZE WRITE_SIZE; do python scripts/pmc_summary.py $(ls $O/pmc_$cn/*.db | head -1) $cn | head -6; done
 echo "== determinism stress"; date
-timeout 400 python scripts/stress_determinism.py 2>&1 | tail -6
+TGP_HIP_OPTIONS=stream_trsv=2 timeout 400 python scripts/stress_determinism.py 2>&1 | tail -6
 date
 } > $O/round.log 2>&1
 tail -150 $O/round.log
