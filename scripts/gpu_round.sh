@@ -1,29 +1,22 @@
 #!/bin/bash
-# round 2, batch 8: helper-workgroup split of the streaming solves, Kernel.matmul in one pass
+# round 2, batch 11: does a fifth ACTIVE queue cost the chain?  far updates on their own stream vs on the solve stream,
+# fused vs unfused evaluations
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 O=$R/gpurun_out
+B="--no-cpu-baseline --no-secondary"
+line() { python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); r=d.get('roofline') or {}
+print('$1', 'evals/s %.2f ms %.2f  update %.1f TF (%.3f)  potrf %.2f ms' % (d['value'], d['ms_per_step'], r.get('achieved',0), r.get('frac',0), (d.get('stage_ms') or {}).get('potrf',0)))"; }
 {
-echo "== pytest -m gpu (stream_trsv=1 auto)"; date
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8
-echo "== pytest solves with the split forced"; date
-TGP_HIP_OPTIONS=stream_trsv=2 timeout 900 python -m pytest tests/test_gpu_gp.py tests/test_gpu_kernels.py -m gpu -q -x 2>&1 | tail -4
-for v in 3 2 1; do
-echo "== adjacent paths, stream_trsv=$v"; date
-TGP_HIP_OPTIONS=stream_trsv=$v timeout 200 python scripts/time_paths.py 16384 4096 | grep -E "resident|predict mean at"
-TGP_HIP_OPTIONS=stream_trsv=$v timeout 200 python scripts/time_paths.py 65536 4096 2>&1 | grep -E "resident|predict mean at"
-done
-echo "== kernel times"; date
-cd /tmp
-for v in 3 2; do
-TGP_HIP_OPTIONS=stream_trsv=$v timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_solves_$v -o bench -- python $R/scripts/time_paths.py 16384 4096 > /dev/null 2>&1
-echo "-- stream_trsv=$v"; python $R/scripts/prof_top.py $(ls $O/prof_solves_$v/*.db | head -1) 30 | grep -E "stream|winv|prep|kmat_gemv|trsv"
-done
-cd $R
-echo "== determinism stress"; date
-TGP_HIP_OPTIONS=stream_trsv=2 timeout 400 python scripts/stress_determinism.py 2>&1 | tail -6
+for w in c2 n4096 n8192; do
+for fu in "" "--unfused"; do
+for opts in "inpanel_near=0" "inpanel_near=1" "inpanel_near=1,far_shares_solve=1" "inpanel_near=2,far_shares_solve=1"; do
+  TGP_HIP_OPTIONS="$opts" timeout 120 python bench.py $B --workload $w $fu --steps 10 --warmup 3 2>/dev/null | tail -1 | line "$w $fu [$opts]"
+done; done; done
 date
 } > $O/round.log 2>&1
 tail -150 $O/round.log
