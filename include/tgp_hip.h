@@ -95,6 +95,8 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "lookahead"         1: factor the next panel beside the trailing update (default), 0: off
  *   "first_small_tiles" look-ahead block-column updates of at most this many 128x128 tiles
  *                       run on 64x64 tiles (default 1100)
+ *   "nb_wide_rows"      panels that start with at least this many rows left are 2 nb_outer wide
+ *                       (default 30000; 0: never) -- never the first panel
  *   "first_split"       blocks of a panel after which its share of the next block-column
  *                       update is issued early, beside the panel's last blocks (default 5; 0 off)
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
@@ -317,8 +319,8 @@ int tgp_dist_get_column(tgp_dist* h, int64_t l, void* out_host);
  * tests/test_schedule.py replays the records and checks that every pair of conflicting
  * accesses is ordered by stream order or an event. */
 int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t first_split,
-                     int64_t first_small_tiles, int32_t fused, int64_t* out, int64_t cap_records,
-                     int64_t* n_records);
+                     int64_t first_small_tiles, int64_t nb_wide_rows, int32_t fused, int64_t* out,
+                     int64_t cap_records, int64_t* n_records);
 
 #ifdef __cplusplus
 }

@@ -20,12 +20,12 @@ KIND = {1: "potf2", 2: "trsm", 3: "gemm", 4: "trsv_step", 5: "record", 6: "wait"
         8: "residual_copy", 9: "reductions"}
 
 
-def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1):
+def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1, wide_rows=0):
     lib = _ffi.load_library()
     cap = 40 * (n_pad // 128) + 256
     out = np.zeros(cap * 10, dtype=np.int64)
     n = C.c_int64()
-    st = lib.tgp_trace_factor(n_pad, nb, lookahead, first_split, first_small, fused,
+    st = lib.tgp_trace_factor(n_pad, nb, lookahead, first_split, first_small, wide_rows, fused,
                               out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n))
     assert st == 0, lib.tgp_last_error()
     return out[: n.value * 10].reshape(-1, 10).tolist()
@@ -146,10 +146,15 @@ CONFIGS = [
     (5120, 512, 1, 3, 1100, 1),
     (4096, 2048, 1, 5, 1100, 1),
     (16384, 1024, 1, 5, 1100, 1),
+    # panels of 2 nb while at least `wide_rows` rows are left (never the first)
+    (8192, 1024, 1, 5, 1100, 1, 3000),
+    (5120, 512, 1, 3, 1100, 0, 1024),
+    (6144, 1024, 1, 0, 0, 1, 128),
+    (4224, 1024, 0, 5, 1100, 1, 2048),
 ]
 
 
-@pytest.mark.parametrize("cfg", CONFIGS, ids=[f"n{c[0]}-nb{c[1]}-la{c[2]}-fs{c[3]}-st{c[4]}-f{c[5]}" for c in CONFIGS])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[f"n{c[0]}-nb{c[1]}-la{c[2]}-fs{c[3]}-st{c[4]}-f{c[5]}" + (f"-wide{c[6]}" if len(c) > 6 else "") for c in CONFIGS])
 def test_schedule_has_no_data_race(cfg):
     n_pad = cfg[0]
     recs = trace(*cfg)

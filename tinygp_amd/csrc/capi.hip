@@ -216,6 +216,7 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "first_small_tiles")) slot = &ctx->first_small_tiles;
   else if (!strcmp(key, "keep_grad_buffers")) slot = &ctx->keep_grad_buffers;
   else if (!strcmp(key, "stream_trsv")) slot = &ctx->stream_trsv;
+  else if (!strcmp(key, "nb_wide_rows")) slot = &ctx->nb_wide_rows;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)
     TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);
@@ -1018,8 +1019,8 @@ int tgp_solver_timings(tgp_solver* s, double* ms, int n) {
 // event operations the five streams would receive for an n_pad x n_pad problem, without a GPU
 // (no HIP call is made).  Ten int64 per record: kind, stream, v[0..7] (tgp_trace_rec).
 int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t first_split,
-                     int64_t first_small_tiles, int32_t fused, int64_t* out, int64_t cap_records,
-                     int64_t* n_records) {
+                     int64_t first_small_tiles, int64_t nb_wide_rows, int32_t fused, int64_t* out,
+                     int64_t cap_records, int64_t* n_records) {
   using namespace tgp;
   TGP_ARG_CHECK(n_pad > 0 && n_pad % 128 == 0 && out != nullptr && n_records != nullptr,
                 "trace: n_pad must be a positive multiple of 128");
@@ -1040,6 +1041,7 @@ int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t
   ctx.lookahead = lookahead;
   ctx.first_split = first_split;
   ctx.first_small_tiles = first_small_tiles;
+  ctx.nb_wide_rows = nb_wide_rows;
   std::vector<tgp_trace_rec> recs;
   ctx.trace = &recs;
   // never dereferenced: only differences of these pointers are recorded

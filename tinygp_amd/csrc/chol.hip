@@ -1125,6 +1125,15 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     }
     return TGP_OK;
   };
+  // panel width: 2 NB (half as many read-modify-write passes over the trailing matrix) while at
+  // least `nb_wide_rows` rows are left -- there the evaluation is bound by the trailing update, not
+  // by the chain -- and never for the first panel, whose chain nothing hides
+  auto width = [&](int64_t k0) -> int64_t {
+    const int64_t rem = n - k0;
+    int64_t w = NB;
+    if (ctx->nb_wide_rows > 0 && k0 > 0 && rem >= ctx->nb_wide_rows) w = 2 * NB;
+    return rem < w ? rem : w;
+  };
   const bool la = ctx->lookahead != 0 && S1 != nullptr;
   if (!la) {
     TGP_TRY(join_assembly());
@@ -1143,8 +1152,8 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       return tiles <= ctx->first_small_tiles ? 4 : 0;
     };
     {  // first panel: on the side stream too, so that the main stream can take the early share
-      const int64_t kb0 = (n < NB) ? n : NB, mt0 = n - kb0;
-      const int64_t kbn0 = (mt0 < NB) ? mt0 : NB;
+      const int64_t kb0 = width(0), mt0 = n - kb0;
+      const int64_t kbn0 = width(kb0);
       const int64_t split = (mt0 > 0 && ctx->first_split > 0 && ctx->first_split < kb0 / TILE)
                                 ? ctx->first_split : 0;
       const std::function<int(hipEvent_t)> early = [&](hipEvent_t ready) -> int {
@@ -1161,11 +1170,11 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       TGP_TRY(st_wait(ctx, S0, ctx->ev_b));
       TGP_TRY(join_assembly());
     }
-    for (int64_t k0 = 0; k0 < n; k0 += NB) {
-      const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
+    for (int64_t k0 = 0, kb = 0; k0 < n; k0 += kb) {
+      kb = width(k0);
       const int64_t next = k0 + kb, mt = n - next;
       if (mt <= 0) break;
-      const int64_t kbn = (mt < NB) ? mt : NB;
+      const int64_t kbn = width(next);
       const T* P = A + k0 * ld + next;
       // 1. block column of the next panel first ...
       // (`k_done` columns of this panel were already applied while its last blocks were
@@ -1188,9 +1197,11 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       // (a quarter of the k-range) is left on the critical path between two chains.
       TGP_TRY(st_wait(ctx, S1, ctx->ev_a));
       const int64_t next2 = next + kbn, mt2 = n - next2;
-      const int64_t kbn2 = (mt2 < NB) ? mt2 : NB;
-      const int64_t split = (mt2 > 0 && ctx->first_split > 0 && ctx->first_split < kbn / TILE)
-                                ? ctx->first_split : 0;
+      const int64_t kbn2 = mt2 > 0 ? width(next2) : 0;
+      // (a wide panel leaves as many blocks behind the early share as a normal one)
+      const int64_t fs = (ctx->first_split > 0 && kbn > NB) ? ctx->first_split + (kbn - NB) / TILE
+                                                            : ctx->first_split;
+      const int64_t split = (mt2 > 0 && fs > 0 && fs < kbn / TILE) ? fs : 0;
       const std::function<int(hipEvent_t)> early = [&](hipEvent_t ready) -> int {
         TGP_TRY(st_wait(ctx, S0, ready));
         TGP_TRY(trailing(mt2, kbn2, split * TILE, A + next * ld + next2, A + next2 * ld + next2,

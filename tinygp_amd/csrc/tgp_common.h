@@ -86,6 +86,9 @@ struct tgp_ctx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_e = nullptr;
   int64_t nb_outer = 1024;  // measured best for N = 4k .. 32k (profiles/r01_f_nb_sweep.txt)
   int64_t lookahead = 1;
+  // panels that start with at least this many rows left are 2 nb_outer wide (0: never): half as many passes
+  // over the trailing matrix; +1.3 % at N = 65 536, a loss below ~30 000 rows (profiles/r02_i_wide_panels.txt)
+  int64_t nb_wide_rows = 30000;
   int64_t profile = 0;
   int64_t first_split = 5;  // blocks of a panel after which its share of the next block-column update is issued early (0: off)
   int64_t stream_trsv = 1;  // forward solves on a resident factor: one streaming launch (0: one launch pair per block)
