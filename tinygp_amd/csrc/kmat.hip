@@ -30,27 +30,39 @@ template <> struct MathC<float> {
   static constexpr float TWO_PI = 6.283185307179586f;
 };
 
-// One leaf of the program (a stationary kernel or a constant) at the pair's distances.
-template <typename T>
-__device__ __forceinline__ T leaf_value(const KProg& kp, int i, T r1, T r2, T l2dist, T l1sq) {
+// One leaf of the program (a stationary kernel or a constant) at the pair's r1 = sum|d| and
+// r2 = sum d^2.  The distance a leaf does not use is not computed: the metric and the op are
+// wave-uniform, so e.g. ExpSquared never pays for the fp64 square root of the L2 distance.
+// distance.py:51-56: zero-safe sqrt; distance.py:30-38: L1 "squared" = distance^2
+// FAM = 1: the program holds only Constant / Exp / ExpSquared / Matern leaves (checked on the
+// host): the cosine, sine and power paths -- and their registers -- are compiled out.
+template <typename T, int FAM = 0>
+__device__ __forceinline__ T leaf_value(const KProg& kp, int i, T r1, T r2) {
   const int op = kp.op[i];
   const bool l2 = kp.metric[i] == TGP_METRIC_L2;
-  const T dist = l2 ? l2dist : r1;
-  const T sq = l2 ? r2 : l1sq;
+  auto dist = [&]() -> T { return l2 ? ((r2 == T(0)) ? r1 : sqrt(r2)) : r1; };
+  auto sq = [&]() -> T { return l2 ? r2 : r1 * r1; };
   const T p0 = T(kp.p0[i]);
   const T p1 = T(kp.p1[i]);
   switch (op) {
     case TGP_K_CONST: return p0;
-    case TGP_K_EXP: return exp(-dist / p0);
-    case TGP_K_EXPSQ: return exp(T(-0.5) * (sq / (p0 * p0)));
-    case TGP_K_M32: { const T a = MathC<T>::SQRT3 * (dist / p0); return (T(1) + a) * exp(-a); }
-    case TGP_K_M52: { const T a = MathC<T>::SQRT5 * (dist / p0);
+    case TGP_K_EXP: return exp(-dist() / p0);
+    case TGP_K_EXPSQ: return exp(T(-0.5) * (sq() / (p0 * p0)));
+    case TGP_K_M32: { const T a = MathC<T>::SQRT3 * (dist() / p0); return (T(1) + a) * exp(-a); }
+    case TGP_K_M52: { const T a = MathC<T>::SQRT5 * (dist() / p0);
                       return (T(1) + a + (a * a) / T(3)) * exp(-a); }
-    case TGP_K_COS: return cos(MathC<T>::TWO_PI * (dist / p0));
-    case TGP_K_ESS: { const T s = sin(MathC<T>::PI * (dist / p0)); return exp(-p1 * (s * s)); }
-    case TGP_K_RQ: return pow(T(1) + T(0.5) * (sq / (p0 * p0)) / p1, -p1);
-    default: return T(0);
+    default: break;
   }
+  if constexpr (FAM == 0) {
+    switch (op) {
+      case TGP_K_COS: return cos(MathC<T>::TWO_PI * (dist() / p0));
+      case TGP_K_ESS: { const T s = sin(MathC<T>::PI * (dist() / p0)); return exp(-p1 * (s * s)); }
+      case TGP_K_RQ: return pow(T(1) + T(0.5) * (sq() / (p0 * p0)) / p1, -p1);
+      default: break;
+    }
+  }
+  (void)p1;
+  return T(0);
 }
 
 // Evaluate the postfix program for one pair given r1 = sum|d| and r2 = sum d^2.
@@ -58,15 +70,12 @@ __device__ __forceinline__ T leaf_value(const KProg& kp, int i, T r1, T r2, T l2
 // take a direct path; anything else runs the general stack machine, whose evaluation stack
 // lives in 8 named registers (no runtime-indexed array -> no scratch).  All branches are
 // wave-uniform (the program sits in kernarg / SGPRs).
-template <typename T>
+template <typename T, int FAM = 0>
 __device__ __forceinline__ T eval_kprog(const KProg& kp, T r1, T r2) {
-  // distance.py:51-56: zero-safe sqrt; distance.py:30-38: L1 "squared" = distance^2
-  const T l2dist = (r2 == T(0)) ? r1 : sqrt(r2);
-  const T l1sq = r1 * r1;
-  if (kp.n == 1) return leaf_value<T>(kp, 0, r1, r2, l2dist, l1sq);
+  if (kp.n == 1) return leaf_value<T, FAM>(kp, 0, r1, r2);
   if (kp.n == 3 && kp.op[0] < TGP_K_ADD && kp.op[1] < TGP_K_ADD) {
-    const T a = leaf_value<T>(kp, 0, r1, r2, l2dist, l1sq);
-    const T b = leaf_value<T>(kp, 1, r1, r2, l2dist, l1sq);
+    const T a = leaf_value<T, FAM>(kp, 0, r1, r2);
+    const T b = leaf_value<T, FAM>(kp, 1, r1, r2);
     return (kp.op[2] == TGP_K_ADD) ? (a + b) : (a * b);
   }
   T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
@@ -77,7 +86,7 @@ __device__ __forceinline__ T eval_kprog(const KProg& kp, T r1, T r2) {
       s0 = r; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
       continue;
     }
-    const T v = leaf_value<T>(kp, i, r1, r2, l2dist, l1sq);
+    const T v = leaf_value<T, FAM>(kp, i, r1, r2);
     s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
   }
   return s0;
@@ -86,12 +95,12 @@ __device__ __forceinline__ T eval_kprog(const KProg& kp, T r1, T r2) {
 // d(leaf)/d(param) at the pair's distances: param 0 = p0 (scale or constant), 1 = p1
 // (gamma / alpha).  Derived from the forms of kernels/stationary.py:76-235.
 template <typename T>
-__device__ __forceinline__ T leaf_deriv(const KProg& kp, int i, int param, T r1, T r2, T l2dist,
-                                        T l1sq) {
+__device__ __forceinline__ T leaf_deriv(const KProg& kp, int i, int param, T r1, T r2) {
   const int op = kp.op[i];
   const bool l2 = kp.metric[i] == TGP_METRIC_L2;
-  const T dist = l2 ? l2dist : r1;
-  const T sq = l2 ? r2 : l1sq;
+  // (the derivative passes are not the hot ones: both distances up front)
+  const T dist = l2 ? ((r2 == T(0)) ? r1 : sqrt(r2)) : r1;
+  const T sq = l2 ? r2 : r1 * r1;
   const T p0 = T(kp.p0[i]);
   const T p1 = T(kp.p1[i]);
   switch (op) {
@@ -119,8 +128,6 @@ __device__ __forceinline__ T leaf_deriv(const KProg& kp, int i, int param, T r1,
 template <typename T>
 __device__ __forceinline__ T eval_kprog_deriv(const KProg& kp, int which_op, int which_param, T r1,
                                               T r2) {
-  const T l2dist = (r2 == T(0)) ? r1 : sqrt(r2);
-  const T l1sq = r1 * r1;
   T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
   T d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, d6 = 0, d7 = 0;
   for (int i = 0; i < kp.n; ++i) {
@@ -132,8 +139,8 @@ __device__ __forceinline__ T eval_kprog_deriv(const KProg& kp, int which_op, int
       d0 = dv; d1 = d2; d2 = d3; d3 = d4; d4 = d5; d5 = d6; d6 = d7;
       continue;
     }
-    const T v = leaf_value<T>(kp, i, r1, r2, l2dist, l1sq);
-    const T dv = (i == which_op) ? leaf_deriv<T>(kp, i, which_param, r1, r2, l2dist, l1sq) : T(0);
+    const T v = leaf_value<T>(kp, i, r1, r2);
+    const T dv = (i == which_op) ? leaf_deriv<T>(kp, i, which_param, r1, r2) : T(0);
     s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
     d7 = d6; d6 = d5; d5 = d4; d4 = d3; d3 = d2; d2 = d1; d1 = d0; d0 = dv;
   }
@@ -142,16 +149,100 @@ __device__ __forceinline__ T eval_kprog_deriv(const KProg& kp, int which_op, int
 
 constexpr int KT = 128;  // tile edge
 
+// ---- fast path: the program is one exp-family leaf, optionally times a constant ("amp * leaf") --
+// OP and the metric are template parameters, so the inner loops below are straight-line code the
+// compiler can unroll and interleave across elements (the general evaluator runs a chain of
+// wave-uniform branches per element).  Same expressions, same order: bit-identical values.
+struct FastProg {
+  int op = -1, l2 = 0;   // op < 0: not a fast program
+  double p0 = 1, amp = 1;
+};
+static FastProg fast_prog(const KProg& kp) {
+  FastProg f;
+  auto leaf_ok = [](int op) { return op == TGP_K_EXP || op == TGP_K_EXPSQ || op == TGP_K_M32 || op == TGP_K_M52; };
+  int li = -1, ci = -1;
+  if (kp.n == 1 && leaf_ok(kp.op[0])) li = 0;
+  else if (kp.n == 3 && kp.op[2] == TGP_K_MUL) {
+    if (kp.op[0] == TGP_K_CONST && leaf_ok(kp.op[1])) { ci = 0; li = 1; }
+    else if (kp.op[1] == TGP_K_CONST && leaf_ok(kp.op[0])) { ci = 1; li = 0; }
+  }
+  if (li < 0) return f;
+  f.op = kp.op[li];
+  f.l2 = kp.metric[li] == TGP_METRIC_L2;
+  f.p0 = kp.p0[li];
+  f.amp = ci >= 0 ? kp.p0[ci] : 1.0;  // x * 1 == x exactly
+  return f;
+}
+
+template <typename T, int OP, int L2>
+__device__ __forceinline__ T leaf_fast(T r1, T r2, T p0, T p0sq) {
+  if constexpr (OP == TGP_K_EXPSQ) {
+    const T sq = L2 ? r2 : r1 * r1;
+    return exp(T(-0.5) * (sq / p0sq));
+  } else {
+    const T dist = L2 ? ((r2 == T(0)) ? r1 : sqrt(r2)) : r1;
+    if constexpr (OP == TGP_K_EXP) {
+      return exp(-dist / p0);
+    } else if constexpr (OP == TGP_K_M32) {
+      const T a = MathC<T>::SQRT3 * (dist / p0);
+      return (T(1) + a) * exp(-a);
+    } else {
+      const T a = MathC<T>::SQRT5 * (dist / p0);
+      return (T(1) + a + (a * a) / T(3)) * exp(-a);
+    }
+  }
+}
+
+// Full interior tiles only (every row and column inside n1 x n2): no bounds checks in the loop.
+template <typename T, int D, int OP, int L2>
+__global__ __launch_bounds__(256) void kmat_fast_kernel(T p0, T amp, int64_t n1, int64_t n2,
+                                                        const T* __restrict__ X1,
+                                                        const T* __restrict__ X2,
+                                                        const T* __restrict__ diag, T* __restrict__ out,
+                                                        int64_t ld, int flags, int tc0) {
+  const int tr = blockIdx.x, tc = blockIdx.y + tc0;
+  if ((flags & KMAT_LOWER) && tr < tc) return;
+  __shared__ T s2[KT * D];
+  const int64_t r0 = int64_t(tr) * KT, c0 = int64_t(tc) * KT;
+  for (int t = threadIdx.x; t < KT * D; t += 256) s2[t] = X2[c0 * D + t];
+  const int il = threadIdx.x & (KT - 1);
+  const int g = threadIdx.x >> 7;  // column half
+  const int64_t gi = r0 + il;
+  T xr[D];
+#pragma unroll
+  for (int t = 0; t < D; ++t) xr[t] = X1[gi * D + t];
+  const bool on_diag = diag != nullptr && tr == tc;
+  const T dg = on_diag ? diag[gi] : T(0);
+  const T p0sq = p0 * p0;
+  __syncthreads();
+  T* o = out + (c0 + g * (KT / 2)) * ld + gi;
+  const T* sc = s2 + g * (KT / 2) * D;
+#pragma unroll 4
+  for (int c = 0; c < KT / 2; ++c) {
+    T r1 = 0, r2 = 0;
+#pragma unroll
+    for (int t = 0; t < D; ++t) {
+      const T dx = xr[t] - sc[c * D + t];
+      r1 += fabs(dx);
+      r2 += dx * dx;
+    }
+    T v = amp * leaf_fast<T, OP, L2>(r1, r2, p0, p0sq);
+    if (on_diag && il == g * (KT / 2) + c) v += dg;  // noise.py:77-78 fused
+    o[int64_t(c) * ld] = v;
+  }
+}
+
 // D = 0: dynamic dimension (coordinates re-read from LDS); D > 0: row point in registers.
-template <typename T, int D>
+template <typename T, int D, int FAM>
 __global__ __launch_bounds__(256) void kmat_kernel(KProg kp, int64_t n1, int64_t n2, int d,
                                                    const T* __restrict__ X1,
                                                    const T* __restrict__ X2,
                                                    const T* __restrict__ diag, T* __restrict__ out,
                                                    int64_t ld, int64_t rows_out, int64_t cols_out,
-                                                   int flags, int tc0) {
+                                                   int flags, int tc0, int ftr, int ftc) {
   const int tr = blockIdx.x, tc = blockIdx.y + tc0;
   if ((flags & KMAT_LOWER) && tr < tc) return;
+  if (tr < ftr && tc < ftc) return;  // full tiles already written by kmat_fast_kernel
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* s1 = reinterpret_cast<T*>(smem);  // [KT][d]
   T* s2 = s1 + KT * d;                 // [KT][d]
@@ -194,7 +285,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(KProg kp, int64_t n1, int64_t
           r2 += dx * dx;
         }
       }
-      v = eval_kprog<T>(kp, r1, r2);
+      v = eval_kprog<T, FAM>(kp, r1, r2);
       if (diag != nullptr && gi == gj) v += dg;  // noise.py:77-78 fused
     } else {
       v = ((flags & KMAT_PAD_IDENTITY) && gi == gj) ? T(1) : T(0);
@@ -297,7 +388,7 @@ __global__ __launch_bounds__(256) void kdiag_kernel(KProg kp, int64_t n, const T
 // of columns of `y` in Kernel.matmul).  One lane per row i, X2 / v chunks staged through LDS and
 // broadcast-read.
 constexpr int GV_ROWS = 256, GV_JB = 256, GV_NV = 8;
-template <typename T>
+template <typename T, int FAM>
 __global__ __launch_bounds__(256) void kmat_gemv_kernel(KProg kp, int64_t n1, int64_t n2, int d,
                                                         const T* __restrict__ X1,
                                                         const T* __restrict__ X2,
@@ -334,7 +425,57 @@ __global__ __launch_bounds__(256) void kmat_gemv_kernel(KProg kp, int64_t n1, in
           r2 += dx * dx;
         }
       }
-      const T kv = eval_kprog<T>(kp, r1, r2);
+      const T kv = eval_kprog<T, FAM>(kp, r1, r2);
+#pragma unroll
+      for (int r = 0; r < GV_NV; ++r) acc[r] += kv * sv[jj * GV_NV + r];
+    }
+  }
+  if (i < n1)
+    for (int r = 0; r < nv; ++r) partial[(int64_t(blockIdx.y) * nv + r) * n1 + i] = acc[r];
+}
+
+
+// the same for "leaf" / "amp * leaf" programs: straight-line inner loop (see kmat_fast_kernel)
+template <typename T, int OP, int L2>
+__global__ __launch_bounds__(256) void kmat_gemv_fast_kernel(T p0, T amp, int64_t n1, int64_t n2, int d,
+                                                             const T* __restrict__ X1,
+                                                             const T* __restrict__ X2,
+                                                             const T* __restrict__ v, int nv,
+                                                             T* __restrict__ partial, int64_t jchunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sx = reinterpret_cast<T*>(smem);  // [GV_JB][d]
+  T* sv = sx + GV_JB * d;              // [GV_JB][GV_NV]
+  const int64_t i = int64_t(blockIdx.x) * GV_ROWS + threadIdx.x;
+  const int64_t j0 = int64_t(blockIdx.y) * jchunk;
+  const int64_t j1 = (j0 + jchunk < n2) ? j0 + jchunk : n2;
+  T xi[TGP_MAX_DIM];
+#pragma unroll
+  for (int t = 0; t < TGP_MAX_DIM; ++t) xi[t] = (t < d && i < n1) ? X1[i * d + t] : T(0);
+  const T p0sq = p0 * p0;
+  T acc[GV_NV];
+#pragma unroll
+  for (int r = 0; r < GV_NV; ++r) acc[r] = 0;
+  for (int64_t jb = j0; jb < j1; jb += GV_JB) {
+    const int cnt = int((j1 - jb < GV_JB) ? (j1 - jb) : GV_JB);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt * d; t += 256) sx[t] = X2[jb * d + t];
+    for (int t = threadIdx.x; t < cnt * GV_NV; t += 256) {
+      const int jj = t / GV_NV, r = t % GV_NV;
+      sv[t] = (r < nv) ? v[int64_t(r) * n2 + jb + jj] : T(0);
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int jj = 0; jj < cnt; ++jj) {
+      T r1 = 0, r2 = 0;
+#pragma unroll
+      for (int t = 0; t < TGP_MAX_DIM; ++t) {
+        if (t < d) {
+          const T dx = xi[t] - sx[jj * d + t];
+          r1 += fabs(dx);
+          r2 += dx * dx;
+        }
+      }
+      const T kv = amp * leaf_fast<T, OP, L2>(r1, r2, p0, p0sq);
 #pragma unroll
       for (int r = 0; r < GV_NV; ++r) acc[r] += kv * sv[jj * GV_NV + r];
     }
@@ -384,6 +525,17 @@ int make_kprog(const tgp_kop* prog, int nops, KProg* out) {
   return TGP_OK;
 }
 
+// only Constant / Exp / ExpSquared / Matern leaves (+ sums and products): the FAM = 1 kernels
+static bool exp_family(const KProg& kp) {
+  for (int i = 0; i < kp.n; ++i) {
+    const int op = kp.op[i];
+    if (!(op == TGP_K_CONST || op == TGP_K_EXP || op == TGP_K_EXPSQ || op == TGP_K_M32 ||
+          op == TGP_K_M52 || op >= TGP_K_ADD))
+      return false;
+  }
+  return true;
+}
+
 template <typename T>
 int launch_kmat_cols(tgp_ctx* ctx, hipStream_t st, const KProg& kp, int64_t n1, int64_t n2, int d,
                      const T* X1, const T* X2, const T* diag, T* out, int64_t ld, int64_t rows_out,
@@ -398,11 +550,57 @@ int launch_kmat_cols(tgp_ctx* ctx, hipStream_t st, const KProg& kp, int64_t n1, 
     return TGP_OK;
   }
   TGP_ARG_CHECK(ntc <= 65535, "kmat: too many column tiles");
+  // full tiles of "leaf" / "amp * leaf" programs: the straight-line kernel
+  int ftr = 0, ftc = 0;
+  const FastProg fp = fast_prog(kp);
+  if (fp.op >= 0 && d <= 3) {
+    ftr = int(n1 / KT);
+    ftc = int(n2 / KT);
+    const int64_t fc = std::min<int64_t>(tc0 + ntc, ftc) - tc0;  // column tiles of this call that are full
+    if (ftr > 0 && fc > 0) {
+      dim3 fgrid((unsigned)ftr, (unsigned)fc);
+#define TGP_FAST3(DD, OP, L2)                                                                     \
+  hipLaunchKernelGGL((kmat_fast_kernel<T, DD, OP, L2>), fgrid, dim3(256), 0, st, T(fp.p0),        \
+                     T(fp.amp), n1, n2, X1, X2, diag, out, ld, flags, (int)tc0)
+#define TGP_FAST2(DD, OP)                                                                         \
+  do {                                                                                           \
+    if (fp.l2) TGP_FAST3(DD, OP, 1); else TGP_FAST3(DD, OP, 0);                                   \
+  } while (0)
+#define TGP_FAST1(DD)                                                                             \
+  do {                                                                                           \
+    switch (fp.op) {                                                                             \
+      case TGP_K_EXP: TGP_FAST2(DD, TGP_K_EXP); break;                                            \
+      case TGP_K_EXPSQ: TGP_FAST2(DD, TGP_K_EXPSQ); break;                                        \
+      case TGP_K_M32: TGP_FAST2(DD, TGP_K_M32); break;                                            \
+      default: TGP_FAST2(DD, TGP_K_M52); break;                                                   \
+    }                                                                                            \
+  } while (0)
+      if (d == 1) TGP_FAST1(1);
+      else if (d == 2) TGP_FAST1(2);
+      else TGP_FAST1(3);
+#undef TGP_FAST1
+#undef TGP_FAST2
+#undef TGP_FAST3
+    } else {
+      ftr = ftc = 0;
+    }
+    if (ftr == tr && ftc >= tc0 + ntc) {  // nothing ragged left
+      TGP_HIP_TRY(hipGetLastError());
+      return TGP_OK;
+    }
+  }
   dim3 grid((unsigned)tr, (unsigned)ntc);
   const size_t shmem = 2 * size_t(KT) * d * sizeof(T);
+  const bool fam = exp_family(kp);
 #define TGP_KMAT_LAUNCH(DD)                                                                      \
-  hipLaunchKernelGGL((kmat_kernel<T, DD>), grid, dim3(256), shmem, st, kp, n1, n2, d, X1, X2,    \
-                     diag, out, ld, rows_out, cols_out, flags, (int)tc0)
+  do {                                                                                           \
+    if (fam)                                                                                     \
+      hipLaunchKernelGGL((kmat_kernel<T, DD, 1>), grid, dim3(256), shmem, st, kp, n1, n2, d, X1, \
+                         X2, diag, out, ld, rows_out, cols_out, flags, (int)tc0, ftr, ftc);      \
+    else                                                                                         \
+      hipLaunchKernelGGL((kmat_kernel<T, DD, 0>), grid, dim3(256), shmem, st, kp, n1, n2, d, X1, \
+                         X2, diag, out, ld, rows_out, cols_out, flags, (int)tc0, ftr, ftc);      \
+  } while (0)
   switch (d) {
     case 1: TGP_KMAT_LAUNCH(1); break;
     case 2: TGP_KMAT_LAUNCH(2); break;
@@ -455,8 +653,26 @@ int launch_kmat_gemv_multi(tgp_ctx* ctx, const KProg& kp, int64_t n1, int64_t n2
   const size_t shmem = size_t(GV_JB) * (d + GV_NV) * sizeof(T);
   for (int64_t r0 = 0; r0 < nv_total; r0 += GV_NV) {
     const int nv = int(std::min<int64_t>(GV_NV, nv_total - r0));
-    hipLaunchKernelGGL((kmat_gemv_kernel<T>), dim3((unsigned)rb, (unsigned)nch), dim3(256), shmem,
-                       ctx->stream, kp, n1, n2, d, X1, X2, v + r0 * n2, nv, partial, jchunk);
+    const FastProg fp = fast_prog(kp);
+#define TGP_GV3(OP, L2)                                                                             \
+  hipLaunchKernelGGL((kmat_gemv_fast_kernel<T, OP, L2>), dim3((unsigned)rb, (unsigned)nch), dim3(256), shmem, \
+                     ctx->stream, T(fp.p0), T(fp.amp), n1, n2, d, X1, X2, v + r0 * n2, nv, partial, jchunk)
+#define TGP_GV2(OP)                                                                                 \
+  do {                                                                                             \
+    if (fp.l2) TGP_GV3(OP, 1); else TGP_GV3(OP, 0);                                                 \
+  } while (0)
+    if (fp.op == TGP_K_EXP) TGP_GV2(TGP_K_EXP);
+    else if (fp.op == TGP_K_EXPSQ) TGP_GV2(TGP_K_EXPSQ);
+    else if (fp.op == TGP_K_M32) TGP_GV2(TGP_K_M32);
+    else if (fp.op == TGP_K_M52) TGP_GV2(TGP_K_M52);
+#undef TGP_GV2
+#undef TGP_GV3
+    else if (exp_family(kp))
+      hipLaunchKernelGGL((kmat_gemv_kernel<T, 1>), dim3((unsigned)rb, (unsigned)nch), dim3(256), shmem,
+                         ctx->stream, kp, n1, n2, d, X1, X2, v + r0 * n2, nv, partial, jchunk);
+    else
+      hipLaunchKernelGGL((kmat_gemv_kernel<T, 0>), dim3((unsigned)rb, (unsigned)nch), dim3(256), shmem,
+                         ctx->stream, kp, n1, n2, d, X1, X2, v + r0 * n2, nv, partial, jchunk);
     hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((n1 + 255) / 256), (unsigned)nv), dim3(256), 0,
                        ctx->stream, n1, (int)nch, nv, partial, out + r0 * n1);
   }
