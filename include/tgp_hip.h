@@ -283,9 +283,13 @@ int tgp_dist_assemble(tgp_dist* h, const tgp_kop* prog, int nops);
 int tgp_dist_begin(tgp_dist* h, const void* resid_host);
 /* owner of panel 0: factor + pack it (no-op on the other ranks) */
 int tgp_dist_first_panel(tgp_dist* h);
-/* panel k has arrived in its ring slot (the main stream already waits for it): forward-
- * substitution step k; on the owner of panel k+1 also the look-ahead update, chain and pack */
+/* panel k has arrived in its ring slot (the main stream already waits for it); on the owner of
+ * panel k+1: the look-ahead update of that block column, its chain and its pack */
 int tgp_dist_after_recv(tgp_dist* h, int64_t k);
+/* forward-substitution step k of the replicated right-hand side (solvers/direct.py:66-70 on the
+ * received panel) and sum log L_ii of panel k (direct.py:61-64); call after the broadcast of
+ * panel k+1 has been started and before tgp_dist_rest(k) */
+int tgp_dist_fwd_step(tgp_dist* h, int64_t k);
 /* update of all remaining owned block columns by panel k: one fp64/fp32 MFMA launch */
 int tgp_dist_rest(tgp_dist* h, int64_t k);
 /* joins the streams; *info = this rank's potrf info (host: MIN over ranks of the non-zero

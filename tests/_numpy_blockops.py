@@ -103,6 +103,16 @@ class NumpyBlockOps:
         self.calls.append(("after_recv", k))
         nb = self.nb
         P = self._panel_view(k)
+        k1 = k + 1
+        if k1 < self.nblk and k1 % self.G == self.rank:
+            C = self._col(k1 // self.G)[k1 * nb:]
+            C -= P[nb:] @ P[nb:2 * nb].T
+            self._factor_and_pack(k1)
+
+    def fwd_step(self, k):
+        self.calls.append(("fwd_step", k))
+        nb = self.nb
+        P = self._panel_view(k)
         if self.solving:
             with np.errstate(all="ignore"):
                 xk = sla.solve_triangular(P[:nb], self.xn[k * nb:(k + 1) * nb], lower=True, check_finite=False)
@@ -110,11 +120,6 @@ class NumpyBlockOps:
                 self.xn[(k + 1) * nb:] -= P[nb:] @ xk
         with np.errstate(all="ignore"):
             self.logdet[k] = np.sum(np.log(np.diag(P[:nb])))
-        k1 = k + 1
-        if k1 < self.nblk and k1 % self.G == self.rank:
-            C = self._col(k1 // self.G)[k1 * nb:]
-            C -= P[nb:] @ P[nb:2 * nb].T
-            self._factor_and_pack(k1)
 
     def rest(self, k):
         self.calls.append(("rest", k))

@@ -105,6 +105,7 @@ SIGNATURES = {
     "tgp_dist_assemble": [_vp, _pkop, _int],
     "tgp_dist_begin": [_vp, _vp],
     "tgp_dist_first_panel": [_vp],
+    "tgp_dist_fwd_step": [_vp, _i64],
     "tgp_dist_after_recv": [_vp, _i64],
     "tgp_dist_rest": [_vp, _i64],
     "tgp_dist_end": [_vp, _pi32, _pdbl, _pdbl],

@@ -39,6 +39,7 @@ struct tgp_dist {
   void* ring[3] = {nullptr, nullptr, nullptr};  // caller-owned broadcast slots (panel k in slot k mod 3)
   hipEvent_t ev_solve[3] = {nullptr, nullptr, nullptr};  // forward step that read the slot has finished
   bool ev_solve_set[3] = {false, false, false};
+  hipEvent_t ev_arrived = nullptr;  // panel k is in its slot (recorded on the main stream by after_recv)
   void* x = nullptr;       // caller-owned replicated vector (n_pad): residual -> L^-1 r -> K^-1 r
   void* Xown = nullptr;    // coordinates of the owned columns, compacted (cond-mean partial)
   void* aown = nullptr;    // alpha at the owned columns, compacted
@@ -179,6 +180,7 @@ int tgp_dist_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X
   D_TRY(hipMalloc(&h->dinv, size_t(h->npad / TILE) * 2048 * es));
   D_TRY(hipMalloc((void**)&h->d_logdet, size_t(h->nblk + 1) * sizeof(double)));
   for (auto& e : h->ev_solve) D_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  D_TRY(hipEventCreateWithFlags(&h->ev_arrived, hipEventDisableTiming));
   D_TRY(hipMemcpyAsync(h->X, X_host, size_t(n) * d * es, hipMemcpyHostToDevice, ctx->stream));
   D_TRY(hipMemcpyAsync(h->diag, noise_diag_host, size_t(n) * es, hipMemcpyHostToDevice, ctx->stream));
   // compacted coordinates of the owned columns (for the conditional-mean partial products)
@@ -211,6 +213,7 @@ int tgp_dist_destroy(tgp_dist* h) {
   void* bufs[] = {h->X, h->diag, h->A, h->dinv, h->Xown, h->aown, (void*)h->d_logdet};
   for (void* b : bufs)
     if (b) hipFree(b);
+  if (h->ev_arrived) hipEventDestroy(h->ev_arrived);
   for (auto e : h->ev_solve)
     if (e) hipEventDestroy(e);
   delete h;
@@ -285,35 +288,25 @@ int tgp_dist_first_panel(tgp_dist* h) {
 }
 
 // Panel k sits in its ring slot on this rank and the MAIN stream has been made to wait for
-// its arrival by the caller (RCCL work.wait()).  Queues: forward-substitution step k (solve
-// stream), and -- if this rank owns panel k+1 -- the look-ahead update of that block column,
-// its first potf2, its chain (priority stream) and its pack.
+// its arrival by the caller (RCCL work.wait()).  If this rank owns panel k+1: the look-ahead
+// update of that block column, its first potf2, its chain (priority stream) and its pack.
+// The host then starts the broadcast of panel k+1 and calls tgp_dist_fwd_step(k).
 int tgp_dist_after_recv(tgp_dist* h, int64_t k) {
   DIST_GUARD(h);
   TGP_ARG_CHECK(k >= 0 && k < h->nblk, "panel index out of range");
   tgp_ctx* ctx = h->ctx;
-  hipStream_t S0 = ctx->stream, S2 = ctx->solve_stream;
+  hipStream_t S0 = ctx->stream;
   return ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
     const int64_t rows = rows_of(h, k), nb = h->nb, nd = slot_dinv_elems(h);
     const int sl = int(k % tgp_dist::NSLOT), sl_next = int((k + 1) % tgp_dist::NSLOT);
     const T* slot = (const T*)h->ring[sl];
     const T* P = slot + nd;  // rows x nb, ld = rows, row 0 = global row k*nb
+    TGP_HIP_TRY(hipEventRecord(h->ev_arrived, S0));
     // The slot panel k+1 will be written into (by the owner's pack or by RCCL, both ordered
     // behind the main stream from here on) was last read by the forward step of panel k-2:
-    // two panels of slack for the solve stream, which shares the chip with the updates.
+    // two panels of slack for the forward solve, which shares the chip with the updates.
     if (h->ev_solve_set[sl_next]) TGP_HIP_TRY(hipStreamWaitEvent(S0, h->ev_solve[sl_next], 0));
-    TGP_HIP_TRY(hipEventRecord(ctx->ev_b, S0));
-    TGP_HIP_TRY(hipStreamWaitEvent(S2, ctx->ev_b, 0));
-    if (h->solving) {
-      T* xk = (T*)h->x + k * nb;
-      for (int64_t j = 0; j < nb; j += TILE)
-        TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, rows - (j + TILE), P + j * rows + j, rows,
-                                        slot + (j / TILE) * 2048, xk + j));
-    }
-    TGP_TRY(launch_sum_log_diag_at<T>(ctx, S2, nb, P, rows, h->d_logdet + k));
-    TGP_HIP_TRY(hipEventRecord(h->ev_solve[sl], S2));
-    h->ev_solve_set[sl] = true;
     const int64_t k1 = k + 1;
     if (k1 < h->nblk && owner_of(h, k1) == h->rank) {
       TGP_TRY(join_assembly<T>(h));
@@ -327,6 +320,34 @@ int tgp_dist_after_recv(tgp_dist* h, int64_t k) {
       TGP_TRY(panel_potf2<T>(ctx, S0, C, ld, (T*)h->dinv + (k1 * nb / TILE) * 2048, k1 * nb, 0, false));
       TGP_TRY(factor_and_pack<T>(h, k1, true));
     }
+    return TGP_OK;
+  });
+}
+
+// Forward-substitution step k of the replicated right-hand side (and sum log L_ii of panel k),
+// straight from the received panel, on the solve stream.  A separate entry point so that the host
+// can start the broadcast of panel k+1 first.
+int tgp_dist_fwd_step(tgp_dist* h, int64_t k) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk, "panel index out of range");
+  tgp_ctx* ctx = h->ctx;
+  hipStream_t S2 = ctx->solve_stream;
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int64_t rows = rows_of(h, k), nb = h->nb, nd = slot_dinv_elems(h);
+    const int sl = int(k % tgp_dist::NSLOT);
+    const T* slot = (const T*)h->ring[sl];
+    const T* P = slot + nd;
+    TGP_HIP_TRY(hipStreamWaitEvent(S2, h->ev_arrived, 0));
+    if (h->solving) {
+      T* xk = (T*)h->x + k * nb;
+      for (int64_t j = 0; j < nb; j += TILE)
+        TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, rows - (j + TILE), P + j * rows + j, rows,
+                                        slot + (j / TILE) * 2048, xk + j));
+    }
+    TGP_TRY(launch_sum_log_diag_at<T>(ctx, S2, nb, P, rows, h->d_logdet + k));
+    TGP_HIP_TRY(hipEventRecord(h->ev_solve[sl], S2));
+    h->ev_solve_set[sl] = true;
     return TGP_OK;
   });
 }

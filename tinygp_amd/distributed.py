@@ -39,6 +39,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -47,6 +48,22 @@ from tinygp_amd import _ffi
 __all__ = ["HipBlockOps", "BlockCyclicCholesky"]
 
 MAIN, PANEL = 0, 1
+
+
+class _Done:
+    """Stand-in for a collective's work handle when there is nobody to talk to: wait() orders the
+    current stream behind everything queued so far on the stream the data was produced on."""
+
+    def __init__(self, ops, which):
+        self.ops = ops
+        self.ev = None
+        if hasattr(ops, "streams"):  # (the CPU stand-in of the tests is synchronous)
+            self.ev = ops.torch.cuda.Event()
+            self.ev.record(ops.streams[which])
+
+    def wait(self):
+        if self.ev is not None:
+            self.ops.torch.cuda.current_stream().wait_event(self.ev)
 
 
 class HipBlockOps:
@@ -120,6 +137,9 @@ class HipBlockOps:
     def after_recv(self, k: int):
         _ffi.check(self.lib.tgp_dist_after_recv(self.h, k), "tgp_dist_after_recv")
 
+    def fwd_step(self, k: int):
+        _ffi.check(self.lib.tgp_dist_fwd_step(self.h, k), "tgp_dist_fwd_step")
+
     def rest(self, k: int):
         _ffi.check(self.lib.tgp_dist_rest(self.h, k), "tgp_dist_rest")
 
@@ -187,8 +207,6 @@ class BlockCyclicCholesky:
         self.kernel = kernel
         self.prog = kernel.program()
         if ops is None:
-            import os
-
             ops = HipBlockOps(int(os.environ.get("LOCAL_RANK", "0")))
         self.ops = ops
         self.owned = [j for j in range(self.nblk) if j % self.G == self.rank]
@@ -197,6 +215,13 @@ class BlockCyclicCholesky:
         self.info = 0
         self.factored = self.solved = self.have_alpha = False
         self.bytes_received = 0  # panel bytes this rank received in the last factorisation
+        # A process group of one has nobody to broadcast to.  Routing the panels through the
+        # collective library anyway costs 40 instead of 31 ms per evaluation at N = 16 384: with its
+        # stream in play the dependent launches of the panel chains arrive later on the device (the
+        # host is not the limit -- it has everything enqueued within 5 ms;
+        # profiles/r02_k_block_column_queues.txt).  TGP_DIST_SELF_BROADCAST=1 keeps the call, to
+        # time exactly that.
+        self.self_broadcast = os.environ.get("TGP_DIST_SELF_BROADCAST", "0") == "1"
 
     def rows(self, j: int) -> int:
         return self.npad - j * self.nb
@@ -213,6 +238,8 @@ class BlockCyclicCholesky:
         buf = self.ops.slot(k, self.rows(k))
         if not own:
             self.bytes_received += buf.numel() * buf.element_size()
+        if self.G == 1 and not self.self_broadcast:
+            return _Done(self.ops, PANEL)  # nobody to send to: only the stream dependency remains
         with self.ops.stream(PANEL if own else MAIN):
             return self.dist.broadcast(buf, src=self._src(self.owner(k)), group=self.group, async_op=True)
 
@@ -233,9 +260,10 @@ class BlockCyclicCholesky:
         for k in range(self.nblk):
             with ops.stream(MAIN):
                 work.wait()  # RCCL: a stream dependency, not a host block
-            ops.after_recv(k)  # fwd-solve step k; owner of k+1: look-ahead update + chain + pack
+            ops.after_recv(k)  # owner of k+1: look-ahead update + chain + pack
             if k + 1 < self.nblk:
                 work = self._bcast_panel(k + 1)  # enqueued before the big update: overlaps it
+            ops.fwd_step(k)  # forward-substitution step k from the received panel
             ops.rest(k)
         info, self._sumsq, self._logdet = ops.end()
         # agree on the first failing pivot (LAPACK convention), 0 if none
