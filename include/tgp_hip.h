@@ -97,6 +97,8 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       run on 64x64 tiles (default 1100)
  *   "nb_wide_rows"      panels that start with at least this many rows left are 2 nb_outer wide
  *                       (default 30000; 0: never) -- never the first panel
+ *   "solve_on_update"   1 (default): the forward-substitution steps fused into the factorisation are
+ *                       queued on the update stream (three busy queues); 0: on their own stream
  *   "first_split"       blocks of a panel after which its share of the next block-column
  *                       update is issued early, beside the panel's last blocks (default 5; 0 off)
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)

@@ -217,6 +217,7 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "keep_grad_buffers")) slot = &ctx->keep_grad_buffers;
   else if (!strcmp(key, "stream_trsv")) slot = &ctx->stream_trsv;
   else if (!strcmp(key, "nb_wide_rows")) slot = &ctx->nb_wide_rows;
+  else if (!strcmp(key, "solve_on_update")) slot = &ctx->solve_on_update;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)
     TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);

@@ -1037,7 +1037,8 @@ template <typename T>
 int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* dinv,
                 int64_t pivot_off, int64_t k0, int64_t kb, bool head_done, T* y,
                 int64_t after_blocks, const std::function<int(hipEvent_t)>& mid) {
-  hipStream_t S2 = ctx->solve_stream, S3 = ctx->update_stream;
+  hipStream_t S3 = ctx->update_stream;
+  hipStream_t S2 = ctx->solve_on_update != 0 ? S3 : ctx->solve_stream;  // behind the update of the same block
   for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
     T* Ljj = A + j0 * ld + j0;
     T* dj = dinv + (j0 / TILE) * 2048;
@@ -1058,7 +1059,7 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
       TGP_TRY(ev_record(ctx, ctx->ev_e, S3));
     }
     if (y != nullptr) {
-      TGP_TRY(st_wait(ctx, S2, ctx->ev_d));
+      if (S2 != S3 || !upd) TGP_TRY(st_wait(ctx, S2, ctx->ev_d));  // (already waited for by the update)
       TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, mb, Ljj, ld, dj, y + j0));
     }
     if (after_blocks > 0 && upd && j0 + TILE == k0 + after_blocks * TILE) TGP_TRY(mid(ctx->ev_d));
@@ -1075,7 +1076,8 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   TGP_ARG_CHECK(n % TILE == 0 && ld >= n, "potrf: n must be a multiple of %d and ld >= n", TILE);
   if (info_host) *info_host = 0;
   if (n == 0) return TGP_OK;
-  hipStream_t S0 = ctx->stream, S1 = ctx->panel_stream, S2 = ctx->solve_stream;
+  hipStream_t S0 = ctx->stream, S1 = ctx->panel_stream;
+  hipStream_t S2 = ctx->solve_on_update != 0 ? ctx->update_stream : ctx->solve_stream;
   if (y != nullptr) {  // S2 must see y (uploaded on S0)
     TGP_TRY(ev_record(ctx, ctx->ev_c, S0));
     TGP_TRY(st_wait(ctx, S2, ctx->ev_c));

@@ -86,6 +86,9 @@ struct tgp_ctx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_e = nullptr;
   int64_t nb_outer = 1024;  // measured best for N = 4k .. 32k (profiles/r01_f_nb_sweep.txt)
   int64_t lookahead = 1;
+  // the fused forward-substitution steps ride on the update stream, behind the in-panel update of the same
+  // block: three busy queues instead of four (c2 30.3 -> 29.8 ms, N = 4096 2.66 -> 2.45 ms; 0: own stream)
+  int64_t solve_on_update = 1;
   // panels that start with at least this many rows left are 2 nb_outer wide (0: never): half as many passes
   // over the trailing matrix; +1.3 % at N = 65 536, a loss below ~30 000 rows (profiles/r02_i_wide_panels.txt)
   int64_t nb_wide_rows = 30000;
