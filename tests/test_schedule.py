@@ -1,7 +1,7 @@
 """Host logic of the factorisation schedule, checked without a GPU.
 
 ``tgp_trace_factor`` replays what ``tgp_solver_factor`` / ``tgp_solver_factor_logprob`` would
-enqueue on the library's five streams (same code path, launches replaced by records).  The
+enqueue on the library's streams (same code path, launches replaced by records).  The
 checker below models every record's reads and writes at 128 x 128 tile granularity and
 verifies with vector clocks that each pair of conflicting accesses (write-write, write-read,
 read-write) is ordered by stream order or by an event record / wait pair -- i.e. that the

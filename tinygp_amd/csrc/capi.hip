@@ -30,6 +30,14 @@ static int grow(void** p, size_t* cur, size_t bytes) {
 }
 
 int ensure_dinv(tgp_ctx* ctx, size_t bytes) { return grow(&ctx->d_dinv, &ctx->dinv_bytes, bytes); }
+int ensure_solve_stream(tgp_ctx* ctx) {
+  if (ctx->solve_stream != nullptr || ctx->trace) return TGP_OK;
+  int lo = 0, hi = 0;
+  TGP_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->solve_stream, hipStreamNonBlocking, hi));
+  return TGP_OK;
+}
+
 int ensure_work(tgp_ctx* ctx, size_t bytes) { return grow(&ctx->d_work, &ctx->work_bytes, bytes); }
 
 template <typename F>
@@ -148,7 +156,9 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   int lo = 0, hi = 0;
   TGP_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->panel_stream, hipStreamNonBlocking, hi));
-  TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->solve_stream, hipStreamNonBlocking, hi));
+  // (the solve stream is created on first use -- ensure_solve_stream: a FIFTH stream in use costs every
+  // dependent launch of the panel chains, profiles/r02_m_stream_count.txt, and the default schedule
+  // does not need it)
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->update_stream, hipStreamNonBlocking, hi));
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->asm_stream, hipStreamNonBlocking, lo));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
@@ -217,6 +227,7 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "keep_grad_buffers")) slot = &ctx->keep_grad_buffers;
   else if (!strcmp(key, "stream_trsv")) slot = &ctx->stream_trsv;
   else if (!strcmp(key, "nb_wide_rows")) slot = &ctx->nb_wide_rows;
+  else if (!strcmp(key, "dist_solve_aux")) slot = &ctx->dist_solve_aux;
   else if (!strcmp(key, "solve_on_update")) slot = &ctx->solve_on_update;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)

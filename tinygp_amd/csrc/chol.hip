@@ -1077,6 +1077,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   if (info_host) *info_host = 0;
   if (n == 0) return TGP_OK;
   hipStream_t S0 = ctx->stream, S1 = ctx->panel_stream;
+  if (ctx->solve_on_update == 0 && y != nullptr) TGP_TRY(ensure_solve_stream(ctx));
   hipStream_t S2 = ctx->solve_on_update != 0 ? ctx->update_stream : ctx->solve_stream;
   if (y != nullptr) {  // S2 must see y (uploaded on S0)
     TGP_TRY(ev_record(ctx, ctx->ev_c, S0));
@@ -1100,17 +1101,17 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     return panel_chain<T>(ctx, st, n, A, ld, dinv, 0, k0, kb, head_done, y, after_blocks, mid);
   };
   const std::function<int(hipEvent_t)> no_mid = [](hipEvent_t) { return TGP_OK; };
-  auto trailing = [&](int64_t m, int64_t nn, int64_t kb, const T* P, T* C, int role) -> int {
+  auto trailing = [&](hipStream_t sq, int64_t m, int64_t nn, int64_t kb, const T* P, T* C, int role) -> int {
     ProfSpan sp{};
     const bool prof = prof_on && role != 4;  // spans time the 128x128-tile kernel only
     if (prof) {
       TGP_TRY(prof_event(ctx, &sp.e0));
       TGP_TRY(prof_event(ctx, &sp.e1));
-      TGP_HIP_TRY(hipEventRecord(sp.e0, S0));
+      TGP_HIP_TRY(hipEventRecord(sp.e0, sq));
     }
-    TGP_TRY(launch_gemm_nt<T>(ctx, S0, m, nn, kb, P, ld, P, ld, C, ld, 1, 0, role));
+    TGP_TRY(launch_gemm_nt<T>(ctx, sq, m, nn, kb, P, ld, P, ld, C, ld, 1, 0, role));
     if (prof) {
-      TGP_HIP_TRY(hipEventRecord(sp.e1, S0));
+      TGP_HIP_TRY(hipEventRecord(sp.e1, sq));
       // algorithmic flops of the lower-trapezoid update: entries (i >= j) x 2 kb
       const double entries = double(nn) * double(m) - double(nn) * double(nn - 1) / 2.0;
       sp.flops = 2.0 * entries * double(kb);
@@ -1143,7 +1144,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
       TGP_TRY(panel(S0, k0, kb, false, 0, no_mid));
       const int64_t next = k0 + kb, mt = n - next;
-      if (mt > 0) TGP_TRY(trailing(mt, mt, kb, A + k0 * ld + next, A + next * ld + next, 0));
+      if (mt > 0) TGP_TRY(trailing(S0, mt, mt, kb, A + k0 * ld + next, A + next * ld + next, 0));
     }
   } else {
     int64_t k_done = 0;
@@ -1161,7 +1162,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       const std::function<int(hipEvent_t)> early = [&](hipEvent_t ready) -> int {
         TGP_TRY(join_assembly());
         TGP_TRY(st_wait(ctx, S0, ready));
-        TGP_TRY(trailing(mt0, kbn0, split * TILE, A + kb0, A + kb0 * ld + kb0, first_role(mt0, kbn0)));
+        TGP_TRY(trailing(S0, mt0, kbn0, split * TILE, A + kb0, A + kb0 * ld + kb0, first_role(mt0, kbn0)));
         k_done = split * TILE;
         return TGP_OK;
       };
@@ -1181,7 +1182,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       // 1. block column of the next panel first ...
       // (`k_done` columns of this panel were already applied while its last blocks were
       // being factored -- see `early` below.)
-      TGP_TRY(trailing(mt, kbn, kb - k_done, P + k_done * ld, A + next * ld + next, first_role(mt, kbn)));
+      TGP_TRY(trailing(S0, mt, kbn, kb - k_done, P + k_done * ld, A + next * ld + next, first_role(mt, kbn)));
       k_done = 0;
       // the panel's first potf2 goes in front of the big update on the main stream: issued
       // beside it, it waits a whole round of tiles (~0.3 ms) for a free CU
@@ -1191,7 +1192,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       // panel take the host longer than a small update takes the GPU) ...
       const int64_t m2 = mt - kbn;
       if (m2 > 0) {
-        TGP_TRY(trailing(m2, m2, kb, P + kbn, A + (next + kbn) * ld + next + kbn, 0));
+        TGP_TRY(trailing(S0, m2, m2, kb, P + kbn, A + (next + kbn) * ld + next + kbn, 0));
       }
       // 3. ... while the side stream factors the next panel.  Once its first `first_split`
       // blocks are final, their share of the block-column update that will gate the panel
@@ -1206,7 +1207,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       const int64_t split = (mt2 > 0 && fs > 0 && fs < kbn / TILE) ? fs : 0;
       const std::function<int(hipEvent_t)> early = [&](hipEvent_t ready) -> int {
         TGP_TRY(st_wait(ctx, S0, ready));
-        TGP_TRY(trailing(mt2, kbn2, split * TILE, A + next * ld + next2, A + next2 * ld + next2,
+        TGP_TRY(trailing(S0, mt2, kbn2, split * TILE, A + next * ld + next2, A + next2 * ld + next2,
                          first_role(mt2, kbn2)));
         k_done = split * TILE;
         return TGP_OK;

@@ -46,6 +46,7 @@ struct tgp_dist {
   double* d_logdet = nullptr;  // per-panel sum log L_ii (nblk) + [nblk] = sum of squares
   int64_t n_own = 0;
   bool solving = false, asm_pending = false;
+  bool asm_deferred = false;  // owned block columns l >= 1 are still to be assembled (tgp_dist_first_panel)
   KProg kp{};
 };
 
@@ -126,6 +127,28 @@ int factor_and_pack(tgp_dist* h, int64_t k, bool head_done) {
   hipLaunchKernelGGL((pack_panel_kernel<T>), dim3(gx, (unsigned)h->nb), dim3(256), 0, S1, Ap, ld,
                      slot + nd, rows);
   TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+// K(X, X) + noise for the owned block columns (lower part of each), identity padding.  Only the
+// first owned column is assembled here (it gates this rank's first panel or first update); the
+// others follow on the same main stream in tgp_dist_first_panel, BEHIND the point where the first
+// panel's chain branches off to the priority stream -- hidden beside that chain without a stream of
+// their own (a rank with peers should have no more than four streams in use, the collective
+// library's included: profiles/r02_m_stream_count.txt).
+template <typename T>
+int assemble_columns(tgp_dist* h, int64_t l_begin, int64_t l_end) {
+  tgp_ctx* ctx = h->ctx;
+  const int flags = KMAT_LOWER | KMAT_PAD_IDENTITY;
+  for (int64_t l = l_begin; l < l_end; ++l) {
+    const int64_t j0 = (l * h->G + h->rank) * h->nb;
+    const int64_t n1 = std::max<int64_t>(h->n - j0, 0), n2 = std::max<int64_t>(std::min(h->nb, h->n - j0), 0);
+    const int64_t x0 = std::min(j0, h->n);
+    TGP_TRY(launch_kmat_cols<T>(ctx, ctx->stream, h->kp, n1, n2, h->d, (const T*)h->X + x0 * h->d,
+                                (const T*)h->X + x0 * h->d, (const T*)h->diag + x0,
+                                (T*)h->A + l * h->nb * h->npad + j0, h->npad, h->npad - j0, h->nb,
+                                flags, 0, h->nb / TILE));
+  }
   return TGP_OK;
 }
 
@@ -227,35 +250,14 @@ int tgp_dist_stream(tgp_dist* h, int which, void** stream_out) {
   return TGP_OK;
 }
 
-// K(X, X) + noise for the owned block columns (lower part of each), identity padding.  The
-// first owned column on the main stream (it gates this rank's first panel or first update),
-// the others on the assembly stream beside whatever comes first.
 int tgp_dist_assemble(tgp_dist* h, const tgp_kop* prog, int nops) {
   DIST_GUARD(h);
   TGP_TRY(make_kprog(prog, nops, &h->kp));
-  tgp_ctx* ctx = h->ctx;
+  h->asm_pending = false;
+  h->asm_deferred = h->nloc > 1;
   return ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
-    const int flags = KMAT_LOWER | KMAT_PAD_IDENTITY;
-    if (h->nloc > 1) {
-      TGP_HIP_TRY(hipEventRecord(ctx->ev_asm, ctx->stream));
-      TGP_HIP_TRY(hipStreamWaitEvent(ctx->asm_stream, ctx->ev_asm, 0));
-    }
-    for (int64_t l = 0; l < h->nloc; ++l) {
-      const int64_t j0 = (l * h->G + h->rank) * h->nb;
-      const int64_t n1 = std::max<int64_t>(h->n - j0, 0), n2 = std::max<int64_t>(std::min(h->nb, h->n - j0), 0);
-      const int64_t x0 = std::min(j0, h->n);
-      hipStream_t st = l == 0 ? ctx->stream : ctx->asm_stream;
-      TGP_TRY(launch_kmat_cols<T>(ctx, st, h->kp, n1, n2, h->d, (const T*)h->X + x0 * h->d,
-                                  (const T*)h->X + x0 * h->d, (const T*)h->diag + x0,
-                                  (T*)h->A + l * h->nb * h->npad + j0, h->npad, h->npad - j0, h->nb,
-                                  flags, 0, h->nb / TILE));
-    }
-    if (h->nloc > 1) {
-      TGP_HIP_TRY(hipEventRecord(ctx->ev_asm, ctx->asm_stream));
-      h->asm_pending = true;
-    }
-    return TGP_OK;
+    return assemble_columns<T>(h, 0, std::min<int64_t>(h->nloc, 1));
   });
 }
 
@@ -277,13 +279,18 @@ int tgp_dist_begin(tgp_dist* h, const void* resid_host) {
   return TGP_OK;
 }
 
-// Owner of panel 0 only: its chain + pack.  (Later panels are started by tgp_dist_after_recv.)
+// Owner of panel 0: its chain + pack.  Every rank: the rest of its block columns is assembled now.
+// (Later panels are started by tgp_dist_after_recv.)
 int tgp_dist_first_panel(tgp_dist* h) {
   DIST_GUARD(h);
-  if (owner_of(h, 0) != h->rank) return TGP_OK;
   return ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
-    return factor_and_pack<T>(h, 0, false);
+    if (owner_of(h, 0) == h->rank) TGP_TRY(factor_and_pack<T>(h, 0, false));
+    if (h->asm_deferred) {
+      h->asm_deferred = false;
+      TGP_TRY(assemble_columns<T>(h, 1, h->nloc));
+    }
+    return TGP_OK;
   });
 }
 
@@ -331,7 +338,10 @@ int tgp_dist_fwd_step(tgp_dist* h, int64_t k) {
   DIST_GUARD(h);
   TGP_ARG_CHECK(k >= 0 && k < h->nblk, "panel index out of range");
   tgp_ctx* ctx = h->ctx;
-  hipStream_t S2 = ctx->solve_stream;  // (on the update stream, as in potrf: no gain here -- 30.98 vs 30.75 ms)
+  // stream: the update stream (behind the in-panel updates of the chain that was queued just before;
+  // the steps have two panels of slack), so that a rank uses three streams of its own
+  if (ctx->dist_solve_aux == 0) TGP_TRY(ensure_solve_stream(ctx));
+  hipStream_t S2 = ctx->dist_solve_aux != 0 ? ctx->update_stream : ctx->solve_stream;
   return ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
     const int64_t rows = rows_of(h, k), nb = h->nb, nd = slot_dinv_elems(h);

@@ -86,6 +86,7 @@ struct tgp_ctx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_e = nullptr;
   int64_t nb_outer = 1024;  // measured best for N = 4k .. 32k (profiles/r01_f_nb_sweep.txt)
   int64_t lookahead = 1;
+  int64_t dist_solve_aux = 1;  // block-column driver: forward steps on the update stream (0: a solve stream of their own)
   // the fused forward-substitution steps ride on the update stream, behind the in-panel update of the same
   // block: three busy queues instead of four (c2 30.3 -> 29.8 ms, N = 4096 2.66 -> 2.45 ms; 0: own stream)
   int64_t solve_on_update = 1;
@@ -164,6 +165,7 @@ inline int st_wait(tgp_ctx* ctx, hipStream_t st, hipEvent_t ev) {
 
 int ensure_dinv(tgp_ctx* ctx, size_t bytes);
 int ensure_work(tgp_ctx* ctx, size_t bytes);
+int ensure_solve_stream(tgp_ctx* ctx);  // the solve stream exists only once something asks for it
 
 // ---- launchers (all async on the given stream) -------------------------------------
 template <typename T>

@@ -215,13 +215,11 @@ class BlockCyclicCholesky:
         self.info = 0
         self.factored = self.solved = self.have_alpha = False
         self.bytes_received = 0  # panel bytes this rank received in the last factorisation
-        # A process group of one has nobody to broadcast to.  Routing the panels through the
-        # collective library anyway costs 40 instead of 31 ms per evaluation at N = 16 384: with its
-        # stream in play the dependent launches of the panel chains arrive later on the device (the
-        # host is not the limit -- it has everything enqueued within 5 ms;
-        # profiles/r02_k_block_column_queues.txt).  TGP_DIST_SELF_BROADCAST=1 keeps the call, to
-        # time exactly that.
-        self.self_broadcast = os.environ.get("TGP_DIST_SELF_BROADCAST", "0") == "1"
+        # A process group of one still sends its panels through the collective (the same code path as
+        # with peers; 30.9 vs 30.8 ms at N = 16 384 since the driver keeps to three streams of its own
+        # -- with five in use plus RCCL's it was 39.5 ms, profiles/r02_m_stream_count.txt).
+        # TGP_DIST_SELF_BROADCAST=0 skips the call.
+        self.self_broadcast = os.environ.get("TGP_DIST_SELF_BROADCAST", "1") != "0"
 
     def rows(self, j: int) -> int:
         return self.npad - j * self.nb
