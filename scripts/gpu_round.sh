@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 2, batch 25: block-column driver with three streams of its own (assembly deferred on the main stream, forward steps on the update stream)
+# round 2, batch 27: the big update of a step launched after the first blocks of the next chain (head_blocks / head_rows)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -9,20 +9,15 @@ B="--no-cpu-baseline --no-secondary"
 line() { python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d.get('roofline') or {}
-print('$1', 'evals/s %.2f ms %.2f  update %.1f TF (%.3f)' % (d['value'], d['ms_per_step'], r.get('achieved',0), r.get('frac',0)))"; }
+print('$1', 'evals/s %.2f ms %.2f  update %.1f TF (%.3f)  potrf %.2f ms' % (d['value'], d['ms_per_step'], r.get('achieved',0), r.get('frac',0), (d.get('stage_ms') or {}).get('potrf',0)))"; }
 {
-for w in c2 n8192; do
-  timeout 120 python bench.py $B --workload $w --steps 10 --warmup 3 2>/dev/null | tail -1 | line "single $w"
-  for sb in 0 1; do
-  TGP_DIST_SELF_BROADCAST=$sb timeout 300 python bench.py $B --distributed --workload $w --steps 10 --warmup 3 2>/dev/null | tail -1 | line "dist $w [self_broadcast=$sb]"
-  done
+for opts in "head_blocks=0" "head_blocks=1,head_rows=100000" "head_blocks=1,head_rows=11000" "head_blocks=1,head_rows=8000" "head_blocks=2,head_rows=100000" "head_blocks=2,head_rows=11000" "head_blocks=2,head_rows=8000" "head_blocks=3,head_rows=9000" "head_blocks=4,head_rows=7000"; do
+  TGP_HIP_OPTIONS="$opts" timeout 120 python bench.py $B --steps 10 --warmup 3 2>/dev/null | tail -1 | line "c2 [$opts]"
 done
-for sb in 0 1; do
-TGP_DIST_SELF_BROADCAST=$sb timeout 300 python bench.py $B --distributed --workload n65536 --steps 2 --warmup 1 2>/dev/null | tail -1 | line "dist n65536 [self_broadcast=$sb]"
-done
-timeout 600 python bench.py $B --distributed --workload c4 --steps 1 --warmup 1 2>/dev/null | tail -1 | line "dist c4"
-timeout 900 python -m pytest tests/test_gpu_distributed.py -m gpu -q -x 2>&1 | grep -E "passed|failed"
-TGP_DIST_SELF_BROADCAST=1 timeout 900 python -m pytest tests/test_gpu_distributed.py -m gpu -q -x 2>&1 | grep -E "passed|failed"
+for w in n8192 n32768; do for opts in "head_blocks=0" "head_blocks=1,head_rows=11000" "head_blocks=2,head_rows=11000"; do
+  TGP_HIP_OPTIONS="$opts" timeout 120 python bench.py $B --workload $w --steps 5 --warmup 2 2>/dev/null | tail -1 | line "$w [$opts]"
+done; done
+TGP_HIP_OPTIONS="head_blocks=2,head_rows=11000" timeout 900 python -m pytest tests/test_gpu_gp.py tests/test_gpu_kernels.py -m gpu -q -x 2>&1 | grep -E "passed|failed"
 date
 } > $O/round.log 2>&1
 tail -60 $O/round.log

@@ -19,9 +19,9 @@ def read(path):
 
 
 rows = read(sys.argv[1])
-idx = [i for i, r in enumerate(rows) if r["name"].startswith("kmat_kernel")]
+idx = [i for i, r in enumerate(rows) if r["name"].startswith(("kmat_kernel", "kmat_fast_kernel"))]
 # the last step starts at the last kmat launch that follows a reduction kernel (two kmat launches per step)
-starts = [i for i in idx if i == 0 or not rows[i - 1]["name"].startswith("kmat_kernel")]
+starts = [i for i in idx if i == 0 or not rows[i - 1]["name"].startswith(("kmat_kernel", "kmat_fast_kernel"))]
 step = rows[starts[-1]:]
 t0 = step[0]["start"]
 print("step %.0f us, %d kernels" % (step[-1]["end"] - t0, len(step)))
