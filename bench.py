@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured co
 # units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM" for wide coalesced reads).  PMC
 # collection serialises kernels, so it cannot run inside the timed region; configurations
 # other than the one the passes were collected on report null.
-PMC_TRAFFIC = {"file": "profiles/r02_e_final_evidence.md",
+PMC_TRAFFIC = {"file": "profiles/r02_n_final_evidence.md",
                "bytes_per_launch": (2 * 55.119e9 + 12.634e9) / 42, "nb": 1024}
 
 
@@ -323,7 +323,7 @@ def secondary_rooflines(ctx, solver, spec, kernel):
         ctx.sync()
         dt = (time.perf_counter() - t0) / reps
         nbytes = es * n * (n + 1) / 2
-        out.append({"kernel": "kmat_kernel (assembly of the lower triangle)", "bound": "hbm",
+        out.append({"kernel": "kmat_fast_kernel (assembly of the lower triangle)", "bound": "hbm",
                     "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "ms": dt * 1e3,
                     "algorithmic_bytes": nbytes, "note": "bytes written; host-timed over 5 launches"})
