@@ -845,7 +845,18 @@ int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, doub
     // K^-1 = L^-T L^-1 = M M^T, lower tiles, k-loop from the row tile (M upper triangular)
     TGP_TRY(launch_gemm_nt<T>(ctx, ctx->stream, s->npad, s->npad, s->npad, (const T*)s->Minv, s->npad,
                               (const T*)s->Minv, s->npad, (T*)s->Kinv, s->npad, 1, 5, 1));
-    for (int i = 0; i < s->kp.n; ++i) {
+    int fleaf = -1, fkonst = -1;
+    const int fast = launch_kgrad_fast<T>(ctx, s->kp, s->n, s->d, (const T*)s->X, (const T*)alpha,
+                                          (const T*)s->Kinv, s->npad, ctx->d_scal + 2, &fleaf, &fkonst);
+    if (fast < 0) return fast;
+    if (fast == 1) {  // d_scal[2] = d/d constant, d_scal[3] = d/d scale
+      if (fkonst >= 0)
+        TGP_HIP_TRY(hipMemcpyAsync(&g[size_t(2 * fkonst)], ctx->d_scal + 2, sizeof(double),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+      TGP_HIP_TRY(hipMemcpyAsync(&g[size_t(2 * fleaf)], ctx->d_scal + 3, sizeof(double), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    }
+    for (int i = 0; i < s->kp.n && fast == 0; ++i) {
       const int op = s->kp.op[i];
       if (op >= TGP_K_ADD) continue;
       const int nparam = (op == TGP_K_ESS || op == TGP_K_RQ) ? 2 : 1;

@@ -156,6 +156,7 @@ constexpr int KT = 128;  // tile edge
 struct FastProg {
   int op = -1, l2 = 0;   // op < 0: not a fast program
   double p0 = 1, amp = 1;
+  int leaf = -1, konst = -1;  // positions of the leaf and of the constant (-1: none) in the program
 };
 static FastProg fast_prog(const KProg& kp) {
   FastProg f;
@@ -171,6 +172,8 @@ static FastProg fast_prog(const KProg& kp) {
   f.l2 = kp.metric[li] == TGP_METRIC_L2;
   f.p0 = kp.p0[li];
   f.amp = ci >= 0 ? kp.p0[ci] : 1.0;  // x * 1 == x exactly
+  f.leaf = li;
+  f.konst = ci;
   return f;
 }
 
@@ -434,6 +437,91 @@ __global__ __launch_bounds__(256) void kmat_gemv_kernel(KProg kp, int64_t n1, in
     for (int r = 0; r < nv; ++r) partial[(int64_t(blockIdx.y) * nv + r) * n1 + i] = acc[r];
 }
 
+
+
+// d(leaf)/d(scale), the expressions of leaf_deriv with op and metric fixed at compile time
+template <typename T, int OP, int L2>
+__device__ __forceinline__ T leaf_deriv_fast(T r1, T r2, T p0) {
+  if constexpr (OP == TGP_K_EXPSQ) {
+    const T sq = L2 ? r2 : r1 * r1;
+    return exp(T(-0.5) * (sq / (p0 * p0))) * sq / (p0 * p0 * p0);
+  } else {
+    const T dist = L2 ? ((r2 == T(0)) ? r1 : sqrt(r2)) : r1;
+    if constexpr (OP == TGP_K_EXP) {
+      return exp(-dist / p0) * dist / (p0 * p0);
+    } else if constexpr (OP == TGP_K_M32) {
+      const T a = MathC<T>::SQRT3 * (dist / p0);
+      return a * a * exp(-a) / p0;
+    } else {
+      const T a = MathC<T>::SQRT5 * (dist / p0);
+      return (a * a / T(3)) * (T(1) + a) * exp(-a) / p0;
+    }
+  }
+}
+
+// kgrad_kernel for "leaf" / "amp * leaf" programs: BOTH derivatives (d/d amp = leaf,
+// d/d scale = amp * d leaf) in one pass over K^-1.  partial[tile] and partial[ntiles + tile].
+template <typename T, int OP, int L2>
+__global__ __launch_bounds__(256) void kgrad_fast_kernel(T p0, T amp, int64_t n, int d,
+                                                         const T* __restrict__ X,
+                                                         const T* __restrict__ alpha,
+                                                         const T* __restrict__ Kinv, int64_t ld,
+                                                         double* __restrict__ partial) {
+  const int tr = blockIdx.x, tc = blockIdx.y;
+  const int tile_id = tr * gridDim.y + tc, ntiles = gridDim.x * gridDim.y;
+  if (tr < tc) {
+    if (threadIdx.x == 0) partial[tile_id] = partial[ntiles + tile_id] = 0.0;
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* s1 = reinterpret_cast<T*>(smem);  // [KT][d]
+  T* s2 = s1 + KT * d;                 // [KT][d]
+  __shared__ double red[2][256];
+  const int64_t r0 = int64_t(tr) * KT, c0 = int64_t(tc) * KT;
+  for (int t = threadIdx.x; t < KT * d; t += 256) {
+    const int64_t gi = r0 + t / d, gj = c0 + t / d;
+    s1[t] = (gi < n) ? X[gi * d + t % d] : T(0);
+    s2[t] = (gj < n) ? X[gj * d + t % d] : T(0);
+  }
+  __syncthreads();
+  const int il = threadIdx.x & (KT - 1), g = threadIdx.x >> 7;
+  const int64_t gi = r0 + il;
+  const T ai = (gi < n) ? alpha[gi] : T(0);
+  const T p0sq = p0 * p0;
+  double acc_a = 0.0, acc_s = 0.0;
+  if (gi < n) {
+    for (int c = 0; c < KT / 2; ++c) {
+      const int jl = g * (KT / 2) + c;
+      const int64_t gj = c0 + jl;
+      if (gj >= n || gj > gi) continue;
+      T r1 = 0, r2 = 0;
+      for (int t = 0; t < d; ++t) {
+        const T dx = s1[il * d + t] - s2[jl * d + t];
+        r1 += fabs(dx);
+        r2 += dx * dx;
+      }
+      const T leaf = leaf_fast<T, OP, L2>(r1, r2, p0, p0sq);
+      const T dk = amp * leaf_deriv_fast<T, OP, L2>(r1, r2, p0);
+      const double w = double(ai * alpha[gj] - Kinv[gj * ld + gi]) * (gi == gj ? 0.5 : 1.0);
+      acc_a += w * double(leaf);
+      acc_s += w * double(dk);
+    }
+  }
+  red[0][threadIdx.x] = acc_a;
+  red[1][threadIdx.x] = acc_s;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + sft];
+      red[1][threadIdx.x] += red[1][threadIdx.x + sft];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[tile_id] = red[0][0];
+    partial[ntiles + tile_id] = red[1][0];
+  }
+}
 
 // the same for "leaf" / "amp * leaf" programs: straight-line inner loop (see kmat_fast_kernel)
 template <typename T, int OP, int L2>
@@ -702,6 +790,42 @@ int launch_kgrad(tgp_ctx* ctx, const KProg& kp, int which_op, int which_param, i
   return TGP_OK;
 }
 
+// Gradient sums of a "leaf" / "amp * leaf" program in one pass: out_dev[0] = d/d(constant) (only
+// meaningful when the program has one), out_dev[1] = d/d(scale).  Returns 1 when the program is
+// of that shape (*leaf / *konst = their positions, -1: none), 0 when the caller must use launch_kgrad.
+template <typename T>
+int launch_kgrad_fast(tgp_ctx* ctx, const KProg& kp, int64_t n, int d, const T* X, const T* alpha,
+                      const T* Kinv, int64_t ld, double* out_dev, int* leaf, int* konst) {
+  const FastProg fp = fast_prog(kp);
+  if (fp.op < 0) return 0;
+  const int64_t tiles = (n + KT - 1) / KT;
+  TGP_ARG_CHECK(tiles <= 65535, "kgrad: too many tiles");
+  TGP_TRY(ensure_work(ctx, 2 * size_t(tiles) * tiles * sizeof(double)));
+  double* partial = static_cast<double*>(ctx->d_work);
+  const size_t shmem = 2 * size_t(KT) * d * sizeof(T);
+  const dim3 grid((unsigned)tiles, (unsigned)tiles);
+#define TGP_KG3(OP, L2)                                                                            \
+  hipLaunchKernelGGL((kgrad_fast_kernel<T, OP, L2>), grid, dim3(256), shmem, ctx->stream, T(fp.p0), \
+                     T(fp.amp), n, d, X, alpha, Kinv, ld, partial)
+#define TGP_KG2(OP)                                                                                \
+  do {                                                                                            \
+    if (fp.l2) TGP_KG3(OP, 1); else TGP_KG3(OP, 0);                                                \
+  } while (0)
+  if (fp.op == TGP_K_EXP) TGP_KG2(TGP_K_EXP);
+  else if (fp.op == TGP_K_EXPSQ) TGP_KG2(TGP_K_EXPSQ);
+  else if (fp.op == TGP_K_M32) TGP_KG2(TGP_K_M32);
+  else TGP_KG2(TGP_K_M52);
+#undef TGP_KG2
+#undef TGP_KG3
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream, tiles * tiles, partial, out_dev);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream, tiles * tiles,
+                     partial + tiles * tiles, out_dev + 1);
+  TGP_HIP_TRY(hipGetLastError());
+  *leaf = fp.leaf;
+  *konst = fp.konst;
+  return 1;
+}
+
 template <typename T>
 int launch_noise_grad(tgp_ctx* ctx, int64_t n, const T* alpha, const T* Kinv, int64_t ld, T* out) {
   hipLaunchKernelGGL((noise_grad_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -714,6 +838,8 @@ int launch_noise_grad(tgp_ctx* ctx, int64_t n, const T* alpha, const T* Kinv, in
   template int launch_kgrad<T>(tgp_ctx*, const KProg&, int, int, int64_t, int, const T*, const T*, \
                                const T*, int64_t, double*);                                       \
   template int launch_noise_grad<T>(tgp_ctx*, int64_t, const T*, const T*, int64_t, T*);          \
+  template int launch_kgrad_fast<T>(tgp_ctx*, const KProg&, int64_t, int, const T*, const T*,     \
+                                    const T*, int64_t, double*, int*, int*);                      \
   template int launch_kmat<T>(tgp_ctx*, const KProg&, int64_t, int64_t, int, const T*, const T*,  \
                               const T*, T*, int64_t, int64_t, int64_t, int);                      \
   template int launch_kmat_cols<T>(tgp_ctx*, hipStream_t, const KProg&, int64_t, int64_t, int,    \

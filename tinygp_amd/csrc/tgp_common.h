@@ -268,6 +268,11 @@ int launch_kgrad(tgp_ctx* ctx, const KProg& kp, int which_op, int which_param, i
                  const T* X, const T* alpha, const T* Kinv, int64_t ld, double* out_dev);
 template <typename T>
 int launch_noise_grad(tgp_ctx* ctx, int64_t n, const T* alpha, const T* Kinv, int64_t ld, T* out);
+// "leaf" / "amp * leaf" programs: both kernel-parameter sums in ONE pass over K^-1 (returns 0 when
+// the program has another shape: use launch_kgrad per parameter)
+template <typename T>
+int launch_kgrad_fast(tgp_ctx* ctx, const KProg& kp, int64_t n, int d, const T* X, const T* alpha,
+                      const T* Kinv, int64_t ld, double* out_dev, int* leaf, int* konst);
 
 int ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops);
 int ubench(tgp_ctx* ctx, int kind, int blocks_per_cu, double* tflops, double* cycles_per_op);
