@@ -552,6 +552,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # Rehearsal of the N > 1 launch line on a box with ONE GPU (tests/test_gpu_bench_contract.py): every
+    # rank uses device 0 and the collectives go through gloo (RCCL refuses two ranks on one device).
+    # The line it prints carries "rehearsal": true -- its numbers mean nothing.
+    rehearsal = os.environ.get("TGP_BENCH_ONE_GPU", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -568,7 +574,9 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if world > 1:
+        if rehearsal:
+            dist_mod.init_process_group(backend="gloo")
+        elif world > 1:
             dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:  # a single rank still goes through RCCL (self-broadcast)
             dist_mod.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
@@ -594,6 +602,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and out is not None:
+        if rehearsal:
+            out["rehearsal"] = True
         emit(out)
 
 

@@ -1,0 +1,51 @@
+"""bench.py's contract at N > 1, rehearsed on the one GPU a test box has: the driver's launch
+line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W`)
+with every rank on device 0 and gloo collectives (TGP_BENCH_ONE_GPU=1).  Checks what can be checked
+without N GPUs: it runs, rank 0 prints exactly one JSON line, the line has the contract's fields for
+the block-column path (strong scaling, broadcast volume per rank, roofline), and the replicas mode
+prints the weak-scaling aggregate."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _launch(nproc, extra, port):
+    env = dict(os.environ, TGP_BENCH_ONE_GPU="1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+           "--gpus", str(nproc), "--steps", "2", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_block_column_line_at_two_ranks():
+    d = _launch(2, ["--workload", "n4096", "--no-cpu-baseline"], 29811)
+    assert d["rehearsal"] is True
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["scaling"] == "strong" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "evals/s" and d["value"] > 0 and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    assert d["config"]["parallelism"] == "block-cyclic columns x2" and d["config"]["n"] == 4096
+    # rank 0 owns panels 0 and 2 of four: it receives panels 1 and 3 (rows x 1024 doubles + dinv each)
+    nb, npad = 1024, 4096
+    expect = sum(((npad - k * nb) * nb + (nb // 128) * 2048) * 8 for k in (1, 3))
+    assert d["panel_broadcast_bytes_received_per_rank"] == expect
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+
+
+def test_replicas_line_at_two_ranks():
+    d = _launch(2, ["--replicas", "--workload", "n2048", "--no-cpu-baseline", "--no-secondary"], 29813)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # whole-job aggregate: two evaluations per step time
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2.0) < 1e-6
