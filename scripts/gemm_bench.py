@@ -16,7 +16,7 @@ es = np.dtype(dt).itemsize
 code = _ffi.dtype_code(dt)
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 for mode, lower in (((-1.0, 1.0), 0), ((-1.0, 1.0), 1)):
-  for K in (512, 1024):
+  for K in (16, 128, 512, 1024, 2048):
     if True:
         rng = np.random.default_rng(0)
         dA = ctx.upload(rng.normal(size=M * K).astype(dt))

@@ -18,6 +18,8 @@
 // The MFMA "A" operand is fed with rows of B (the C COLUMN index) and the "B" operand with
 // rows of A (the C ROW index): D[a][b] = C[i=b][j=a], so a lane's 16-lane group writes 16
 // consecutive rows of one C column = 128 contiguous bytes per group (full lines).
+#include <type_traits>
+
 #include "tgp_common.h"
 
 namespace tgp {
@@ -190,19 +192,74 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) rot[t] = 4 * ((lq + t) & 3) + lj;
 
-    load_global(kt0);
-    store_lds(kt0 & 1);
-    __syncthreads();
-    for (int kt = kt0; kt < nkt; ++kt) {
+    // The C read-modify-write used to be an epilogue that no MFMA overlapped (a fixed 0.92 ms per
+    // 16384^2 launch, 10 % of a K = 1024 update: every workgroup of the chip reads and writes its
+    // tile in the same few microseconds).  With at least NCH + 1 k-tiles the READ half is spread
+    // over the k-loop instead: k-tile r fetches chunk r of C (two of a lane's 64 entries) right
+    // behind the operand prefetch and subtracts it one k-tile later, when the in-order return of
+    // the operand loads has already proved it complete -- no additional wait.  The MFMA operand
+    // read from LDS is negated on the way, so the accumulators end as C - A B^T and the epilogue
+    // is 64 stores, nothing loaded.
+    constexpr int NCH = 8;  // chunks of eight entries: (a, b-pair)
+    const bool pipe = (g.mode == 0) && (nkt - kt0 >= NCH);
+    double cst[8];
+    // C addresses as a wave-uniform base (SGPRs) + four loop-invariant 32-bit lane offsets: no
+    // per-chunk address registers
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const char* Cu = reinterpret_cast<const char*>(g.C + (j0 + (wu & 1) * 64) * g.ldc + i0 + (wu >> 1) * 64);
+    uint32_t voff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) voff[t] = uint32_t((int64_t(4 * lq + lk) * g.ldc + rot[t]) * 8);
+    // Operand staging is direct global -> LDS (global_load_lds_dwordx4: one wave instruction moves the
+    // 1 KiB k-row of 128 elements straight into its LDS row -- LDS address in M0, lane l lands at
+    // +16 l): no staging VGPRs, no ds_write pass.  Issued one k-tile ahead into the other buffer.
+    // Written as asm: through the builtin the compiler orders every later ds_read behind the
+    // transfer (vmcnt(0) at the top of the k-tile it was meant to overlap); here the only wait is
+    // the explicit one in front of the barrier that ends the k-tile.
+    const uint32_t lds_a = uint32_t(size_t((__attribute__((address_space(3))) T*)(&sA[0][0]))) + uint32_t(wu * LDS_LD * 8);
+    const uint32_t lds_b = uint32_t(size_t((__attribute__((address_space(3))) T*)(&sB[0][0]))) + uint32_t(wu * LDS_LD * 8);
+    const T* Au = g.A + i0;                 // wave-uniform row bases; the lane adds 16 l bytes
+    const T* Bu = g.B + int64_t(gt) * BN;
+    const uint32_t lane16 = uint32_t(lane) * 16u;
+    auto issue_tile = [&](int kt_, int buf_) {
+      const int64_t kg = int64_t(kt_) * BK + wu;
+#pragma unroll
+      for (int r = 0; r < BK / 4; ++r) {
+        const T* ap = Au + (kg + 4 * r) * g.lda;
+        const T* bp = Bu + (kg + 4 * r) * g.ldb;
+        const uint32_t off = uint32_t((buf_ * BK + 4 * r) * LDS_LD * 8);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(lane16), "s"(ap), "s"(lds_a + off) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(lane16), "s"(bp), "s"(lds_b + off) : "memory", "m0");
+      }
+    };
+    auto tile_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // STAGE: -1 plain k-tile; c in 0..NCH-1: fetch chunk c of C behind the operand prefetch and
+    // add it behind the barrier that ends the k-tile (the vmcnt(0) in front of it -- needed for the
+    // LDS-direct loads anyway -- has completed it: no wait of its own)
+    auto ktile = [&](int kt, auto stage, auto negated) {
+      constexpr int c = decltype(stage)::value;
       const int buf = kt & 1;
-      if (kt + 1 < nkt) load_global(kt + 1);
+      if (kt + 1 < nkt) issue_tile(kt + 1, buf ^ 1);
+      if constexpr (c >= 0) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const char* cb = Cu + (int64_t((c >> 1) * 16) * g.ldc + ((c & 1) * 2 + bb) * 16) * 8;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) cst[bb * 4 + t] = *reinterpret_cast<const double*>(cb + voff[t]);
+        }
+      }
       const T* pa = &sB[buf][lk * LDS_LD + wc * 64 + lrow];
       const T* pb = &sA[buf][lk * LDS_LD + wr * 64];
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) {
         double aop[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * LDS_LD + a * 16];
+        for (int a = 0; a < 4; ++a) {
+          aop[a] = pa[ks * 4 * LDS_LD + a * 16];
+          if constexpr (decltype(negated)::value) aop[a] = -aop[a];  // accumulate -A B^T
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           double bop[4];
@@ -215,12 +272,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
               acc[a][b][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aop[a], bop[t], acc[a][b][t], 0, 0, 0);
         }
       }
-      if (kt + 1 < nkt) store_lds(buf ^ 1);
+      tile_landed();
       __syncthreads();
+      if constexpr (c >= 0) {
+        __builtin_amdgcn_sched_barrier(0);  // the adds stay behind the barrier's wait
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[c >> 1][(c & 1) * 2 + bb][t] += cst[bb * 4 + t];
+      }
+    };
+    issue_tile(kt0, kt0 & 1);
+    tile_landed();
+    __syncthreads();
+    int kt = kt0;
+    if (pipe) {
+      // every staged k-tile is its own (single-trip) loop: as one straight-line block the nine
+      // bodies are scheduled together and spill
+      int one = 1;
+      asm volatile("" : "+s"(one));
+#define TGP_STAGED(C) \
+  for (int q = 0; q < one; ++q, ++kt) ktile(kt, std::integral_constant<int, C>{}, std::true_type{});
+      TGP_STAGED(0) TGP_STAGED(1) TGP_STAGED(2) TGP_STAGED(3) TGP_STAGED(4)
+      TGP_STAGED(5) TGP_STAGED(6) TGP_STAGED(7)
+#undef TGP_STAGED
+      for (; kt < nkt; ++kt) ktile(kt, std::integral_constant<int, -1>{}, std::true_type{});
+    } else {
+      for (; kt < nkt; ++kt) ktile(kt, std::integral_constant<int, -1>{}, std::false_type{});
     }
-    // epilogue.  The read-modify-write is batched: 32 independent loads in flight, then 32
-    // stores, twice (element by element it is 64 dependent HBM round trips per lane).
-    if (g.mode == 0) {
+    if (pipe) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          char* cb = const_cast<char*>(Cu) + (int64_t(a * 16) * g.ldc + b * 16) * 8;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) *reinterpret_cast<double*>(cb + voff[t]) = acc[a][b][t];
+        }
+      }
+    } else if (g.mode == 0) {
+      // short k: the read-modify-write is batched: 32 independent loads in flight, then 32
+      // stores, twice (element by element it is 64 dependent HBM round trips per lane).
 #pragma unroll
       for (int ap = 0; ap < 4; ap += 2) {
         T* col[2];
