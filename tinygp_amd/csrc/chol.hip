@@ -109,18 +109,15 @@ __device__ long long g_potf2_stamps[64];
 #define POTF2_STAMP(i) do {} while (0)
 #endif
 
-// waves_per_eu(4): at most 128 VGPRs, so that two potf2 waves fit on a SIMD beside one wave of the
-// trailing-update GEMM (238 VGPRs) -- otherwise potf2 waits for the whole update to drain.
+// The body of potf2 (one workgroup of 512 threads; S = 36 x 256 elements and Rs = 32 elements of
+// LDS): shared by the stand-alone kernel and by the fused panel step (panel_step_kernel).
 template <typename T, bool FOLD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void potf2_kernel(T* __restrict__ A, int64_t ld,
-                                                    T* __restrict__ dinv,
-                                                    int32_t* __restrict__ info,
-                                                    int32_t pivot_base,
-                                                    const T* __restrict__ Xp, int64_t ldx) {
+__device__ __forceinline__ void potf2_body(T* __restrict__ S, T* __restrict__ Rs, T* __restrict__ A,
+                                           int64_t ld, T* __restrict__ dinv,
+                                           int32_t* __restrict__ info, int32_t pivot_base,
+                                           const T* __restrict__ Xp, int64_t ldx) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
-  __shared__ __attribute__((aligned(16))) T S[36 * 256];
-  __shared__ T Rs[2 * 16];                                 // 1 / L_ii of the current / previous block
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar address math
   const int lrow = lane & 15;
@@ -389,6 +386,240 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // column blocks 0..6 went out while later steps ran; the last one now, a slice per wave
   store_strip(7, 4 * w, 4 * w + 4);
   POTF2_STAMP(34);
+}
+
+// waves_per_eu(4): at most 128 VGPRs, so that two potf2 waves fit on a SIMD beside one wave of the
+// trailing-update GEMM (234 VGPRs) -- otherwise potf2 waits for the whole update to drain.
+template <typename T, bool FOLD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void potf2_kernel(T* __restrict__ A, int64_t ld,
+                                                    T* __restrict__ dinv,
+                                                    int32_t* __restrict__ info,
+                                                    int32_t pivot_base,
+                                                    const T* __restrict__ Xp, int64_t ldx) {
+  __shared__ __attribute__((aligned(16))) T S[36 * 256];
+  __shared__ T Rs[2 * 16];                                 // 1 / L_ii of the current / previous block
+  potf2_body<T, FOLD>(S, Rs, A, ld, dinv, info, pivot_base, Xp, ldx);
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused panel step: ONE launch per 128-column block instead of potf2 | trsm (+ the events between
+// them and the in-panel update of the next column block).
+//
+//   workgroup 0        potf2 of the diagonal tile (with the fold of its pending update), then it
+//                      publishes L_jj and its 16 x 16 inverses with an agent-scope release + flag;
+//   workgroups 1..m/128  one per 128-row tile below: while potf2 runs they are already resident and
+//                      apply the pending update of THEIR tile of this column block themselves
+//                      (A_ij -= X_i,j-1 X_j,j-1^T: a 128 x 128 x 128 product on the MFMAs, operands
+//                      double-buffered through the same 72 KiB of LDS potf2 uses), then wait for the
+//                      flag, stage L_jj / its inverses in LDS and solve their rows (trsm).
+//
+// Why: beside a running trailing update the separate kernels waited for workgroup slots one
+// after the other (trsm 55 us per launch in place against 12 on an idle chip, the in-panel update
+// 126 us), and the update of column block j+1 sat between trsm(j) and trsm(j+1).  Here the rows'
+// workgroups are placed while potf2 computes, the update they depend on is their own work, and
+// the in-panel update that is left (column blocks j+2.. -- launch_gemm_nt, role 1) has a whole
+// step of slack.  Workgroups are dispatched in index order, so workgroup 0 is resident whenever
+// another one polls; the poll is bounded all the same (a lost producer ends in info = INT32_MIN,
+// never in a hung GPU).
+// ---------------------------------------------------------------------------------------
+constexpr int32_t STEP_TIMEOUT = INT32_MIN;
+
+template <typename T, bool FOLD>
+__device__ __forceinline__ void trsm_fold_body(T* __restrict__ S, int it, const T* __restrict__ Ljj,
+                                               int64_t ld, const T* __restrict__ dinv,
+                                               const T* __restrict__ Xp, const uint32_t* flag,
+                                               uint32_t epoch, int wait_flag, int32_t* info) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lk = lane >> 4;
+  __builtin_amdgcn_s_setprio(2);
+  T* Bt = const_cast<T*>(Ljj) + TILE + int64_t(it) * TILE;  // this workgroup's 128 rows of the column block
+
+  if constexpr (FOLD) {
+    // C (128 x 128 at Bt) -= Xi Xj^T, Xi = the same rows of the previous block column, Xj = Xp
+    constexpr int FK = 16, F_LD = 144;  // as gemm_nt: [k][128 rows], 144 mod 32 == 16
+    static_assert(4 * FK * F_LD == 36 * 256, "the fold's operand buffers are exactly potf2's tile image");
+    T* sA = S;                  // [2][FK * F_LD]
+    T* sB = S + 2 * FK * F_LD;  // [2][FK * F_LD]
+    const T* Xi = Xp + TILE + int64_t(it) * TILE;
+    const int wr = w >> 1, wc = w & 1;  // wave tile: 32 rows x 64 columns
+    T2 ra[2], rb[2];
+    auto load_global = [&](int kt) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int64_t kk = int64_t(kt) * FK + w + 8 * r;
+        ra[r] = *reinterpret_cast<const T2*>(Xi + kk * ld + lane * 2);
+        rb[r] = *reinterpret_cast<const T2*>(Xp + kk * ld + lane * 2);
+      }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int kk = w + 8 * r;
+        *reinterpret_cast<T2*>(&sA[buf * FK * F_LD + kk * F_LD + lane * 2]) = ra[r];
+        *reinterpret_cast<T2*>(&sB[buf * FK * F_LD + kk * F_LD + lane * 2]) = rb[r];
+      }
+    };
+    acc_t acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    constexpr int nkt = TILE / FK;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nkt) load_global(kt + 1);
+      const T* pa = &sB[buf * FK * F_LD + lk * F_LD + wc * 64 + lrow];  // MFMA A operand <- Xj rows (C column)
+      const T* pb = &sA[buf * FK * F_LD + lk * F_LD + wr * 32 + lrow];  // MFMA B operand <- Xi rows (C row)
+#pragma unroll
+      for (int ks = 0; ks < FK / 4; ++ks) {
+        T aop[4], bop[2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bop[b] = pb[ks * 4 * F_LD + b * 16];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = M::mma(aop[a], bop[b], acc[a][b]);
+      }
+      if (kt + 1 < nkt) store_lds(buf ^ 1);
+      __syncthreads();
+    }
+    // C[wr*32 + b*16 + lrow, wc*64 + a*16 + drow(lane, r)] -= acc[a][b][r]; 16 loads in flight per pass
+    T* Cb = Bt + int64_t(wc * 64) * ld + wr * 32 + lrow;
+#pragma unroll
+    for (int a = 0; a < 4; a += 2) {
+      T c[2][2][4];
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            c[aa][b][r] = Cb[int64_t((a + aa) * 16 + M::drow(lane, r)) * ld + b * 16];
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Cb[int64_t((a + aa) * 16 + M::drow(lane, r)) * ld + b * 16] = c[aa][b][r] - acc[a + aa][b][r];
+    }
+    __syncthreads();  // the updated rows are visible to the whole workgroup; S is free again
+  }
+
+  if (wait_flag) {  // L_jj and its inverses come from workgroup 0 of this launch
+    if (tid == 0) {
+      uint32_t seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long spin = 0;
+      for (; seen != epoch && spin < (1L << 21); ++spin) {
+        __builtin_amdgcn_s_sleep(2);
+        seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (seen != epoch) atomicExch(info, STEP_TIMEOUT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    // (every wave reads the published tile for the first time below; the acquire above dropped
+    // this CU's L1 lines, which potf2's own CU -- possibly this one -- filled before factoring)
+  }
+
+  // L_jj -> LDS in potf2's block image: the 28 blocks below the diagonal as they are, the diagonal
+  // slots take the 16 x 16 inverses (all a solve needs of a diagonal block)
+  {
+    T tr[5][4];
+#pragma unroll
+    for (int trip = 0; trip < 5; ++trip) {
+      const int b = w + 8 * trip;
+      if (b < 36) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= b) ++i;
+        const int j = b - i * (i + 1) / 2;
+        if (i == j) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tr[trip][q] = dinv[i * 256 + q * 64 + lane];
+        } else {
+          const int voff = lk * int(ld) + lrow;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tr[trip][q] = (Ljj + int64_t(j * 16 + q * 4) * ld + i * 16)[voff];
+        }
+      }
+    }
+#pragma unroll
+    for (int trip = 0; trip < 5; ++trip) {
+      const int b = w + 8 * trip;
+      if (b < 36) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[b * 256 + q * 64 + lane] = tr[trip][q];
+      }
+    }
+  }
+  // this wave's 16 rows of the column block (the fold's result, if any), D layout
+  T* bp = Bt + w * 16 + lrow;
+  acc_t V[8];  // V[j]: B_j until step j, then Z_j = -Y_j
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) V[jb][r] = bp[int64_t(jb * 16 + M::drow(lane, r)) * ld];
+  __syncthreads();
+  // transposed recurrence Y_j = inv(L_jj) (B_j^T - sum_{k<j} L_jk Y_k) as in trsm_kernel, operands
+  // from LDS (element (r, c) of block (i, j) at blk(i, j) + c * 16 + r)
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    acc_t acc = V[jb], acc2 = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb < jb; ++kb) {
+      const T* Lb = &S[blk(jb, kb)];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const T l = Lb[M::drow(lane, s) * 16 + lrow];
+        if (s & 1) acc2 = M::mma(l, V[kb][s], acc2);
+        else acc = M::mma(l, V[kb][s], acc);
+      }
+    }
+    acc += acc2;
+    const T* Db = &S[blk(jb, jb)];
+    acc_t y = acc_t{0, 0, 0, 0}, y2 = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const T d = Db[M::drow(lane, s) * 16 + lrow];
+      if (s & 1) y2 = M::mma(d, acc[s], y2);
+      else y = M::mma(d, acc[s], y);
+    }
+    y += y2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bp[int64_t(jb * 16 + M::drow(lane, r)) * ld] = y[r];
+    V[jb] = -y;
+  }
+}
+
+template <typename T, bool FOLD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void panel_step_kernel(
+    T* __restrict__ A, int64_t ld, T* __restrict__ dinv, int32_t* __restrict__ info, int32_t pivot_base,
+    const T* __restrict__ Xp, int has_p, uint32_t* __restrict__ flag, uint32_t epoch) {
+  __shared__ __attribute__((aligned(16))) T S[36 * 256];
+  __shared__ T Rs[2 * 16];
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x);
+  if (b < has_p) {
+    potf2_body<T, FOLD>(S, Rs, A, ld, dinv, info, pivot_base, Xp, ld);
+    // publish: every wave's stores have left it -> barrier -> one agent-scope release -> flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the fence's own wait)
+      __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  trsm_fold_body<T, FOLD>(S, b - has_p, A, ld, dinv, Xp, flag, epoch, has_p, info);
 }
 
 // dinv for an existing factor: one thread per (16-block, column)
