@@ -101,6 +101,9 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       queued on the update stream (three busy queues); 0: on their own stream
  *   "first_split"       blocks of a panel after which its share of the next block-column
  *                       update is issued early, beside the panel's last blocks (default 5; 0 off)
+ *   "fused_step"        1 (default): the panel chain is one launch per 128-column block (potf2, the
+ *                       rows' own pending update and trsm behind a device-side flag: chol.hip,
+ *                       panel_step_kernel); 0: potf2 | trsm | in-panel update as separate launches
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
  *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming
  *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block
@@ -320,6 +323,10 @@ int tgp_dist_get_column(tgp_dist* h, int64_t l, void* out_host);
  *        5 event record  v = {event}          6 stream wait  v = {event}
  *        7 assembly      v = {first column tile, column tiles, ld, flags}
  *        8 residual copy into the work vector     9 final reductions
+ *       10 fused panel step   v = {tile offset, pending-update operand offset or -1, rows below, ld,
+ *                                  has_potf2}  (potf2 + per row tile: pending update, trsm)
+ * `fused`: bit 0 = forward substitution fused into the factorisation; bit 1 = the unfused panel
+ * chain (context option fused_step = 0).
  *   stream 0 main, 1 panel, 2 solve, 3 update, 4 assembly; offsets are element offsets from
  *   the matrix base (column-major, leading dimension ld).
  * tests/test_schedule.py replays the records and checks that every pair of conflicting

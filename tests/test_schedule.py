@@ -17,10 +17,12 @@ from tinygp_amd import _ffi
 
 NSTREAMS = 5
 KIND = {1: "potf2", 2: "trsm", 3: "gemm", 4: "trsv_step", 5: "record", 6: "wait", 7: "assembly",
-        8: "residual_copy", 9: "reductions"}
+        8: "residual_copy", 9: "reductions", 10: "panel_step"}
 
 
 def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1, wide_rows=0):
+    """fused: bit 0 = forward substitution fused into the factorisation, bit 1 = the unfused panel
+    chain (potf2 | trsm | in-panel update per block) instead of one panel-step launch per block."""
     lib = _ffi.load_library()
     cap = 40 * (n_pad // 128) + 256
     out = np.zeros(cap * 10, dtype=np.int64)
@@ -76,6 +78,21 @@ def accesses(rec, T):
                 R.add(("A", cr + ti, cc + tj)); W.add(("A", cr + ti, cc + tj))
         R |= {("A", ar + ti, ac + kk) for ti in range(m) for kk in range(k)}
         R |= {("A", brr + tj, bcc + kk) for tj in range(n) for kk in range(k)}
+    elif kind == 10:  # fused panel step: potf2 (has_p) + per row tile below: pending update, trsm
+        ld, m, has_p = v[3], v[2] // 128, v[4]
+        tr, tc = tile(v[0], ld)
+        assert tr == tc
+        R.add(("A", tr, tc)); R.add(("D", tr))
+        if has_p:
+            W.add(("A", tr, tc)); W.add(("D", tr))
+        if v[1] >= 0:
+            xr, xc = tile(v[1], ld)
+            assert (xr, xc) == (tr, tc - 1)
+            R.add(("A", xr, xc))
+        for i in range(1, m + 1):
+            R.add(("A", tr + i, tc)); W.add(("A", tr + i, tc))
+            if v[1] >= 0:
+                R.add(("A", tr + i, tc - 1))
     elif kind == 4:
         ld = v[2]
         lr, lc = tile(v[0], ld)
@@ -151,6 +168,12 @@ CONFIGS = [
     (5120, 512, 1, 3, 1100, 0, 1024),
     (6144, 1024, 1, 0, 0, 1, 128),
     (4224, 1024, 0, 5, 1100, 1, 2048),
+    # the unfused chain (fused bit 1)
+    (2560, 1024, 1, 5, 1100, 3),
+    (5120, 1024, 1, 5, 1100, 3),
+    (5120, 512, 1, 3, 1100, 2),
+    (5120, 1024, 0, 5, 1100, 3),
+    (8192, 1024, 1, 5, 1100, 3, 3000),
 ]
 
 
@@ -160,9 +183,17 @@ def test_schedule_has_no_data_race(cfg):
     recs = trace(*cfg)
     T = n_pad // 128
     # every block column is factored exactly once, in order
-    potf2 = [r for r in recs if r[0] == 1]
-    assert [(r[2] % r[4]) // 128 for r in potf2] == list(range(T))
-    if cfg[5]:
+    potf2 = [(r[2] % r[4]) // 128 for r in recs if r[0] == 1] + \
+            [(r[2] % r[5]) // 128 for r in recs if r[0] == 10 and r[6] == 1]
+    assert sorted(potf2) == list(range(T))
+    order = [(r[2] % (r[4] if r[0] == 1 else r[5])) // 128 for r in recs
+             if r[0] == 1 or (r[0] == 10 and r[6] == 1)]
+    assert order == list(range(T))
+    if cfg[5] & 2:
+        assert not any(r[0] == 10 for r in recs)
+    else:
+        assert not any(r[0] == 2 for r in recs)  # every trsm of the chain rides in a panel step
+    if cfg[5] & 1:
         assert sum(1 for r in recs if r[0] == 4) == T  # one forward-substitution step per block
     assert find_races(recs, T) == []
 

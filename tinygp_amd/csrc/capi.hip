@@ -164,11 +164,14 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_e, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_f, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
   TGP_HIP_TRY(hipMalloc(&ctx->d_scal, 16 * sizeof(double)));
   TGP_HIP_TRY(hipMalloc(&ctx->d_info, sizeof(int32_t)));
+  TGP_HIP_TRY(hipMalloc(&ctx->d_step_flag, 64));
+  TGP_HIP_TRY(hipMemset(ctx->d_step_flag, 0, 64));
   hipDeviceProp_t prop;
   TGP_HIP_TRY(hipGetDeviceProperties(&prop, device));
   ctx->cus = prop.multiProcessorCount;
@@ -197,11 +200,13 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
   if (ctx->ev_asm) hipEventDestroy(ctx->ev_asm);
   if (ctx->ev_d) hipEventDestroy(ctx->ev_d);
   if (ctx->ev_e) hipEventDestroy(ctx->ev_e);
+  if (ctx->ev_f) hipEventDestroy(ctx->ev_f);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
   if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
   if (ctx->d_scal) hipFree(ctx->d_scal);
   if (ctx->d_info) hipFree(ctx->d_info);
+  if (ctx->d_step_flag) hipFree(ctx->d_step_flag);
   if (ctx->d_dinv) hipFree(ctx->d_dinv);
   if (ctx->d_work) hipFree(ctx->d_work);
   if (ctx->panel_stream) hipStreamDestroy(ctx->panel_stream);
@@ -229,6 +234,7 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "nb_wide_rows")) slot = &ctx->nb_wide_rows;
   else if (!strcmp(key, "dist_solve_aux")) slot = &ctx->dist_solve_aux;
   else if (!strcmp(key, "solve_on_update")) slot = &ctx->solve_on_update;
+  else if (!strcmp(key, "fused_step")) slot = &ctx->fused_step;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)
     TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);
@@ -1060,6 +1066,8 @@ int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t
   ctx.ev_d = (hipEvent_t)fake(0x130);
   ctx.ev_e = (hipEvent_t)fake(0x140);
   ctx.ev_asm = (hipEvent_t)fake(0x150);
+  ctx.ev_f = (hipEvent_t)fake(0x160);
+  ctx.fused_step = (fused & 2) ? 0 : 1;  // bit 1: the unfused chain (potf2 | trsm | update per block)
   ctx.nb_outer = nb_outer;
   ctx.lookahead = lookahead;
   ctx.first_split = first_split;
@@ -1075,9 +1083,9 @@ int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t
   ctx.trace_base = base;
   KProg kp{};
   TGP_TRY(assemble_lower<double>(&ctx, kp, n_pad, 1, X, X, base, n_pad));
-  if (fused) trace_push(&ctx, 8, ctx.stream);  // residual -> work vector (main stream)
+  if (fused & 1) trace_push(&ctx, 8, ctx.stream);  // residual -> work vector (main stream)
   int32_t info = 0;
-  const int st = potrf<double>(&ctx, n_pad, base, n_pad, dinv, &info, fused ? y : nullptr);
+  const int st = potrf<double>(&ctx, n_pad, base, n_pad, dinv, &info, (fused & 1) ? y : nullptr);
   if (st < 0) return st;
   trace_push(&ctx, 9, ctx.stream);  // reductions over diag(L) and the solved vector (main stream)
   *n_records = (int64_t)recs.size();

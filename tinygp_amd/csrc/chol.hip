@@ -493,24 +493,21 @@ __device__ __forceinline__ void trsm_fold_body(T* __restrict__ S, int it, const 
       __syncthreads();
     }
     // C[wr*32 + b*16 + lrow, wc*64 + a*16 + drow(lane, r)] -= acc[a][b][r]; 16 loads in flight per pass
-    T* Cb = Bt + int64_t(wc * 64) * ld + wr * 32 + lrow;
+    // (uniform base in SGPRs + one 32-bit lane offset: no per-access address registers)
+    T* Cu = Bt + int64_t(wc * 64) * ld + wr * 32;
+    const uint32_t coff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
 #pragma unroll
-    for (int a = 0; a < 4; a += 2) {
-      T c[2][2][4];
+    for (int a = 0; a < 4; ++a) {
+      T c[2][4];
 #pragma unroll
-      for (int aa = 0; aa < 2; ++aa)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int r = 0; r < 4; ++r) c[b][r] = (Cu + int64_t(a * 16 + M::drow(0, r)) * ld + b * 16)[coff];
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            c[aa][b][r] = Cb[int64_t((a + aa) * 16 + M::drow(lane, r)) * ld + b * 16];
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            Cb[int64_t((a + aa) * 16 + M::drow(lane, r)) * ld + b * 16] = c[aa][b][r] - acc[a + aa][b][r];
+        for (int r = 0; r < 4; ++r) (Cu + int64_t(a * 16 + M::drow(0, r)) * ld + b * 16)[coff] = c[b][r] - acc[a][b][r];
+      __builtin_amdgcn_sched_barrier(0);  // one pass of eight loads at a time (register budget: 128)
     }
     __syncthreads();  // the updated rows are visible to the whole workgroup; S is free again
   }
@@ -561,14 +558,18 @@ __device__ __forceinline__ void trsm_fold_body(T* __restrict__ S, int it, const 
       }
     }
   }
+  __builtin_amdgcn_sched_barrier(0);  // (the image's staging registers are dead before the rows are fetched)
   // this wave's 16 rows of the column block (the fold's result, if any), D layout
-  T* bp = Bt + w * 16 + lrow;
+  T* bu = Bt + w * 16;  // wave-uniform; lane offset below
+  const uint32_t boff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
   acc_t V[8];  // V[j]: B_j until step j, then Z_j = -Y_j
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) V[jb][r] = bp[int64_t(jb * 16 + M::drow(lane, r)) * ld];
+    for (int r = 0; r < 4; ++r) V[jb][r] = (bu + int64_t(jb * 16 + M::drow(0, r)) * ld)[boff];
   __syncthreads();
+  T* bs = bu;  // the stores recompute their addresses (kept from the loads they are 64 spilled registers)
+  asm volatile("" : "+s"(bs));
   // transposed recurrence Y_j = inv(L_jj) (B_j^T - sum_{k<j} L_jk Y_k) as in trsm_kernel, operands
   // from LDS (element (r, c) of block (i, j) at blk(i, j) + c * 16 + r)
 #pragma unroll
@@ -595,7 +596,7 @@ __device__ __forceinline__ void trsm_fold_body(T* __restrict__ S, int it, const 
     }
     y += y2;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bp[int64_t(jb * 16 + M::drow(lane, r)) * ld] = y[r];
+    for (int r = 0; r < 4; ++r) (bs + int64_t(jb * 16 + M::drow(0, r)) * ld)[boff] = y[r];
     V[jb] = -y;
   }
 }
@@ -1204,6 +1205,27 @@ int launch_trsm(tgp_ctx* ctx, hipStream_t st, int64_t m, const T* L, int64_t ldl
 }
 
 template <typename T>
+int launch_panel_step(tgp_ctx* ctx, hipStream_t st, int64_t m, T* Ljj, int64_t ld, T* dj, int32_t* info,
+                      int32_t pivot_base, const T* Xp, bool has_p) {
+  TGP_ARG_CHECK(m >= 0 && m % TILE == 0, "panel step: rows below must be a multiple of %d", TILE);
+  if (ctx->trace) {  // v: tile offset, pending-update operand offset (-1: none), rows below, ld, has_p
+    trace_push(ctx, 10, st, trace_off(ctx, Ljj), trace_off(ctx, Xp), m, ld, has_p ? 1 : 0);
+    return TGP_OK;
+  }
+  const unsigned grid = (unsigned)(m / TILE) + (has_p ? 1u : 0u);
+  if (grid == 0) return TGP_OK;
+  const uint32_t epoch = ++ctx->step_epoch;  // launches of a context are issued under its lock, in stream order
+  if (Xp != nullptr)
+    hipLaunchKernelGGL((panel_step_kernel<T, true>), dim3(grid), dim3(512), 0, st, Ljj, ld, dj, info, pivot_base,
+                       Xp, has_p ? 1 : 0, ctx->d_step_flag, epoch);
+  else
+    hipLaunchKernelGGL((panel_step_kernel<T, false>), dim3(grid), dim3(512), 0, st, Ljj, ld, dj, info, pivot_base,
+                       Xp, has_p ? 1 : 0, ctx->d_step_flag, epoch);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+template <typename T>
 int compute_dinv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* dinv) {
   if (n == 0) return TGP_OK;
   hipLaunchKernelGGL((dinv_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -1270,6 +1292,41 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
                 int64_t after_blocks, const std::function<int(hipEvent_t)>& mid) {
   hipStream_t S3 = ctx->update_stream;
   hipStream_t S2 = ctx->solve_on_update != 0 ? S3 : ctx->solve_stream;  // behind the update of the same block
+  if (ctx->fused_step != 0) {
+    // One launch per block (panel_step_kernel).  The rows' workgroups apply the update of THIS column
+    // block from the previous one themselves, so the separate in-panel update of block j covers the
+    // column blocks j+2.. only and is not needed before step j+2: two alternating markers.
+    hipEvent_t far_ev[2] = {ctx->ev_e, ctx->ev_f};
+    int64_t q = 0;
+    for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE, ++q) {
+      T* Ljj = A + j0 * ld + j0;
+      T* dj = dinv + (j0 / TILE) * 2048;
+      const bool pend = j0 > k0;
+      const bool has_p = pend || !head_done;
+      const int64_t mb = n - (j0 + TILE);
+      if (q >= 2) TGP_TRY(st_wait(ctx, st, far_ev[q & 1]));  // far update of block q-2 (and, in order, all before it)
+      TGP_TRY(launch_panel_step<T>(ctx, st, mb, Ljj, ld, dj, ctx->d_info, (int32_t)(pivot_off + j0),
+                                   pend ? (const T*)(A + (j0 - TILE) * ld + j0) : (const T*)nullptr, has_p));
+      const int64_t nc = (k0 + kb) - (j0 + 2 * TILE);  // columns j+2.. of the panel
+      const int64_t mb2 = mb - TILE;                    // rows below block j+1's diagonal tile, and that tile
+      const bool upd = mb2 > 0 && nc > 0;
+      const bool need_mid = after_blocks > 0 && mb > 0 && (k0 + kb) - (j0 + TILE) > 0 &&
+                            j0 + TILE == k0 + after_blocks * TILE;
+      if (y != nullptr || upd || need_mid) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
+      if (upd) {
+        TGP_TRY(st_wait(ctx, S3, ctx->ev_d));
+        TGP_TRY(launch_gemm_nt<T>(ctx, S3, mb2, nc, TILE, Ljj + 2 * TILE, ld, Ljj + 2 * TILE, ld,
+                                  A + (j0 + 2 * TILE) * ld + j0 + 2 * TILE, ld, 1, 0, 1));
+        TGP_TRY(ev_record(ctx, far_ev[q & 1], S3));
+      }
+      if (y != nullptr) {
+        if (S2 != S3 || !upd) TGP_TRY(st_wait(ctx, S2, ctx->ev_d));
+        TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, mb, Ljj, ld, dj, y + j0));
+      }
+      if (need_mid) TGP_TRY(mid(ctx->ev_d));
+    }
+    return TGP_OK;
+  }
   for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
     T* Ljj = A + j0 * ld + j0;
     T* dj = dinv + (j0 / TILE) * 2048;
@@ -1468,6 +1525,10 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       ctx->prof_syrk_flops += sp.flops;
     }
   }
+  if (info == STEP_TIMEOUT) {
+    set_error("potrf: a panel step's hand-off flag never arrived (device-side timeout)");
+    return TGP_E_HIP;
+  }
   if (info_host) *info_host = info;
   return info > 0 ? info : TGP_OK;
 }
@@ -1609,6 +1670,8 @@ int tri_inverse_t(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* din
                                const T*, int64_t);       \
   template int launch_trsm<T>(tgp_ctx*, hipStream_t, int64_t, const T*, int64_t, const T*, T*,   \
                               int64_t);                                                          \
+  template int launch_panel_step<T>(tgp_ctx*, hipStream_t, int64_t, T*, int64_t, T*, int32_t*, int32_t, \
+                                    const T*, bool);                                             \
   template int compute_dinv<T>(tgp_ctx*, int64_t, const T*, int64_t, T*);                        \
   template int panel_potf2<T>(tgp_ctx*, hipStream_t, T*, int64_t, T*, int64_t, int64_t, bool);   \
   template int panel_chain<T>(tgp_ctx*, hipStream_t, int64_t, T*, int64_t, T*, int64_t, int64_t, \

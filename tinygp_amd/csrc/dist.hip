@@ -405,6 +405,10 @@ int tgp_dist_end(tgp_dist* h, int32_t* info, double* sumsq, double* logdet_half)
   TGP_HIP_TRY(hipMemcpyAsync(&inf, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, S0));
   TGP_HIP_TRY(hipStreamSynchronize(S0));
   TGP_HIP_TRY(hipStreamSynchronize(ctx->panel_stream));
+  if (inf == INT32_MIN) {  // panel_step_kernel's bounded wait ran out (chol.hip)
+    set_error("block-column driver: a panel step's hand-off flag never arrived (device-side timeout)");
+    return TGP_E_HIP;
+  }
   double ld = 0;
   for (int64_t k = 0; k < h->nblk; ++k) ld += part[size_t(k)];  // fixed order
   if (info) *info = inf;

@@ -228,10 +228,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
         const T* ap = Au + (kg + 4 * r) * g.lda;
         const T* bp = Bu + (kg + 4 * r) * g.ldb;
         const uint32_t off = uint32_t((buf_ * BK + 4 * r) * LDS_LD * 8);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                     :: "v"(lane16), "s"(ap), "s"(lds_a + off) : "memory", "m0");
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                     :: "v"(lane16), "s"(bp), "s"(lds_b + off) : "memory", "m0");
+        uint32_t keep;  // (m0 is a reserved register: saved and restored, not clobbered)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(ap), "s"(lds_a + off), "s"(bp), "s"(lds_b + off) : "memory");
       }
     };
     auto tile_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };

@@ -62,7 +62,7 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 // without a GPU, for the host-side dependency checker in tests/test_schedule.py.
 struct tgp_trace_rec {
   int64_t kind;    // 1 potf2, 2 trsm, 3 gemm, 4 forward-substitution step, 5 event record,
-                   // 6 stream wait, 7 assembly of column tiles
+                   // 6 stream wait, 7 assembly of column tiles, 10 fused panel step
   int64_t stream;  // 0 main, 1 panel, 2 solve, 3 update, 4 assembly
   int64_t v[8];    // operands as element offsets from the matrix base (see capi.hip)
 };
@@ -84,6 +84,7 @@ struct tgp_ctx {
   hipEvent_t ev_asm = nullptr;          // ... finished (potrf waits before its first update)
   bool asm_pending = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_e = nullptr;
+  hipEvent_t ev_f = nullptr;  // second marker of the far in-panel updates (fused panel step: they alternate)
   int64_t nb_outer = 1024;  // measured best for N = 4k .. 32k (profiles/r01_f_nb_sweep.txt)
   int64_t lookahead = 1;
   int64_t dist_solve_aux = 1;  // block-column driver: forward steps on the update stream (0: a solve stream of their own)
@@ -98,6 +99,11 @@ struct tgp_ctx {
   int64_t stream_trsv = 1;  // forward solves on a resident factor: one streaming launch (0: one launch pair per block)
   int64_t keep_grad_buffers = 0;  // tgp_solver_grad keeps its two N^2 work matrices between calls
   int64_t first_small_tiles = 1100;  // look-ahead block-column updates up to this many tiles use 64x64 tiles
+  // panel chain as ONE launch per 128-column block (panel_step_kernel: potf2 + the rows' own pending update
+  // + trsm behind a device-side flag) instead of potf2 | trsm | update of the next column block (0: the latter)
+  int64_t fused_step = 1;
+  uint32_t* d_step_flag = nullptr;  // the flag potf2's workgroup publishes; value = step_epoch of the launch
+  uint32_t step_epoch = 0;
   // small device scratch: scal[0..15] doubles, info int
   double* d_scal = nullptr;
   int32_t* d_info = nullptr;
@@ -134,6 +140,7 @@ inline int64_t trace_event_id(const tgp_ctx* ctx, hipEvent_t ev) {
   if (ev == ctx->ev_d) return 3;
   if (ev == ctx->ev_e) return 4;
   if (ev == ctx->ev_asm) return 5;
+  if (ev == ctx->ev_f) return 6;
   return -1;
 }
 template <typename T>
@@ -209,6 +216,11 @@ int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_
 template <typename T>
 int launch_trsm(tgp_ctx* ctx, hipStream_t st, int64_t m, const T* L, int64_t ldl, const T* dinv,
                 T* B, int64_t ldb);
+// fused panel step on the 128-block at Ljj: potf2 (has_p; folding the pending update from Xp when
+// Xp != NULL) + per 128-row tile of the m rows below: pending update from Xp's block column, trsm
+template <typename T>
+int launch_panel_step(tgp_ctx* ctx, hipStream_t st, int64_t m, T* Ljj, int64_t ld, T* dj, int32_t* info,
+                      int32_t pivot_base, const T* Xp, bool has_p);
 
 template <typename T>
 int panel_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int64_t pivot_off,
