@@ -1,29 +1,23 @@
 #!/bin/bash
-# round 2, session 2, batch 2: the fused panel step (one launch per 128-column block) -- parity,
-# determinism, bench lines with the option on and off
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-L=gpurun_out/s2b2.log
+# round 2, session 2, batch 3: kernel timelines of the fused and the unfused panel chain (c2, N = 4096)
+R=$GRAFT_REPO_ROOT
+cd $R
+O=$R/gpurun_out
+mkdir -p $O
+L=$O/s2b3.log
 : > $L
-echo "== quick check: N = 4096 factor through the fused step" >> $L; date >> $L
-timeout 120 python bench.py --workload n4096 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary 2>&1 | tail -2 | cut -c1-300 >> $L
-echo "== pytest -m gpu" >> $L; date >> $L
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 >> $L
-echo "== bench lines, fused_step = 1 / 0" >> $L; date >> $L
-for w in n1024 n2048 n4096 n8192 c2 n32768; do
-  for f in 1 0; do
-    echo "# $w fused_step=$f" >> $L
-    TGP_HIP_OPTIONS="fused_step=$f" timeout 600 python bench.py --workload $w --steps 8 --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "
-import sys,json
-for l in sys.stdin:
-    try: d=json.loads(l)
-    except Exception: continue
-    r=d.get('roofline') or {}
-    print(json.dumps({'evals_s':round(d['value'],3),'ms':round(d['ms_per_step'],3),'syrk_TF':round(r.get('achieved',0),2),'chol_TF':round(d.get('cholesky_tflops',0),2)}))
-" >> $L
+B="--no-cpu-baseline --no-secondary"
+cd /tmp; export TMPDIR=/tmp
+for f in 1 0; do
+  for w in c2 n4096; do
+    rm -rf $O/prof_${w}_f$f
+    TGP_HIP_OPTIONS="fused_step=$f" timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_${w}_f$f -o bench -- python $R/bench.py --workload $w --steps 3 --warmup 1 $B > /dev/null 2>&1
+    echo "== $w fused_step=$f" >> $L
+    python $R/scripts/prof_top.py $(ls $O/prof_${w}_f$f/*.db | head -1) 10 >> $L 2>&1
+    python $R/scripts/timeline.py $(ls $O/prof_${w}_f$f/*.db | head -1) /tmp/tl.csv 2500 > /dev/null
+    if [ $w = c2 ]; then python $R/scripts/timeline_panels.py /tmp/tl.csv dump 9 1 >> $L 2>&1; else python $R/scripts/timeline_panels.py /tmp/tl.csv dump 2 1 >> $L 2>&1; fi
+    rm -rf $O/prof_${w}_f$f
   done
 done
-echo "== determinism stress" >> $L; date >> $L
-timeout 300 python scripts/stress_determinism.py 2>&1 | tail -8 >> $L
 date >> $L
-tail -70 $L
+tail -5 $L

@@ -34,7 +34,7 @@ for k, v in dur.items():
 big = [r for r in step if r["name"].startswith("gemm_nt_kernel")]
 mainq = big[0]["queue"] if big else None
 firsts = [r for r in step if r["name"].startswith("gemm_nt_small") and r["queue"] == mainq]
-chain = [r for r in step if r["name"].startswith("potf2") or r["name"].startswith("trsm")]
+chain = [r for r in step if r["name"].startswith(("potf2", "trsm", "panel_step"))]
 for i, rest in enumerate(big):
     # the panel's own first potf2 runs on the main stream just before `rest`
     lo = rest["start"] - 80
@@ -48,3 +48,12 @@ for i, rest in enumerate(big):
     print(f"panel {i+1:2d}: gate {(gate['end']-gate['start']) if gate else 0:5.0f} | rest {rest['end']-rest['start']:6.0f} "
           f"chain {cend-cstart:6.0f} n={len(ch):2d} early+final shares {len(fp)} | "
           f"{'chain' if cend > rest['end'] else 'gemm '} by {abs(cend-rest['end']):5.0f}")
+
+# optional: `dump <first panel> <n panels>` lists every kernel of those panels' windows (start, duration, queue)
+if len(sys.argv) > 4 and sys.argv[2] == "dump" and big:
+    p0, npan = int(sys.argv[3]) - 1, int(sys.argv[4])
+    lo = big[min(p0, len(big) - 1)]["start"] - 100
+    hi = big[min(p0 + npan, len(big) - 1)]["start"] if p0 + npan < len(big) else step[-1]["end"]
+    for r in step:
+        if lo <= r["start"] < hi:
+            print(f"  {r['start']-t0:9.1f} +{r['end']-r['start']:7.1f}  q{r['queue']} grid {r['grid']:6d}  {r['name'][:44]}")

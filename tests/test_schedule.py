@@ -199,13 +199,17 @@ def test_schedule_has_no_data_race(cfg):
 
 
 def test_checker_sees_a_missing_dependency():
-    """The checker is not vacuous: dropping the waits that order the in-panel update before
-    the next trsm, or the join of the side-stream assembly, must be reported."""
+    """The checker is not vacuous: dropping the waits that order the far in-panel updates (two
+    alternating markers) before the panel step two blocks later, or the join of the side-stream
+    assembly, must be reported."""
     recs = trace(2560)
     T = 2560 // 128
     no_update_wait = [r for r in recs if not (r[0] == 6 and r[1] == 1 and r[2] == 4)]  # panel waits ev_e
     assert len(no_update_wait) < len(recs)
     assert find_races(no_update_wait, T)
+    no_update_wait2 = [r for r in recs if not (r[0] == 6 and r[1] == 1 and r[2] == 6)]  # panel waits ev_f
+    assert len(no_update_wait2) < len(recs)
+    assert find_races(no_update_wait2, T)
     no_join = [r for r in recs if not (r[0] == 6 and r[1] == 0 and r[2] == 5)]  # main waits ev_asm
     assert len(no_join) < len(recs)
     assert find_races(no_join, T)
