@@ -104,6 +104,8 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "fused_step"        1 (default): the panel chain is one launch per 128-column block (potf2, the
  *                       rows' own pending update and trsm behind a device-side flag: chol.hip,
  *                       panel_step_kernel); 0: potf2 | trsm | in-panel update as separate launches
+ *   "chain_reserve"     workgroup slots (of two per CU) that a trailing update running beside a panel
+ *                       chain leaves to the chain's kernels (default 64; 0: the update fills the chip)
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
  *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming
  *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block

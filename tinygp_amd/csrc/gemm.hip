@@ -124,7 +124,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
   if (ROLE == 1) __builtin_amdgcn_s_setprio(1);  // in-panel update: on the critical path
   // XCD-aware remap: hardware places workgroup b on XCD b % 8; give every XCD a contiguous
   // run of tile ids so neighbouring tiles (shared panels) meet in one L2.  Bijective form.
-  int bid = blockIdx.x;
+  // Persistent over tiles: workgroup b takes tiles b, b + gridDim, ... (gridDim is a multiple of 8
+  // whenever it is smaller than the tile count, so a workgroup stays on its XCD's run of tile ids).
+  // The launcher sizes the grid: all workgroup slots of the chip for an update that runs alone,
+  // fewer for one that runs beside a panel chain -- the chain's kernels then find free slots instead
+  // of waiting for a round of 250-us tiles to retire (ctx option chain_reserve).
+  for (int tile = blockIdx.x; tile < g.nblk; tile += gridDim.x) {
+  int bid = tile;
   {
     const int nx = 8, q = g.nblk / nx, r = g.nblk % nx;
     const int xcd = bid % nx, idx = bid / nx;
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
       }
     }
   }
+  }  // tiles of this workgroup
 }
 
 // ---- small-tile variant -----------------------------------------------------------------
@@ -624,6 +631,16 @@ __global__ __launch_bounds__(256) void ubench_kernel(double* out, long long* cyc
 
 }  // namespace
 
+// Workgroups of a persistent 128x128-tile launch: two per CU fill the chip (234 VGPRs, 72 KiB of LDS
+// each); `reserve` of those slots are left to the kernels of a panel chain that runs beside the
+// update.  A multiple of 8 whenever tiles are left over, so a workgroup's tiles stay on one XCD.
+static unsigned persistent_grid(const tgp_ctx* ctx, int nblk, int64_t reserve) {
+  int64_t slots = 2 * int64_t(ctx->cus > 0 ? ctx->cus : 256) - (reserve > 0 ? reserve : 0);
+  slots = slots / 8 * 8;
+  if (slots < 8) slots = 8;
+  return unsigned(nblk <= slots ? nblk : slots);
+}
+
 template <typename T>
 int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k, const T* A,
                    int64_t lda, const T* B, int64_t ldb, T* C, int64_t ldc, int lower, int mode,
@@ -668,10 +685,12 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   } else {
     g.nblk = g.tm * g.tn;
   }
+  const unsigned grid = persistent_grid(ctx, g.nblk, role == 0 ? ctx->reserve_hint : 0);
+  ctx->reserve_hint = 0;
   if (role == 0)
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3(grid), dim3(256), 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3(grid), dim3(256), 0, st, g);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -703,7 +722,7 @@ int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb
   }
   TGP_ARG_CHECK(total < (int64_t(1) << 31), "gemm_nt_dist: too many tiles");
   g.nblk = int(total);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3((unsigned)g.nblk), dim3(256), 0, st, g);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3(persistent_grid(ctx, g.nblk, 0)), dim3(256), 0, st, g);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }

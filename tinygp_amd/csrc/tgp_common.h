@@ -102,6 +102,10 @@ struct tgp_ctx {
   // panel chain as ONE launch per 128-column block (panel_step_kernel: potf2 + the rows' own pending update
   // + trsm behind a device-side flag) instead of potf2 | trsm | update of the next column block (0: the latter)
   int64_t fused_step = 1;
+  // workgroup slots (of 2 per CU) that a trailing update which runs beside a panel chain leaves free
+  // for the chain's kernels (gemm.hip: the update is persistent over its tiles, so its grid is its footprint)
+  int64_t chain_reserve = 64;
+  int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
   uint32_t* d_step_flag = nullptr;  // the flag potf2's workgroup publishes; value = step_epoch of the launch
   uint32_t step_epoch = 0;
   // small device scratch: scal[0..15] doubles, info int
