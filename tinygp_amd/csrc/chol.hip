@@ -1480,7 +1480,10 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       // panel take the host longer than a small update takes the GPU) ...
       const int64_t m2 = mt - kbn;
       if (m2 > 0) {
-        ctx->reserve_hint = ctx->chain_reserve;  // the next panel's chain runs beside this launch
+        // the next panel's chain runs beside this launch; when the launch is the shorter of the two it
+        // leaves workgroup slots to the chain
+        const int64_t t2 = m2 / TILE;
+        if (t2 * (t2 + 1) / 2 <= ctx->reserve_max_tiles) ctx->reserve_hint = ctx->chain_reserve;
         TGP_TRY(trailing(S0, m2, m2, kb, P + kbn, A + (next + kbn) * ld + next + kbn, 0));
       }
       // 3. ... while the side stream factors the next panel.  Once its first `first_split`

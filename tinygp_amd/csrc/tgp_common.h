@@ -105,6 +105,7 @@ struct tgp_ctx {
   // workgroup slots (of 2 per CU) that a trailing update which runs beside a panel chain leaves free
   // for the chain's kernels (gemm.hip: the update is persistent over its tiles, so its grid is its footprint)
   int64_t chain_reserve = 64;
+  int64_t reserve_max_tiles = 3000;  // ... when the update has at most this many 128 x 128 tiles (chain-bound panels)
   int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
   uint32_t* d_step_flag = nullptr;  // the flag potf2's workgroup publishes; value = step_epoch of the launch
   uint32_t step_epoch = 0;
