@@ -53,7 +53,7 @@ PMC_TRAFFIC = {"file": "profiles/r02_n_final_evidence.md",
 
 
 def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles: int = 0,
-                          first_split: int = 0):
+                          first_split: int = 0, gate_split: bool = True):
     """(algorithmic bytes, launches) of one factorisation's 128x128-tile trailing-update launches.
 
     Mirrors the launch shapes of csrc/chol.hip (look-ahead: next panel's block column, then
@@ -61,8 +61,12 @@ def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles:
     panel operand (m x k) is read once.  Block-column updates of at most `first_small_tiles`
     128x128 tiles run on the 64x64-tile kernel and are not part of the profiled kernel; a
     block-column update is issued in two k-ranges (`first_split` blocks early, the rest after
-    the panel).
+    the panel); with `gate_split` (the library's default) the share after the panel comes in three
+    column pieces (block 0 | block 1 | blocks 2..), each on the kernel its own tile count selects.
     """
+    def tiles_of(m, nn):
+        return (m // 128) * (nn // 128) - (nn // 128) * (nn // 128 - 1) // 2
+
     total, launches = 0, 0
     k0 = 0
     while k0 < n_pad:
@@ -72,19 +76,26 @@ def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles:
         if mt <= 0:
             break
         kbn = min(nb, mt)
-        for which, (m, nn) in enumerate(((mt, kbn), (mt - kbn, mt - kbn))):
-            if m <= 0:
-                continue
-            tiles = (m // 128) * (nn // 128) - (nn // 128) * (nn // 128 - 1) // 2
-            if which == 0 and tiles <= first_small_tiles:
+        shapes = []  # (m, nn, k, block-column update?)
+        # the update of the next panel's block column by this panel: an early share (issued beside this
+        # panel's last blocks, k = early) and the final share behind the panel (k = kb - early)
+        early = first_split * 128 if 0 < first_split < kb // 128 else 0
+        k_final = kb - early
+        if early:
+            shapes.append((mt, kbn, early, True))
+        if gate_split and kbn >= 3 * 128 and mt > 2 * 128:
+            shapes += [(mt, 128, k_final, True), (mt - 128, 128, k_final, True),
+                       (mt - 256, kbn - 256, k_final, True)]
+        else:
+            shapes.append((mt, kbn, k_final, True))
+        if mt - kbn > 0:
+            shapes.append((mt - kbn, mt - kbn, kb, False))
+        for m, nn, k, is_first in shapes:
+            if is_first and tiles_of(m, nn) <= first_small_tiles:
                 continue
             entries = nn * m - nn * (nn - 1) // 2
-            ks = [kb]
-            if which == 0 and 0 < first_split < kb // 128:
-                ks = [first_split * 128, kb - first_split * 128]
-            for k in ks:
-                total += itemsize * (2 * entries + m * k)
-                launches += 1
+            total += itemsize * (2 * entries + m * k)
+            launches += 1
         k0 = nxt
     return total, launches
 
@@ -428,7 +439,7 @@ def run_single(args, spec, rank, local_rank, world, torch, dist):
         ctx.set_option("lookahead", args.lookahead)
     ctx.set_option("profile", 0 if args.no_profile else 1)
     opt = {}
-    for key in ("nb_outer", "lookahead", "first_small_tiles", "first_split"):
+    for key in ("nb_outer", "lookahead", "first_small_tiles", "first_split", "gate_split", "fused_step"):
         opt[key] = ctx.set_option(key, 128 if key == "nb_outer" else 0)
         ctx.set_option(key, opt[key])
 
@@ -495,7 +506,8 @@ def run_single(args, spec, rank, local_rank, world, torch, dist):
     if not args.no_profile and acc["syrk_ms"] > 0:
         n_pad = -(-n // 128) * 128
         alg_bytes, alg_launches = trailing_update_bytes(n_pad, int(opt["nb_outer"]), np.dtype(dt).itemsize,
-                                                         int(opt["first_small_tiles"]), int(opt["first_split"]))
+                                                         int(opt["first_small_tiles"]), int(opt["first_split"]),
+                                                         bool(opt["gate_split"]) and bool(opt["fused_step"]))
         achieved = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12
         launches = max(acc["syrk_launches"], 1.0)
         default_cfg = (spec["name"] == "c2" and opt["nb_outer"] == PMC_TRAFFIC["nb"] and world == 1

@@ -167,13 +167,18 @@ def test_bench_trailing_update_accounting():
     # one panel: nothing to update
     assert bench.trailing_update_bytes(1024, 1024, 8) == (0, 0)
     # two panels: one block-column update of 8x8 tiles' lower trapezoid (1024 x 1024, k = 1024)
-    total, launches = bench.trailing_update_bytes(2048, 1024, 8)
+    total, launches = bench.trailing_update_bytes(2048, 1024, 8, gate_split=False)
     entries = 1024 * 1024 - 1024 * 1023 // 2
     assert launches == 1 and total == 8 * (2 * entries + 1024 * 1024)
+    # ... split into its column pieces (block 0 | block 1 | blocks 2..) the entries are the same
+    # and the panel operand is read once per piece
+    total3, launches3 = bench.trailing_update_bytes(2048, 1024, 8)
+    assert launches3 == 3 and total3 == 8 * (2 * entries + (1024 + 896 + 768) * 1024)
     # ... which runs on the small-tile kernel (36 tiles <= threshold) and is then not counted
     assert bench.trailing_update_bytes(2048, 1024, 8, first_small_tiles=1100) == (0, 0)
     # c2: 15 block-column updates + 14 rest updates; all block columns are under the threshold
-    assert bench.trailing_update_bytes(16384, 1024, 8)[1] == 29
+    assert bench.trailing_update_bytes(16384, 1024, 8, gate_split=False)[1] == 29
+    assert bench.trailing_update_bytes(16384, 1024, 8)[1] == 3 * 15 + 14
     assert bench.trailing_update_bytes(16384, 1024, 8, first_small_tiles=1100)[1] == 14
 
 

@@ -16,13 +16,15 @@ import pytest
 from tinygp_amd import _ffi
 
 NSTREAMS = 5
+EV_G1, EV_G2 = 7, 8  # split gate: column block 1 / column blocks 2.. of the next panel
 KIND = {1: "potf2", 2: "trsm", 3: "gemm", 4: "trsv_step", 5: "record", 6: "wait", 7: "assembly",
         8: "residual_copy", 9: "reductions", 10: "panel_step"}
 
 
 def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1, wide_rows=0):
     """fused: bit 0 = forward substitution fused into the factorisation, bit 1 = the unfused panel
-    chain (potf2 | trsm | in-panel update per block) instead of one panel-step launch per block."""
+    chain (potf2 | trsm | in-panel update per block) instead of one panel-step launch per block,
+    bit 2 = the block-column update between two chains in one piece (no split gate)."""
     lib = _ffi.load_library()
     cap = 40 * (n_pad // 128) + 256
     out = np.zeros(cap * 10, dtype=np.int64)
@@ -168,6 +170,10 @@ CONFIGS = [
     (5120, 512, 1, 3, 1100, 0, 1024),
     (6144, 1024, 1, 0, 0, 1, 128),
     (4224, 1024, 0, 5, 1100, 1, 2048),
+    # the gate in one piece (fused bit 2)
+    (5120, 1024, 1, 5, 1100, 5),
+    (5120, 512, 1, 3, 1100, 4),
+    (8192, 1024, 1, 0, 0, 5, 3000),
     # the unfused chain (fused bit 1)
     (2560, 1024, 1, 5, 1100, 3),
     (5120, 1024, 1, 5, 1100, 3),
@@ -210,6 +216,10 @@ def test_checker_sees_a_missing_dependency():
     no_update_wait2 = [r for r in recs if not (r[0] == 6 and r[1] == 1 and r[2] == 6)]  # panel waits ev_f
     assert len(no_update_wait2) < len(recs)
     assert find_races(no_update_wait2, T)
+    for ev, who in ((EV_G1, 1), (EV_G2, 3)):  # the panel's second step / the first far update wait for the gate pieces
+        dropped = [r for r in recs if not (r[0] == 6 and r[1] == who and r[2] == ev)]
+        assert len(dropped) < len(recs)
+        assert find_races(dropped, T)
     no_join = [r for r in recs if not (r[0] == 6 and r[1] == 0 and r[2] == 5)]  # main waits ev_asm
     assert len(no_join) < len(recs)
     assert find_races(no_join, T)
@@ -218,9 +228,11 @@ def test_checker_sees_a_missing_dependency():
     assert find_races(no_chain_wait, T)
 
 
-@pytest.mark.parametrize("n_pad,nb,split,small", [(16384, 1024, 5, 1100), (32768, 1024, 5, 1100),
-                                                    (16384, 1024, 0, 0), (8192, 512, 3, 200)])
-def test_bench_accounting_matches_the_launches(n_pad, nb, split, small):
+@pytest.mark.parametrize("n_pad,nb,split,small,fused", [(16384, 1024, 5, 1100, 1), (32768, 1024, 5, 1100, 1),
+                                                          (16384, 1024, 0, 0, 1), (8192, 512, 3, 200, 1),
+                                                          (32768, 1024, 5, 1100, 5), (16384, 1024, 0, 0, 3),
+                                                          (8192, 512, 3, 200, 3)])
+def test_bench_accounting_matches_the_launches(n_pad, nb, split, small, fused):
     """bench.py's algorithmic-bytes model (roofline.algorithmic_bytes_per_launch) is derived from
     launch shapes; they must be the shapes the library really launches for the profiled kernel
     (128 x 128-tile GEMM, role 0, on the main stream)."""
@@ -230,7 +242,7 @@ def test_bench_accounting_matches_the_launches(n_pad, nb, split, small):
     spec = importlib.util.spec_from_file_location("bench", Path(__file__).resolve().parents[1] / "bench.py")
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    recs = trace(n_pad, nb, 1, split, small, 1)
+    recs = trace(n_pad, nb, 1, split, small, fused)
     total, launches = 0, 0
     for r in recs:
         if r[0] == 3 and (r[8] >> 8) == 0:
@@ -239,4 +251,5 @@ def test_bench_accounting_matches_the_launches(n_pad, nb, split, small):
             entries = n * m - n * (n - 1) // 2
             total += 8 * (2 * entries + m * k)
             launches += 1
-    assert (total, launches) == bench.trailing_update_bytes(n_pad, nb, 8, small, split)
+    gate_split = not (fused & 4) and not (fused & 2)  # the split gate needs the fused panel step
+    assert (total, launches) == bench.trailing_update_bytes(n_pad, nb, 8, small, split, gate_split)

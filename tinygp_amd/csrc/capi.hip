@@ -165,6 +165,8 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_e, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_f, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_g1, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_g2, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
@@ -201,6 +203,8 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
   if (ctx->ev_d) hipEventDestroy(ctx->ev_d);
   if (ctx->ev_e) hipEventDestroy(ctx->ev_e);
   if (ctx->ev_f) hipEventDestroy(ctx->ev_f);
+  if (ctx->ev_g1) hipEventDestroy(ctx->ev_g1);
+  if (ctx->ev_g2) hipEventDestroy(ctx->ev_g2);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
   if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
@@ -236,6 +240,7 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "solve_on_update")) slot = &ctx->solve_on_update;
   else if (!strcmp(key, "fused_step")) slot = &ctx->fused_step;
   else if (!strcmp(key, "chain_reserve")) slot = &ctx->chain_reserve;
+  else if (!strcmp(key, "gate_split")) slot = &ctx->gate_split;
   else if (!strcmp(key, "reserve_max_tiles")) slot = &ctx->reserve_max_tiles;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)
@@ -1069,6 +1074,9 @@ int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t
   ctx.ev_e = (hipEvent_t)fake(0x140);
   ctx.ev_asm = (hipEvent_t)fake(0x150);
   ctx.ev_f = (hipEvent_t)fake(0x160);
+  ctx.ev_g1 = (hipEvent_t)fake(0x170);
+  ctx.ev_g2 = (hipEvent_t)fake(0x180);
+  ctx.gate_split = (fused & 4) ? 0 : 1;  // bit 2: the gate in one piece
   ctx.fused_step = (fused & 2) ? 0 : 1;  // bit 1: the unfused chain (potf2 | trsm | update per block)
   ctx.nb_outer = nb_outer;
   ctx.lookahead = lookahead;

@@ -512,6 +512,18 @@ __device__ __forceinline__ void trsm_fold_body(T* __restrict__ S, int it, const 
     __syncthreads();  // the updated rows are visible to the whole workgroup; S is free again
   }
 
+  // this wave's 16 rows of the column block (the fold's result, if any), D layout -- fetched BEFORE the
+  // wait: they do not depend on potf2, and the round trip disappears behind it
+  T* bu = Bt + w * 16;  // wave-uniform; lane offset below
+  const uint32_t boff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
+  acc_t V[8];  // V[j]: B_j until step j, then Z_j = -Y_j
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) V[jb][r] = (bu + int64_t(jb * 16 + M::drow(0, r)) * ld)[boff];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (in registers before the acquire drops the L1)
+  __builtin_amdgcn_sched_barrier(0);
+
   if (wait_flag) {  // L_jj and its inverses come from workgroup 0 of this launch
     if (tid == 0) {
       uint32_t seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -558,15 +570,6 @@ __device__ __forceinline__ void trsm_fold_body(T* __restrict__ S, int it, const 
       }
     }
   }
-  __builtin_amdgcn_sched_barrier(0);  // (the image's staging registers are dead before the rows are fetched)
-  // this wave's 16 rows of the column block (the fold's result, if any), D layout
-  T* bu = Bt + w * 16;  // wave-uniform; lane offset below
-  const uint32_t boff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
-  acc_t V[8];  // V[j]: B_j until step j, then Z_j = -Y_j
-#pragma unroll
-  for (int jb = 0; jb < 8; ++jb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) V[jb][r] = (bu + int64_t(jb * 16 + M::drow(0, r)) * ld)[boff];
   __syncthreads();
   T* bs = bu;  // the stores recompute their addresses (kept from the loads they are 64 spilled registers)
   asm volatile("" : "+s"(bs));
@@ -1297,6 +1300,9 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
     // block from the previous one themselves, so the separate in-panel update of block j covers the
     // column blocks j+2.. only and is not needed before step j+2: two alternating markers.
     hipEvent_t far_ev[2] = {ctx->ev_e, ctx->ev_f};
+    // split gate (potrf): column block 1 of this panel is complete at ev_g1, column blocks 2.. at ev_g2
+    const bool gate = ctx->gate_pending;
+    ctx->gate_pending = false;
     int64_t q = 0;
     for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE, ++q) {
       T* Ljj = A + j0 * ld + j0;
@@ -1305,6 +1311,7 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
       const bool has_p = pend || !head_done;
       const int64_t mb = n - (j0 + TILE);
       if (q >= 2) TGP_TRY(st_wait(ctx, st, far_ev[q & 1]));  // far update of block q-2 (and, in order, all before it)
+      if (gate && q == 1) TGP_TRY(st_wait(ctx, st, ctx->ev_g1));
       TGP_TRY(launch_panel_step<T>(ctx, st, mb, Ljj, ld, dj, ctx->d_info, (int32_t)(pivot_off + j0),
                                    pend ? (const T*)(A + (j0 - TILE) * ld + j0) : (const T*)nullptr, has_p));
       const int64_t nc = (k0 + kb) - (j0 + 2 * TILE);  // columns j+2.. of the panel
@@ -1315,6 +1322,7 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
       if (y != nullptr || upd || need_mid) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
       if (upd) {
         TGP_TRY(st_wait(ctx, S3, ctx->ev_d));
+        if (gate && q == 0) TGP_TRY(st_wait(ctx, S3, ctx->ev_g2));  // the same tiles: gate pieces first
         TGP_TRY(launch_gemm_nt<T>(ctx, S3, mb2, nc, TILE, Ljj + 2 * TILE, ld, Ljj + 2 * TILE, ld,
                                   A + (j0 + 2 * TILE) * ld + j0 + 2 * TILE, ld, 1, 0, 1));
         TGP_TRY(ev_record(ctx, far_ev[q & 1], S3));
@@ -1470,12 +1478,30 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       // 1. block column of the next panel first ...
       // (`k_done` columns of this panel were already applied while its last blocks were
       // being factored -- see `early` below.)
-      TGP_TRY(trailing(S0, mt, kbn, kb - k_done, P + k_done * ld, A + next * ld + next, first_role(mt, kbn)));
+      const bool gsplit = ctx->gate_split != 0 && ctx->fused_step != 0 && kbn >= 3 * TILE && mt > 2 * TILE;
+      if (!gsplit) {
+        TGP_TRY(trailing(S0, mt, kbn, kb - k_done, P + k_done * ld, A + next * ld + next, first_role(mt, kbn)));
+        // the panel's first potf2 goes in front of the big update on the main stream: issued
+        // beside it, it waits a whole round of tiles (~0.3 ms) for a free CU
+        TGP_TRY(potf2_at(S0, next, false));
+        TGP_TRY(ev_record(ctx, ctx->ev_a, S0));
+      } else {
+        // Only column block 0 of the next panel gates its chain; blocks 1 and 2.. follow beside the
+        // chain's first two steps (the fused step of block 1 waits for ev_g1, the far update of block 0
+        // -- and through it step 2 -- for ev_g2).
+        const T* Pk = P + k_done * ld;
+        const int64_t kk = kb - k_done;
+        T* C0 = A + next * ld + next;
+        TGP_TRY(trailing(S0, mt, TILE, kk, Pk, C0, first_role(mt, TILE)));
+        TGP_TRY(potf2_at(S0, next, false));
+        TGP_TRY(ev_record(ctx, ctx->ev_a, S0));
+        TGP_TRY(trailing(S0, mt - TILE, TILE, kk, Pk + TILE, C0 + TILE * ld + TILE, first_role(mt - TILE, TILE)));
+        TGP_TRY(ev_record(ctx, ctx->ev_g1, S0));
+        TGP_TRY(trailing(S0, mt - 2 * TILE, kbn - 2 * TILE, kk, Pk + 2 * TILE, C0 + 2 * TILE * ld + 2 * TILE,
+                         first_role(mt - 2 * TILE, kbn - 2 * TILE)));
+        TGP_TRY(ev_record(ctx, ctx->ev_g2, S0));
+      }
       k_done = 0;
-      // the panel's first potf2 goes in front of the big update on the main stream: issued
-      // beside it, it waits a whole round of tiles (~0.3 ms) for a free CU
-      TGP_TRY(potf2_at(S0, next, false));
-      TGP_TRY(ev_record(ctx, ctx->ev_a, S0));
       // 2. ... the main stream updates the rest (enqueued first: the ~90 API calls of a
       // panel take the host longer than a small update takes the GPU) ...
       const int64_t m2 = mt - kbn;
@@ -1504,6 +1530,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
         k_done = split * TILE;
         return TGP_OK;
       };
+      ctx->gate_pending = gsplit;
       TGP_TRY(panel(S1, next, kbn, true, split, early));
       TGP_TRY(ev_record(ctx, ctx->ev_b, S1));
       TGP_TRY(st_wait(ctx, S0, ctx->ev_b));

@@ -85,6 +85,8 @@ struct tgp_ctx {
   bool asm_pending = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_e = nullptr;
   hipEvent_t ev_f = nullptr;  // second marker of the far in-panel updates (fused panel step: they alternate)
+  hipEvent_t ev_g1 = nullptr, ev_g2 = nullptr;  // split gate: column block 1 / column blocks 2.. of the next panel updated
+  bool gate_pending = false;  // set by potrf in front of a panel whose block column arrives in those pieces
   int64_t nb_outer = 1024;  // measured best for N = 4k .. 32k (profiles/r01_f_nb_sweep.txt)
   int64_t lookahead = 1;
   int64_t dist_solve_aux = 1;  // block-column driver: forward steps on the update stream (0: a solve stream of their own)
@@ -106,6 +108,9 @@ struct tgp_ctx {
   // for the chain's kernels (gemm.hip: the update is persistent over its tiles, so its grid is its footprint)
   int64_t chain_reserve = 64;
   int64_t reserve_max_tiles = 3000;  // ... when the update has at most this many 128 x 128 tiles (chain-bound panels)
+  // the block-column update between two chains (the `gate`) is issued column block 0 | 1 | 2..: the chain starts
+  // behind the first piece and meets the others at its second and third block (fused panel step only)
+  int64_t gate_split = 1;
   int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
   uint32_t* d_step_flag = nullptr;  // the flag potf2's workgroup publishes; value = step_epoch of the launch
   uint32_t step_epoch = 0;
@@ -146,6 +151,8 @@ inline int64_t trace_event_id(const tgp_ctx* ctx, hipEvent_t ev) {
   if (ev == ctx->ev_e) return 4;
   if (ev == ctx->ev_asm) return 5;
   if (ev == ctx->ev_f) return 6;
+  if (ev == ctx->ev_g1) return 7;
+  if (ev == ctx->ev_g2) return 8;
   return -1;
 }
 template <typename T>
