@@ -101,11 +101,15 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       queued on the update stream (three busy queues); 0: on their own stream
  *   "first_split"       blocks of a panel after which its share of the next block-column
  *                       update is issued early, beside the panel's last blocks (default 5; 0 off)
- *   "fused_step"        1 (default): the panel chain is one launch per 128-column block (potf2, the
- *                       rows' own pending update and trsm behind a device-side flag: chol.hip,
- *                       panel_step_kernel); 0: potf2 | trsm | in-panel update as separate launches
+ *   "fused_step"        1: the panel chain is one launch per 128-column block (potf2, the rows' own
+ *                       pending update and trsm behind a device-side flag: chol.hip,
+ *                       panel_step_kernel); 0 (default): potf2 | trsm | in-panel update as separate
+ *                       launches.  "gate_split" (with fused_step = 1): the block-column update
+ *                       between two chains in three column pieces, the chain starts behind the first
+ *   "tail_small"        a trailing update's last, partly filled round of 128x128 tiles runs on the
+ *                       64x64-tile kernel when it has at most this many tiles (default 448; 0: never)
  *   "chain_reserve"     workgroup slots (of two per CU) that a trailing update running beside a panel
- *                       chain leaves to the chain's kernels (default 64; 0: the update fills the chip)
+ *                       chain leaves to the chain's kernels (default 128; 0: the update fills the chip)
  *   "reserve_max_tiles" ... when the update has at most this many 128x128 tiles (default 3000)
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
  *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming

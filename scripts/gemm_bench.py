@@ -15,8 +15,9 @@ dt = np.float64 if len(sys.argv) < 2 or sys.argv[1] == "f64" else np.float32
 es = np.dtype(dt).itemsize
 code = _ffi.dtype_code(dt)
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-for mode, lower in (((-1.0, 1.0), 0), ((-1.0, 1.0), 1)):
-  for K in (16, 128, 512, 1024, 2048):
+ONE = len(sys.argv) > 3 and sys.argv[3] == "one"  # one shape (for counter passes)
+for mode, lower in ((((-1.0, 1.0), 0),) if ONE else (((-1.0, 1.0), 0), ((-1.0, 1.0), 1))):
+  for K in ((1024,) if ONE else (16, 128, 512, 1024, 2048)):
     if True:
         rng = np.random.default_rng(0)
         dA = ctx.upload(rng.normal(size=M * K).astype(dt))

@@ -1,12 +1,12 @@
 #!/bin/bash
-# round 2, session 2, batch 7: split gate + rows fetched before the flag (fused chain), against the unfused chain
+# round 2, session 2, batch 9: the last partial round of a trailing update on small tiles
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-L=gpurun_out/s2b7.log
+L=gpurun_out/s2b9.log
 : > $L
 run() { # workload options
   echo "# $1 $2" >> $L
-  TGP_HIP_OPTIONS="$2" timeout 600 python bench.py --workload $1 --steps 8 --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "
+  TGP_HIP_OPTIONS="$2" timeout 600 python bench.py --workload $1 --steps $3 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "
 import sys,json
 for l in sys.stdin:
     try: d=json.loads(l)
@@ -16,16 +16,17 @@ for l in sys.stdin:
 " >> $L
 }
 echo "== pytest -m gpu" >> $L; date >> $L
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 >> $L
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 >> $L
 date >> $L
-for w in c2 n8192 n4096 n2048 n32768; do
-  run $w "fused_step=0,chain_reserve=0"
-  run $w "fused_step=0,chain_reserve=128"
-  run $w "fused_step=1,gate_split=0,chain_reserve=0"
-  run $w "fused_step=1,gate_split=1,chain_reserve=0"
-  run $w "fused_step=1,gate_split=1,chain_reserve=128"
+for t in 0 192 448; do
+  run c2 "tail_small=$t" 8
+  run n8192 "tail_small=$t" 8
+  run n32768 "tail_small=$t" 4
 done
-echo "== determinism stress (defaults)" >> $L; date >> $L
-timeout 300 python scripts/stress_determinism.py 2>&1 | tail -6 >> $L
+run n65536 "tail_small=0" 2
+run n65536 "tail_small=448" 2
+run c2 "tail_small=448,chain_reserve=0" 8
+echo "== gemm alone lower (tail 448)" >> $L
+timeout 200 python scripts/gemm_bench.py f64 16384 2>&1 | grep "lower=1" >> $L
 date >> $L
-tail -80 $L
+tail -40 $L

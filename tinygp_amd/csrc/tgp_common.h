@@ -103,14 +103,17 @@ struct tgp_ctx {
   int64_t first_small_tiles = 1100;  // look-ahead block-column updates up to this many tiles use 64x64 tiles
   // panel chain as ONE launch per 128-column block (panel_step_kernel: potf2 + the rows' own pending update
   // + trsm behind a device-side flag) instead of potf2 | trsm | update of the next column block (0: the latter)
-  int64_t fused_step = 1;
+  int64_t fused_step = 0;  // measured (profiles/r02_r): parity-green but 0-8 % slower than the separate launches
   // workgroup slots (of 2 per CU) that a trailing update which runs beside a panel chain leaves free
   // for the chain's kernels (gemm.hip: the update is persistent over its tiles, so its grid is its footprint)
-  int64_t chain_reserve = 64;
+  int64_t chain_reserve = 128;
   int64_t reserve_max_tiles = 3000;  // ... when the update has at most this many 128 x 128 tiles (chain-bound panels)
   // the block-column update between two chains (the `gate`) is issued column block 0 | 1 | 2..: the chain starts
   // behind the first piece and meets the others at its second and third block (fused panel step only)
   int64_t gate_split = 1;
+  // a trailing update's last, partly filled round of 128 x 128 tiles runs on the 64 x 64-tile kernel when it has
+  // at most this many tiles (0: never)
+  int64_t tail_small = 448;
   int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
   uint32_t* d_step_flag = nullptr;  // the flag potf2's workgroup publishes; value = step_epoch of the launch
   uint32_t step_epoch = 0;
