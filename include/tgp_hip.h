@@ -106,8 +106,6 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       panel_step_kernel); 0 (default): potf2 | trsm | in-panel update as separate
  *                       launches.  "gate_split" (with fused_step = 1): the block-column update
  *                       between two chains in three column pieces, the chain starts behind the first
- *   "tail_small"        a trailing update's last, partly filled round of 128x128 tiles runs on the
- *                       64x64-tile kernel when it has at most this many tiles (default 448; 0: never)
  *   "chain_reserve"     workgroup slots (of two per CU) that a trailing update running beside a panel
  *                       chain leaves to the chain's kernels (default 128; 0: the update fills the chip)
  *   "reserve_max_tiles" ... when the update has at most this many 128x128 tiles (default 3000)

@@ -10,8 +10,9 @@ def _f(a, dt):
     return np.asfortranarray(a, dtype=dt)
 
 
-def potrf(A, nb_outer=None, lookahead=None):
-    """In-place lower Cholesky of a symmetric (n,n) host matrix, n % 128 == 0. Returns (L, info)."""
+def potrf(A, nb_outer=None, lookahead=None, **options):
+    """In-place lower Cholesky of a symmetric (n,n) host matrix, n % 128 == 0. Returns (L, info).
+    Further context options (fused_step, gate_split, chain_reserve, ...) by keyword."""
     ctx = _ffi.default_ctx()
     dt = A.dtype
     n = A.shape[0]
@@ -20,6 +21,8 @@ def potrf(A, nb_outer=None, lookahead=None):
         old["nb_outer"] = ctx.set_option("nb_outer", nb_outer)
     if lookahead is not None:
         old["lookahead"] = ctx.set_option("lookahead", lookahead)
+    for k, v in options.items():
+        old[k] = ctx.set_option(k, v)
     dA = ctx.upload(_f(A, dt).ravel(order="K"))
     info = C.c_int32()
     try:

@@ -177,6 +177,38 @@ def test_potrf_block_sizes_agree(nb_outer):
     np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-11 * np.abs(Lref).max())
 
 
+@pytest.mark.parametrize("n", [1152, 2560, 5120])
+@pytest.mark.parametrize("opts", [dict(fused_step=1, gate_split=0), dict(fused_step=1, gate_split=1),
+                                  dict(fused_step=1, gate_split=1, lookahead=0),
+                                  dict(fused_step=0, chain_reserve=0), dict(fused_step=1, chain_reserve=256)])
+def test_panel_chain_variants_agree(n, opts):
+    """The optional schedules of the panel chain -- one fused launch per 128-column block
+    (panel_step_kernel: potf2 + the rows' own pending update + trsm behind a device-side flag), the
+    split gate, reserved workgroup slots -- give the default schedule's factor (same arithmetic per
+    entry except the fused step's left-looking update order: 1e-12) and LAPACK's."""
+    K = _spd(n, np.float64, seed=3)
+    Lref, info0 = ll.potrf(K)
+    L, info = ll.potrf(K, **opts)
+    assert info == 0 and info0 == 0
+    np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-12 * np.abs(Lref).max())
+    Llap = sla.cholesky(K, lower=True)
+    np.testing.assert_allclose(L, Llap, rtol=0, atol=1e-11 * np.abs(Llap).max())
+
+
+def test_panel_step_fp32_and_bad_pivot():
+    K = _spd(1536, np.float32, cond_diag=0.5)
+    L, info = ll.potrf(K, fused_step=1)
+    assert info == 0
+    Lref = sla.cholesky(K.astype(np.float64), lower=True)
+    np.testing.assert_allclose(L, Lref, rtol=5e-4, atol=5e-4)
+    # first non-positive pivot is reported from inside the fused step like from potf2
+    Kb = _spd(1024, np.float64, seed=2)
+    Kb[700, 700] = -1.0
+    _, info = ll.potrf(Kb, fused_step=1)
+    _, info_ref = ll.potrf(Kb)
+    assert info == info_ref == 701
+
+
 def test_potrf_fp32():
     K = _spd(1024, np.float32, cond_diag=0.5)
     L, info = ll.potrf(K)

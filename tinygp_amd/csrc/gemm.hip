@@ -69,9 +69,6 @@ struct GemmArgs {
   // l*dG + dr they are; rows of A / B / C are GLOBAL, tm = global row tiles, and local column
   // tile tj updates rows >= its global column tile only (lower trapezoid per column tile).
   int dG, dr, dl0, dnbt;
-  // small kernel as the TAIL of a big-tile launch: workgroups 4 t .. 4 t + 3 are the quadrants of big
-  // tile tail_first + t of a btm x btn big-tile grid (tail_first < 0: its own enumeration)
-  int tail_first, btm, btn;
 };
 
 // Linear workgroup id -> (ti, tj).  Tiles are enumerated column by column (tj major) so
@@ -425,14 +422,7 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmArgs<T> g) {
   __shared__ __attribute__((aligned(16))) T sB[2][BK * S_LD];
   __builtin_amdgcn_s_setprio(1);
   int ti, tj;
-  if (g.tail_first >= 0) {
-    int bi, bj;
-    decode_tile(g.tail_first + int(blockIdx.x >> 2), g.btm, g.btn, g.lower, bi, bj);
-    ti = 2 * bi + int(blockIdx.x & 1);
-    tj = 2 * bj + int((blockIdx.x >> 1) & 1);
-  } else {
-    decode_tile(blockIdx.x, g.tm, g.tn, g.lower, ti, tj);
-  }
+  decode_tile(blockIdx.x, g.tm, g.tn, g.lower, ti, tj);
   if (g.skip00 && ti < 2 && tj < 2) return;  // that tile is updated inside the next potf2
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1;
@@ -670,8 +660,6 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   GemmArgs<T> g;
   g.skip00 = 0;
   g.dG = g.dr = g.dl0 = g.dnbt = 0;
-  g.tail_first = -1;
-  g.btm = g.btn = 0;
   TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");
   // short-K updates, and (role 4) a latency-bound update with too few big tiles to fill the chip
   if ((((role == 1 || role == 3) && k <= 256) || role == 4) && (mode == 0 || mode == 1)) {
@@ -702,30 +690,14 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   }
   const int64_t reserve = role == 0 ? ctx->reserve_hint : 0;
   ctx->reserve_hint = 0;
-  // Tail: equal tiles come in rounds of 2 x CUs, and a last round with few tiles costs a whole tile
-  // time (245 us at K = 1024) on a mostly idle chip -- 5-14 % of an update of 5-13 rounds.  Those last
-  // tiles go to the 64 x 64-tile kernel instead (four workgroups each), behind the full rounds.
-  int tail = 0;
-  const int slots = 2 * (ctx->cus > 0 ? ctx->cus : 256);
-  if (role == 0 && lower && mode == 0 && reserve <= 0 && ctx->tail_small > 0 && g.nblk > slots) {
-    const int r = g.nblk % slots;
-    if (r > 0 && r <= ctx->tail_small) tail = r;
-  }
-  GemmArgs<T> gs = g;
-  g.nblk -= tail;
+  // (Measured and removed, profiles/r02_r: the last, partly filled round of tiles on the 64x64-tile
+  // kernel -- four workgroups per tile behind the full rounds.  Its k-loop of 64 short k-tiles takes
+  // as long as the 245-us round it replaces: 4.43 vs 4.40 ms on a 16384^2 lower update.)
   const unsigned grid = persistent_grid(ctx, g.nblk, reserve);
   if (role == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3(grid), dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3(grid), dim3(256), 0, st, g);
-  if (tail > 0) {
-    gs.tail_first = g.nblk;
-    gs.btm = g.tm;
-    gs.btn = g.tn;
-    gs.tm = int(m / SM);
-    gs.tn = int(n / SM);
-    hipLaunchKernelGGL((gemm_nt_small_kernel<T>), dim3(unsigned(4 * tail)), dim3(256), 0, st, gs);
-  }
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -744,8 +716,6 @@ int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb
   if (nloc <= 0) return TGP_OK;
   GemmArgs<T> g;
   g.skip00 = 0;
-  g.tail_first = -1;
-  g.btm = g.btn = 0;
   g.A = P; g.B = P; g.C = Cloc + l0 * nb * ldc;
   g.lda = ldp; g.ldb = ldp; g.ldc = ldc;
   g.tm = int(n_rows / BM); g.tn = int(nloc * (nb / BN));
