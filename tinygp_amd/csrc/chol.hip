@@ -109,287 +109,8 @@ __device__ long long g_potf2_stamps[64];
 #define POTF2_STAMP(i) do {} while (0)
 #endif
 
-// The body of potf2 (one workgroup of 512 threads; S = 36 x 256 elements and Rs = 32 elements of
-// LDS): shared by the stand-alone kernel and by the fused panel step (panel_step_kernel).
-template <typename T, bool FOLD>
-__device__ __forceinline__ void potf2_body(T* __restrict__ S, T* __restrict__ Rs, T* __restrict__ A,
-                                           int64_t ld, T* __restrict__ dinv,
-                                           int32_t* __restrict__ info, int32_t pivot_base,
-                                           const T* __restrict__ Xp, int64_t ldx) {
-  using M = Mfma<T>;
-  using acc_t = typename M::acc_t;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar address math
-  const int lrow = lane & 15;
-  __builtin_amdgcn_s_setprio(3);
-
-  POTF2_STAMP(0);
-  // the tile: one 16x16 block per wave per trip, 4 elements per lane; with a fold it is fetched
-  // while the fold's second half runs (S is the fold's exchange buffer until then)
-  T tr[5][4];
-  auto load_tile = [&]() {
-#pragma unroll
-    for (int trip = 0; trip < 5; ++trip) {
-      const int b = w + 8 * trip;
-      if (b < 36) {
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= b) ++i;
-        const int j = b - i * (i + 1) / 2;
-        // uniform base (SGPRs) + one 32-bit lane offset: no per-load address registers
-        const int voff = (lane >> 4) * int(ld) + lrow;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const T* src = A + int64_t(j * 16 + q * 4) * ld + i * 16;
-          tr[trip][q] = src[voff];
-        }
-      }
-    }
-  };
-  if constexpr (!FOLD) load_tile();
-  // Pending in-panel update of THIS tile, folded in so that it is not a separate kernel on the
-  // critical path:  A_tile -= Xp Xp^T  with Xp = the previous block column's 128 rows of this
-  // tile (128 x 128, column-major, ld = ldx).  Wave w loads the 16-row slab w of Xp in MFMA
-  // operand layout -- 32 independent loads, ONE round trip to L2 (a version that reads its
-  // operands block by block from global needs ten dependent round trips per wave) -- and the
-  // slabs are exchanged through LDS, 64 k-columns at a time, in the space of S (exactly
-  // 64 x 144 doubles; no LDS beyond the 74 KB that lets potf2 share a CU with a GEMM
-  // workgroup).  Rows p and 7-p hold p + 1 and 8 - p blocks, nine per pair: waves p and p + 4
-  // share pair p (blocks t = 0..4 and t = 5..8 of it).
-  constexpr int XC_LD = 144;  // 144 mod 32 == 16: conflict-free operand reads
-  static_assert(64 * XC_LD <= 36 * 256, "fold exchange buffer must fit in S");
-  T* Xc = S;
-  const int pr = w & 3, i1 = pr, i2 = 7 - pr;
-  const int t0 = (w < 4) ? 0 : 5, nt = (w < 4) ? 5 : 4;
-  acc_t Cf[5];
-  if constexpr (FOLD) {
-    acc_t V[8];
-    const int xoff = M::drow(lane, 0) * int(ldx) + lrow;  // drow(lane, r) = drow(lane, 0) + drow(0, r)
-#pragma unroll
-    for (int jb = 0; jb < 8; ++jb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const T* xs = Xp + int64_t(jb * 16 + M::drow(0, r)) * ldx + w * 16;
-        V[jb][r] = xs[xoff];
-      }
-    const int lk = lane >> 4;
-#pragma unroll
-    for (int tt = 0; tt < 5; ++tt) Cf[tt] = acc_t{0, 0, 0, 0};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h) __syncthreads();  // first half fully consumed
-#pragma unroll
-      for (int jq = 0; jq < 4; ++jq)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          Xc[((jq * 4 + r) * 4 + lk) * XC_LD + w * 16 + lrow] = V[h * 4 + jq][r];
-      if (h) load_tile();  // V is dead: the tile's round trip hides under the second half
-      __syncthreads();
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const T* row = &Xc[(ks * 4 + lk) * XC_LD + lrow];
-        const T b1 = row[i1 * 16], b2 = row[i2 * 16];
-#pragma unroll
-        for (int tt = 0; tt < 5; ++tt) {
-          if (tt < nt) {
-            const int t = t0 + tt;
-            const bool first = t <= pr;
-            const int jj = first ? t : t - pr - 1;
-            Cf[tt] = M::mma(row[jj * 16], first ? b1 : b2, Cf[tt]);
-          }
-        }
-      }
-    }
-    __syncthreads();  // exchange buffer dead: S can take the tile
-  }
-#pragma unroll
-  for (int trip = 0; trip < 5; ++trip) {
-    const int b = w + 8 * trip;
-    if (b < 36) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) S[b * 256 + q * 64 + lane] = tr[trip][q];
-    }
-  }
-  if constexpr (FOLD) {
-    __syncthreads();
-#pragma unroll
-    for (int tt = 0; tt < 5; ++tt) {
-      if (tt < nt) {
-        const int t = t0 + tt;
-        const bool first = t <= pr;
-        const int ii = first ? i1 : i2, jj = first ? t : t - pr - 1;
-        T* Cij = &S[blk(ii, jj)];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] -= Cf[tt][r];
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- column block kb: unblocked right-looking elimination with lane = ROW, for the diagonal
-  // block AND the blocks below it at once.  Lanes 0..15 of an eliminating wave hold the 16 rows
-  // of the diagonal block, lanes 16..63 the rows of three blocks below it (group g: blocks
-  // kb+1+3g .. kb+3+3g).  The pivot-row values every lane needs are broadcast from lanes
-  // 0..15 through v_readlane -> SGPR operands, so the rows below ride along in the same VALU
-  // instructions for free: there is no separate "L_ik = A_ik L_kk^-T" phase (and no 16x16
-  // inverse) on the critical path.  With more than three blocks below, waves 1 (and 2) take
-  // the other groups and simply repeat the diagonal block's elimination in their lanes 0..15
-  // -- no communication between the eliminating waves.
-  auto factor_panel = [&](int kb, int grp) {
-    const int k0 = kb * 16;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));  // opaque: lane predicates are recomputed here, not hoisted
-                                  // out of the kb loop as dozens of live SGPR masks
-    const int lr = ln & 15;
-    const int i0 = (ln < 16) ? kb : kb + 3 * grp + (ln >> 4);
-    const bool keep = (i0 < 8) && (ln >= 16 || grp == 0);  // rows this wave writes back
-    T* B0 = &S[blk(i0 < 8 ? i0 : kb, kb)];
-    T a0[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) a0[c] = B0[c * 16 + lr];
-    // The pivot of column j+1 is predicted from scalars that exist BEFORE the vector update
-    // of step j lands (d_{j+1} = a_{j+1,j+1} - a_{j+1,j}^2 / d_j), so the reciprocal chain
-    // -- the critical path of the 16 sequential columns -- never waits for a VALU -> readlane
-    // round trip; the vector updates run in its shadow.
-    int bad = 0;
-    T d = readlane(a0[0], 0);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (!(d > T(0)) && bad == 0) bad = j + 1;
-      const T rinv = fast_rcp(d);
-      if (j + 1 < 16) {
-        const T t = readlane(a0[j], j + 1), u = readlane(a0[j + 1], j + 1);
-        d = u - (t * t) * rinv;
-      }
-      const T w0 = a0[j] * rinv;
-      // (row c, col j) of the diagonal block, fetched one element ahead of its use so that the
-      // SGPR write -> VALU read wait states of v_readlane are covered by the previous FMA
-      T bnext = (j + 1 < 16) ? readlane(a0[j], j + 1) : T(0);
-#pragma unroll
-      for (int c = j + 1; c < 16; ++c) {
-        const T bc = bnext;
-        if (c + 1 < 16) bnext = readlane(a0[j], c + 1);
-        a0[c] -= w0 * bc;
-      }
-    }
-    if (grp == 0 && bad != 0 && ln == 0) atomicCAS(info, 0, pivot_base + k0 + bad);
-    // scale column j by 1 / L_jj = rsqrt(d_j): one vector rsqrt over the diagonal (lane j
-    // holds d_j in a0[j]) instead of sixteen scalar ones inside the loop
-    T dd = a0[0];
-#pragma unroll
-    for (int j = 1; j < 16; ++j) dd = (lr == j) ? a0[j] : dd;
-    const T rs = fast_rsqrt(dd);  // lanes 0..15: 1 / L_ii; NaN / inf poisons the factor when d <= 0
-#pragma unroll
-    for (int j = 0; j < 16; ++j) a0[j] *= readlane(rs, j);
-    if (grp == 0 && ln < 16) Rs[(kb & 1) * 16 + lr] = rs;
-    // (entries above the diagonal of the diagonal block are left as they are: nothing reads
-    // them in LDS and the final store writes zeros there)
-    if (keep) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) B0[c * 16 + lr] = a0[c];
-    }
-  };
-  // W = L_kk^-1 (one wave, off the critical path; only the panel solves that FOLLOW this kernel
-  // need it): lane c owns column c, outer-product order, operands as LDS broadcasts.
-  auto invert_diag = [&](int kb) {
-    int i = lrow;
-    asm volatile("" : "+v"(i));  // see factor_panel
-    const T* D = &S[blk(kb, kb)];
-    const T* R = &Rs[(kb & 1) * 16];
-    T* out = dinv + kb * 256 + i * 16;  // element (row c, col i) of W at i * 16 + c
-    T sv[16];
-#pragma unroll
-    for (int ii = 0; ii < 16; ++ii) sv[ii] = (ii == i) ? T(1) : T(0);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const T xk = sv[k] * R[k];
-#pragma unroll
-      for (int ii = k + 1; ii < 16; ++ii) sv[ii] -= D[k * 16 + ii] * xk;
-      sv[k] = xk;
-    }
-    if (lane < 16) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) out[c] = sv[c];
-    }
-  };
-  // A_ij -= L_ik L_jk^T on the MFMAs (one 16x16 block pair per call)
-  auto update_pair = [&](int ib, int jb, int kb) {
-    T* Cij = &S[blk(ib, jb)];
-    const T* Xi = &S[blk(ib, kb)];
-    const T* Xj = &S[blk(jb, kb)];
-    acc_t acc, acc2 = acc_t{0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = Cij[M::drow(lane, r) * 16 + lrow];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int kk = M::drow(lane, s);
-      const T xj = -Xj[kk * 16 + lrow], xi = Xi[kk * 16 + lrow];
-      if (s & 1) acc2 = M::mma(xj, xi, acc2);
-      else acc = M::mma(xj, xi, acc);
-    }
-    acc += acc2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Cij[M::drow(lane, r) * 16 + lrow] = acc[r];
-  };
-
-  // the 128 x 16 strip of column block cb of the tile -> global (zeros above the diagonal)
-  auto store_strip = [&](int cb, int q0, int q1) {
-#pragma unroll 4
-    for (int q = q0; q < q1; ++q) {
-      const int e = lane + 64 * q;  // 128 rows x 16 columns
-      const int cl = e >> 7, r = e & 127, c = cb * 16 + cl;
-      A[int64_t(c) * ld + r] = (r >= c) ? S[blk(r >> 4, cb) + cl * 16 + (r & 15)] : T(0);
-    }
-  };
-  // eliminating waves of step kb: one per three blocks below the diagonal block
-  auto n_elim = [](int kb) { return kb >= 7 ? 1 : (7 - kb + 2) / 3; };
-  for (int kb = 0; kb < 8; ++kb) {
-    POTF2_STAMP(1 + 4 * kb);
-    if (w < n_elim(kb)) factor_panel(kb, w);
-    POTF2_STAMP(2 + 4 * kb);
-    __syncthreads();  // column block kb of L is final; the updates of step kb-1 are complete
-    POTF2_STAMP(3 + 4 * kb);
-    if (kb == 7) {
-      if (w == 1) invert_diag(7);
-      break;
-    }
-    // column block kb+1 first (all that the next elimination needs): one pair per wave
-    if (kb + 1 + w < 8) update_pair(kb + 1 + w, kb + 1, kb);
-    __syncthreads();
-    POTF2_STAMP(4 + 4 * kb);
-    // the eliminating waves go straight on to column block kb+1; beside them one wave inverts
-    // L_kk and the others update the remaining pairs (in-kernel look-ahead)
-    const int ne = n_elim(kb + 1);
-    // fp64 MFMA and fp64 VALU share a SIMD's ALUs and wave w runs on SIMD w % 4: an
-    // elimination alone on its SIMD takes 4.7 k cycles instead of 5.0-5.8 k.  Once a single
-    // wave eliminates (column blocks 4..7) there are few enough block pairs left for the wave
-    // that shares its SIMD (wave 4) to sit the step out; the earlier steps need all eight.
-    const bool reserve = ne == 1;
-    const bool sits_out = reserve && w >= 4 && w < 4 + ne;
-    if (w >= ne && !sits_out) {
-      const int nwk = reserve ? 8 - 2 * ne : 8 - ne;                      // working waves
-      const int idx = (reserve && w >= 4) ? w - 2 * ne : w - ne;          // 0 .. nwk-1
-      if (idx == 0) {
-        invert_diag(kb);
-      } else {
-        int cnt = 0;
-        for (int jb = kb + 2; jb < 8; ++jb)
-          for (int ib = jb; ib < 8; ++ib)
-            if ((cnt++ % (nwk - 1)) + 1 == idx) update_pair(ib, jb, kb);
-        // column block kb is final: it goes out under the next step, a slice per updating wave
-        store_strip(kb, (idx - 1) * 32 / (nwk - 1), idx * 32 / (nwk - 1));
-      }
-    }
-  }
-  __syncthreads();
-
-  POTF2_STAMP(33);
-  // column blocks 0..6 went out while later steps ran; the last one now, a slice per wave
-  store_strip(7, 4 * w, 4 * w + 4);
-  POTF2_STAMP(34);
-}
-
 // waves_per_eu(4): at most 128 VGPRs, so that two potf2 waves fit on a SIMD beside one wave of the
-// trailing-update GEMM (234 VGPRs) -- otherwise potf2 waits for the whole update to drain.
+// trailing-update GEMM (<= 251 VGPRs) -- otherwise potf2 waits for the whole update to drain.
 template <typename T, bool FOLD>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void potf2_kernel(T* __restrict__ A, int64_t ld,
                                                     T* __restrict__ dinv,
@@ -398,7 +119,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                     const T* __restrict__ Xp, int64_t ldx) {
   __shared__ __attribute__((aligned(16))) T S[36 * 256];
   __shared__ T Rs[2 * 16];                                 // 1 / L_ii of the current / previous block
-  potf2_body<T, FOLD>(S, Rs, A, ld, dinv, info, pivot_base, Xp, ldx);
+#include "potf2_body.inc"
 }
 
 // ---------------------------------------------------------------------------------------
@@ -425,7 +146,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 constexpr int32_t STEP_TIMEOUT = INT32_MIN;
 
 template <typename T, bool FOLD>
-__device__ __forceinline__ void trsm_fold_body(T* __restrict__ S, int it, const T* __restrict__ Ljj,
+__device__ __forceinline__ void trsm_fold_body(T* S, int it, const T* __restrict__ Ljj,
                                                int64_t ld, const T* __restrict__ dinv,
                                                const T* __restrict__ Xp, const uint32_t* flag,
                                                uint32_t epoch, int wait_flag, int32_t* info) {
@@ -612,7 +333,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   __shared__ T Rs[2 * 16];
   const int b = __builtin_amdgcn_readfirstlane(blockIdx.x);
   if (b < has_p) {
-    potf2_body<T, FOLD>(S, Rs, A, ld, dinv, info, pivot_base, Xp, ld);
+    {
+      const int64_t ldx = ld;
+#include "potf2_body.inc"
+    }
     // publish: every wave's stores have left it -> barrier -> one agent-scope release -> flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
