@@ -48,8 +48,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured co
 # units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM" for wide coalesced reads).  PMC
 # collection serialises kernels, so it cannot run inside the timed region; configurations
 # other than the one the passes were collected on report null.
-PMC_TRAFFIC = {"file": "profiles/r02_n_final_evidence.md",
-               "bytes_per_launch": (2 * 55.119e9 + 12.634e9) / 42, "nb": 1024}
+PMC_TRAFFIC = {"file": "profiles/r02_s_final_evidence.md",
+               "bytes_per_launch": (2 * 55.726e9 + 12.634e9) / 42, "nb": 1024}
 
 
 def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles: int = 0,

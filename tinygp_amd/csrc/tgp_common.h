@@ -107,7 +107,7 @@ struct tgp_ctx {
   // workgroup slots (of 2 per CU) that a trailing update which runs beside a panel chain leaves free
   // for the chain's kernels (gemm.hip: the update is persistent over its tiles, so its grid is its footprint)
   int64_t chain_reserve = 128;
-  int64_t reserve_max_tiles = 3000;  // ... when the update has at most this many 128 x 128 tiles (chain-bound panels)
+  int64_t reserve_max_tiles = 1200;  // ... when the update has at most this many 128 x 128 tiles (chain-bound panels)
   // the block-column update between two chains (the `gate`) is issued column block 0 | 1 | 2..: the chain starts
   // behind the first piece and meets the others at its second and third block (fused panel step only)
   int64_t gate_split = 1;
