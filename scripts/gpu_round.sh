@@ -1,12 +1,13 @@
 #!/bin/bash
-# round 2, session 2, batch 22: config 4 (N = 131072) through the block-column driver at world size 1 with the new update kernel
+# round 2, session 2, batch 23: the GPU suite and the smoke check on the final tree
 R=$GRAFT_REPO_ROOT
 cd $R
 O=$R/gpurun_out
 mkdir -p $O
 {
 date
-timeout 400 python bench.py --distributed --workload c4 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary 2>$O/dist_c4.err | tail -1 > $O/dist_c4.json; cut -c1-1500 $O/dist_c4.json
+timeout 140 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -3
+timeout 60 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -i smoke
 date
-} > $O/round22.log 2>&1
-cat $O/round22.log
+} > $O/round23.log 2>&1
+cat $O/round23.log
