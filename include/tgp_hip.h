@@ -109,6 +109,9 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "chain_reserve"     workgroup slots (of two per CU) that a trailing update running beside a panel
  *                       chain leaves to the chain's kernels (default 128; 0: the update fills the chip)
  *   "reserve_max_tiles" ... when the update has at most this many 128x128 tiles (default 1200)
+ *   "potf2_sync"        1: potf2 with the read / write-back order of the diagonal block between its
+ *                       eliminating waves enforced by LDS flags (staged; default 0 = the timing-ordered,
+ *                       stress-tested kernel -- DESIGN.md, "What comes next", item 6)
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
  *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming
  *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block
