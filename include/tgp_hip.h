@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 1
+/* bumped whenever an exported signature or option changes; the Python binding refuses another version
+ * (round 2 -> 3: tgp_trace_factor gained nb_wide_rows, ~15 entry points added, "potf2_sync" removed) */
+#define TGP_ABI_VERSION 3
 
 /* element types: follows the dtype of the caller's arrays (gp.py:89) */
 #define TGP_F32 0
@@ -109,9 +111,6 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "chain_reserve"     workgroup slots (of two per CU) that a trailing update running beside a panel
  *                       chain leaves to the chain's kernels (default 128; 0: the update fills the chip)
  *   "reserve_max_tiles" ... when the update has at most this many 128x128 tiles (default 1200)
- *   "potf2_sync"        1: potf2 with the read / write-back order of the diagonal block between its
- *                       eliminating waves enforced by LDS flags (staged; default 0 = the timing-ordered,
- *                       stress-tested kernel -- DESIGN.md, "What comes next", item 6)
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
  *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming
  *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block

@@ -1,0 +1,218 @@
+"""Full-size fp64 LAPACK values for the BASELINE configs no dense host factorisation can reach:
+
+  * config 4 (1.5^2 ExpSquared(2.5), 1-D, N = 131 072, fp64): log-likelihood + normalisation;
+  * config 5 (1.5^2 ExpSquared(2.5) + 0.5^2 Matern32(1.0), N = 262 144, fp32 inputs): log-likelihood,
+    posterior mean AND variance at the config's 4 096 test points -- in fp64, the value the fp32 device
+    path is held to at 5e-4 (src/tinygp/test_utils.py:15);
+  * config 2 (N = 16 384): posterior mean and variance at 4 096 test points (+ the check of this
+    method against the dense oracle at that size).
+
+How: on sorted 1-D inputs these kernel matrices are BANDED.  exp(-r^2 / 2 l^2) underflows to exactly 0.0 in
+fp64 beyond r = 96.5 (l = 2.5), i.e. |i - j| > kd ~ 9 900 at 100 points per unit length: config 4's matrix
+as the dense oracle would assemble it has no non-zero entry outside that band (asserted while assembling),
+and the Cholesky factor of a banded matrix has the same band.  So a dense right-looking factorisation on a
+sliding (kd + bs)-square window -- LAPACK dpotrf / dtrsm / dsyrk on exactly the entries
+oracle/tinygp_np.py computes (same formulas, same order: the window is filled with the oracle's own
+kernel objects) -- IS the dense factorisation; the forward substitutions of y and of K(X, X*) ride in the
+same sweep (alpha'alpha, mean = V'z, variance = k** - colsum(V o V) need nothing else:
+solvers/direct.py:75-95, gp.py:318-359).  Config 5's Matern-3/2 term never underflows within the domain, so
+there entries below `cutoff` (1e-30, 29 orders of magnitude under the 0.1 noise floor) are dropped:
+|dK| <= kd * 1e-30 per row, relative effect on any result <= cond(K) * |dK| / |K| < 1e-24 -- and the method
+is checked against the dense oracle's stored values at N = 32 768 (tests/golden/large.npz) and against a
+dense factorisation of config 2 at N = 16 384 below.
+
+    python tests/golden/make_golden_banded.py [check] [c2] [c4] [c5]      (c4: ~4 min, c5: ~6 min on 8 cores)
+"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import scipy.linalg as sla
+from scipy.linalg import lapack
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+
+from oracle import tinygp_np as o  # noqa: E402
+from tinygp_amd import synthetic  # noqa: E402
+
+OUT = Path(__file__).resolve().parent / "large.npz"
+
+
+def bandwidth(kern, X, cutoff):
+    """Smallest kd with |k(x_i, x_j)| <= cutoff for every |i - j| > kd (sorted 1-D X; the kernel decreases
+    with distance): bisect the distance at which the kernel drops to the cutoff, then count points."""
+    lo, hi = 0.0, float(X[-1] - X[0]) + 1.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        v = float(kern(np.array([0.0]), np.array([mid]))[0, 0])
+        if abs(v) > cutoff:
+            lo = mid
+        else:
+            hi = mid
+    r0 = hi
+    j = np.searchsorted(X, X + r0, side="right") - 1  # last index within r0 of x_i
+    return int(np.max(j - np.arange(len(X)))), r0
+
+
+def window_gp(kern, X, y, diag, *, cutoff=0.0, bs=2048, xt=None, log=print):
+    """One forward sweep of the dense right-looking LL^T over a sliding window (see the module docstring).
+    Returns dict(logp, norm, zz, kd[, mean, v2, kss])."""
+    n = len(X)
+    kd, r0 = bandwidth(kern, X, cutoff)
+    W = kd + bs
+    m = 0 if xt is None else len(xt)
+    log(f"  n={n} cutoff={cutoff:g}: kernel <= cutoff beyond r={r0:.3f} -> kd={kd}, window {W}, {m} test points")
+    idx = np.arange(n)
+
+    def fill_rows(r_lo, r_hi, c_lo, c_hi):
+        """K[r_lo:r_hi, c_lo:c_hi] as the oracle assembles it, entries outside the band dropped (asserting
+        that they are <= cutoff), noise on the diagonal."""
+        blk = kern(X[r_lo:r_hi], X[c_lo:c_hi])
+        out = np.abs(idx[r_lo:r_hi, None] - idx[None, c_lo:c_hi]) > kd
+        if out.any():
+            assert np.max(np.abs(blk[out])) <= cutoff, "entry above the cutoff outside the band"
+            blk[out] = 0.0
+        d = np.intersect1d(idx[r_lo:r_hi], idx[c_lo:c_hi])
+        blk[d - r_lo, d - c_lo] += diag
+        return blk
+
+    def rhs_rows(r_lo, r_hi):
+        cols = [y[r_lo:r_hi, None]]
+        if m:
+            cols.append(kern(X[r_lo:r_hi], xt))
+        return np.concatenate(cols, axis=1)
+
+    Wc = min(W, n)
+    Win = np.asfortranarray(fill_rows(0, Wc, 0, Wc))
+    Rw = rhs_rows(0, Wc)
+    logdet, zz = 0.0, 0.0
+    mean, v2 = np.zeros(m), np.zeros(m)
+    g0, t0 = 0, time.time()
+    while g0 < n:
+        b = min(bs, n - g0)
+        Wc = min(W, n - g0)
+        L11, info = lapack.dpotrf(np.array(Win[:b, :b], order="F"), lower=1, clean=1)
+        assert info == 0, (g0, info)
+        logdet += float(np.sum(np.log(np.diag(L11))))
+        R1 = sla.solve_triangular(L11, Rw[:b], lower=True, check_finite=False)
+        z = R1[:, 0]
+        zz += float(z @ z)
+        if m:
+            V = R1[:, 1:]
+            mean += V.T @ z
+            v2 += np.einsum("ij,ij->j", V, V)
+        if Wc > b:
+            L21 = sla.solve_triangular(L11, Win[b:Wc, :b].T, lower=True, check_finite=False).T
+            Rw[b:Wc] -= L21 @ R1
+            Win[b:Wc, b:Wc] -= L21 @ L21.T
+        ng0 = g0 + b
+        if ng0 >= n:
+            break
+        keep, nWc = Wc - b, min(W, n - ng0)
+        Win2 = np.zeros((nWc, nWc), order="F")
+        Win2[:keep, :keep] = Win[b:Wc, b:Wc]
+        Rw2 = np.empty((nWc, 1 + m))
+        Rw2[:keep] = Rw[b:Wc]
+        if nWc > keep:  # rows entering the window: untouched by every eliminated column (outside their band)
+            new = fill_rows(ng0 + keep, ng0 + nWc, ng0, ng0 + nWc)
+            Win2[keep:, :] = new
+            Win2[:keep, keep:] = new[:, :keep].T
+            Rw2[keep:] = rhs_rows(ng0 + keep, ng0 + nWc)
+        Win, Rw, g0 = Win2, Rw2, ng0
+        if (g0 // bs) % 16 == 0:
+            log(f"    row {g0}/{n} ({time.time() - t0:.0f} s)")
+    norm = logdet + 0.5 * n * np.log(2 * np.pi)
+    res = dict(logp=-0.5 * zz - norm, norm=norm, zz=zz, kd=kd)
+    if m:
+        res.update(mean=mean, v2=v2, kss=kern(xt))  # kss: prior variance k(x*, x*) (gp.py:208-221 adds no noise)
+    return res
+
+
+def _c(name):
+    c = synthetic.CONFIGS[name]
+    return c, synthetic.config_kernel(o, c["kernel"])
+
+
+def check():
+    """The window sweep against a DENSE LAPACK factorisation of the same oracle matrix."""
+    out = {}
+    for name, n, cutoff in (("c2", 16384, 0.0), ("c5", 8192, 1e-30)):
+        c, kern = _c(name)
+        X, y = synthetic.make_inputs(n, 1, c["dtype"])
+        X, y = X.astype(np.float64), y.astype(np.float64)
+        xt = np.linspace(0.0, n / 100.0, 512).astype(c["dtype"]).astype(np.float64)
+        got = window_gp(kern, X, y, c["diag"], cutoff=cutoff, bs=1024, xt=xt)
+        gp = o.GaussianProcess(kern, X, diag=c["diag"])
+        want_logp = float(gp.log_probability(y))
+        cond = gp.condition(y, xt).gp
+        e = (abs(got["logp"] - want_logp) / abs(want_logp), float(np.max(np.abs(got["mean"] - cond.loc))),
+             float(np.max(np.abs((got["kss"] - got["v2"]) - cond.variance))))
+        print(f"check {name} N={n}: kd={got['kd']} logp rel {e[0]:.2e}, mean max abs {e[1]:.2e}, "
+              f"variance max abs {e[2]:.2e}", flush=True)
+        # The variance k** - |L^-1 k*|^2 cancels ~2.25 down to ~1e-3 and is sensitive to the factorisation's
+        # backward error: |d var| <= |K^-1 k*|^2 |dK| ~ (4e3)^2 x 1.5e-13 = 2e-6 at config 2's conditioning
+        # (cond ~ 1.4e5), so two LAPACK blockings of the SAME matrix agree to ~1e-8 only -- inside the
+        # reference's own 5e-7 (src/tinygp/test_utils.py:16), and the floor of any fp64 comparison there.
+        assert e[0] < 1e-12 and e[1] < 1e-10 and e[2] < 1e-7
+        out[f"check_{name}_n{n}"] = np.array(e)
+    # config 5's truncated band against the stored dense-oracle values at N = 32 768
+    big = dict(np.load(OUT))
+    c, kern = _c("c5")
+    n = 32768
+    X, y = synthetic.make_inputs(n, 1, "float32")
+    X, y = X.astype(np.float64), y.astype(np.float64)
+    xt = np.linspace(0.0, n / 100.0, 4096).astype(np.float32).astype(np.float64)
+    got = window_gp(kern, X, y, c["diag"], cutoff=1e-30, xt=xt)
+    e = (abs(got["logp"] - float(big["c5_n32768__logp"])) / abs(float(big["c5_n32768__logp"])),
+         float(np.max(np.abs(got["mean"] - big["c5_n32768__test_loc"]))))
+    print(f"check c5 N={n} vs tests/golden/large.npz (dense): logp rel {e[0]:.2e}, mean max abs {e[1]:.2e}", flush=True)
+    assert e[0] < 1e-12 and e[1] < 1e-10
+    out["check_c5_n32768"] = np.array(e)
+    out["c5_n32768__test_var"] = got["kss"] - got["v2"]
+    return out
+
+
+def config2():
+    c, kern = _c("c2")
+    X, y = synthetic.make_inputs(c["n"], 1, c["dtype"])
+    xt = np.linspace(0.0, c["n"] / 100.0, 4096)
+    r = window_gp(kern, X, y, c["diag"], xt=xt)
+    print(f"c2: logp {r['logp']!r}", flush=True)
+    return {"c2_n16384__logp": np.float64(r["logp"]), "c2_n16384__test_loc": r["mean"],
+            "c2_n16384__test_var": r["kss"] - r["v2"]}
+
+
+def config4():
+    c, kern = _c("c4")
+    X, y = synthetic.make_inputs(c["n"], 1, c["dtype"])
+    t0 = time.time()
+    r = window_gp(kern, X, y, c["diag"])
+    print(f"c4: logp {r['logp']!r} norm {r['norm']!r} kd {r['kd']} ({time.time() - t0:.0f} s)", flush=True)
+    return {"c4_n131072__logp": np.float64(r["logp"]), "c4_n131072__norm": np.float64(r["norm"]),
+            "c4_n131072__kd": np.int64(r["kd"])}
+
+
+def config5():
+    c, kern = _c("c5")
+    n, m = c["n"], c["m_test"]
+    X, y = synthetic.make_inputs(n, 1, "float32")  # the fp32 inputs the device sees, in fp64 arithmetic
+    X, y = X.astype(np.float64), y.astype(np.float64)
+    xt = np.linspace(0.0, n / 100.0, m).astype(np.float32).astype(np.float64)
+    t0 = time.time()
+    r = window_gp(kern, X, y, c["diag"], cutoff=1e-30, xt=xt)
+    print(f"c5: logp {r['logp']!r} kd {r['kd']} ({time.time() - t0:.0f} s)", flush=True)
+    return {"c5_n262144__logp": np.float64(r["logp"]), "c5_n262144__norm": np.float64(r["norm"]),
+            "c5_n262144__test_loc": r["mean"], "c5_n262144__test_var": r["kss"] - r["v2"],
+            "c5_n262144__kd": np.int64(r["kd"])}
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["check", "c2", "c4", "c5"]
+    for w in which:
+        new = {"check": check, "c2": config2, "c4": config4, "c5": config5}[w]()
+        res = dict(np.load(OUT)) if OUT.exists() else {}
+        res.update(new)
+        np.savez_compressed(OUT, **res)
+    print(sorted(dict(np.load(OUT))))

@@ -40,17 +40,19 @@ def _worker(rank, world, port, n, nb, bad, m_test, q):
         if m_test:
             xt = np.linspace(X[0], X[-1], m_test)
             mean = s.condition_mean(y, xt)
+            # a DIFFERENT right-hand side must not reuse the cached solve of y (round-2 advisor finding)
+            mean_other = s.condition_mean(3.0 * y + 1.0, xt)
             # a second evaluation (the optimiser step) re-assembles and re-factors in place
             ll2 = s.log_probability(y, kernel=1.1 * _kernels(kernels))
         else:
-            ll2 = None
+            ll2 = mean_other = None
         # host order of the schedule: the broadcast of panel k+1 must be ENQUEUED between
         # after_recv(k) and rest(k) -- i.e. panel k+1 is packed before rest(k) is issued
         calls = ops.calls
         for k in range(s.nblk - 1):
             if (k + 1) % world == rank:
                 assert calls.index(("after_recv", k)) < calls.index(("panel", k + 1)) < calls.index(("rest", k))
-        q.put((rank, ll, s.info, mean, ll2, s.bytes_received))
+        q.put((rank, ll, s.info, mean, ll2, s.bytes_received, mean_other))
     finally:
         dist.destroy_process_group()
 
@@ -81,10 +83,12 @@ def test_block_cyclic_log_probability_and_condition_mean_match_oracle(world, n, 
     out = _run(world, n, nb, m_test=37)
     nblk = -(-n // nb)
     npad = nblk * nb
-    for rank, ll, info, mean, ll2, nbytes in out:  # every rank ends with the same results
+    want_other = gp.predict(3.0 * y + 1.0, xt)
+    for rank, ll, info, mean, ll2, nbytes, mean_other in out:  # every rank ends with the same results
         assert info == 0
         np.testing.assert_allclose(ll, want, rtol=1e-9)
         np.testing.assert_allclose(mean, want_mean, rtol=5e-7, atol=5e-7)
+        np.testing.assert_allclose(mean_other, want_other, rtol=5e-7, atol=5e-7)
         np.testing.assert_allclose(ll2, want2, rtol=1e-9)
         # broadcast volume: every panel this rank does not own, rows x nb (+ dinv)
         expect = sum(((npad - k * nb) * nb + (nb // 128) * 2048) * 8 for k in range(nblk) if k % world != rank)

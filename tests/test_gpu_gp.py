@@ -420,6 +420,35 @@ def test_multi_stream_schedule_is_deterministic(n, reps):
     assert np.array_equal(L1, np.array(solver.scale_tril))
 
 
+@pytest.mark.parametrize("lookahead", [0, 1])
+@pytest.mark.parametrize("fused_step", [0, 1])
+def test_potf2_stress_n3000(lookahead, fused_step):
+    """The setting that exposed round 2's timing-ordered diagonal block (12 wrong factorisations in 25 000 for a
+    sibling build, profiles/r02_u): N = 3 000, 2 000 fused evaluations per look-ahead mode, through the
+    stand-alone potf2 kernel and through the fused panel step's copy of the same body -- every result
+    bit-identical to the first.  (The order itself is proved on the host: tests/test_potf2_lds.py; the
+    10^5-evaluation runs are in profiles/r03_a.)"""
+    from tinygp_amd import _ffi
+
+    n, reps = 3000, 2000 if fused_step == 0 else 600
+    ctx = _ffi.default_ctx()
+    old = {"lookahead": ctx.set_option("lookahead", lookahead), "fused_step": ctx.set_option("fused_step", fused_step)}
+    try:
+        X, y = _cases.synthetic.make_inputs(n, 1)
+        ks = [1.5**2 * kernels.ExpSquared(2.5), 1.4**2 * kernels.ExpSquared(2.2)]
+        solver = DirectSolver(ks[0], X, noise.Diagonal(np.full(n, 0.01)))
+        solver.set_residual(y)
+        ref = [solver.factor_log_probability(None, k) for k in ks]
+        want = [float(o.GaussianProcess(kk, X, diag=0.01).log_probability(y))
+                for kk in (1.5**2 * o.ExpSquared(2.5), 1.4**2 * o.ExpSquared(2.2))]
+        np.testing.assert_allclose(ref, want, rtol=LL_RTOL)
+        bad = [r for r in range(reps) if solver.factor_log_probability(None, ks[r % 2]) != ref[r % 2]]
+        assert not bad, (len(bad), bad[:5])
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
+
+
 def _factor_property_checks(gp, X, k, diag, seed):
     """Size-independent properties: (i) L^-T L^-1 (K z) == z with K z from the fused
     kernel mat-vec, which never touches the factor; (ii) L^-1 (L z) == z."""

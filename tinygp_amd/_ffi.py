@@ -115,6 +115,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 3  # TGP_ABI_VERSION of include/tgp_hip.h
+
+
 def load_library(path: Path | None = None) -> C.CDLL:
     """dlopen the library and attach signatures.  Needs no GPU (used by the ABI test)."""
     path = library_path() if path is None else Path(path)
@@ -130,6 +133,10 @@ def load_library(path: Path | None = None) -> C.CDLL:
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name == "tgp_last_error"
                       else C.c_int64 if name == "tgp_dist_slot_elems" else C.c_int)
+    got = lib_.tgp_abi_version()
+    if got != ABI_VERSION:  # a stale libtgp_hip.so would mis-parse re-ordered arguments silently
+        raise TgpError(f"{path} has ABI version {got}, this binding needs {ABI_VERSION}: rebuild it "
+                       "(`make -C tinygp_amd/csrc`)")
     return lib_
 
 

@@ -241,7 +241,6 @@ int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* ol
   else if (!strcmp(key, "fused_step")) slot = &ctx->fused_step;
   else if (!strcmp(key, "chain_reserve")) slot = &ctx->chain_reserve;
   else if (!strcmp(key, "gate_split")) slot = &ctx->gate_split;
-  else if (!strcmp(key, "potf2_sync")) slot = &ctx->potf2_sync;
   else if (!strcmp(key, "reserve_max_tiles")) slot = &ctx->reserve_max_tiles;
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)

@@ -96,11 +96,11 @@ __device__ __forceinline__ float readlane(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// LDS image: only the 36 lower 16x16 blocks, each contiguous and column-major
-// (element (r, c) of block (i, j) at blk(i, j) * 256 + c * 16 + r).  72 KiB: small
-// enough to share a CU with one 74 KiB GEMM workgroup during look-ahead, and a 32-lane
-// operand read (16 rows x 2 k) is 256 contiguous bytes: conflict-free without padding.
-__device__ __forceinline__ constexpr int blk(int i, int j) { return (i * (i + 1) / 2 + j) * 256; }
+// LDS image of the tile: blk(i, j) (potf2_layout.h, shared with the host replay of potf2_body.inc)
+#define TGP_HD __device__ __forceinline__
+#include "potf2_layout.h"
+// keeps a lane-derived value opaque to the optimiser (predicates are recomputed, not hoisted)
+#define TGP_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 
 #ifdef TGP_POTF2_STAMPS
 __device__ long long g_potf2_stamps[64];
@@ -111,22 +111,7 @@ __device__ long long g_potf2_stamps[64];
 
 // waves_per_eu(4): at most 128 VGPRs, so that two potf2 waves fit on a SIMD beside one wave of the
 // trailing-update GEMM (<= 251 VGPRs) -- otherwise potf2 waits for the whole update to drain.
-// four LDS flags of the SYNC variant (a __shared__ array cannot have length zero)
-template <bool SYNC> struct ElimFlags {
-  static __device__ __forceinline__ int* get() {
-    __shared__ int f[4];
-    return f;
-  }
-};
-template <> struct ElimFlags<false> {
-  static __device__ __forceinline__ int* get() { return nullptr; }
-};
-
-// SYNC (context option potf2_sync, default 0): the read / write-back order of the diagonal block between
-// the eliminating waves is enforced with LDS flags instead of left to timing -- see potf2_body.inc.  The
-// SYNC = false instantiation is instruction for instruction the kernel of the start of round 2's second
-// session (checked with a diff of the ISA); the other one is staged for the next round's stress test.
-template <typename T, bool FOLD, bool SYNC>
+template <typename T, bool FOLD>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void potf2_kernel(T* __restrict__ A, int64_t ld,
                                                     T* __restrict__ dinv,
                                                     int32_t* __restrict__ info,
@@ -134,10 +119,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                     const T* __restrict__ Xp, int64_t ldx) {
   __shared__ __attribute__((aligned(16))) T S[36 * 256];
   __shared__ T Rs[2 * 16];                                 // 1 / L_ii of the current / previous block
-  int* Fl = ElimFlags<SYNC>::get();  // (no LDS at all in the default instantiation)
-  if constexpr (SYNC) {
-    if (threadIdx.x < 4) Fl[threadIdx.x] = 0;
-  }
+  __shared__ T Dg[256];  // copy of the current diagonal 16 x 16 block for the eliminating waves of group >= 1
 #include "potf2_body.inc"
 }
 
@@ -350,12 +332,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const T* __restrict__ Xp, int has_p, uint32_t* __restrict__ flag, uint32_t epoch) {
   __shared__ __attribute__((aligned(16))) T S[36 * 256];
   __shared__ T Rs[2 * 16];
+  __shared__ T Dg[256];
   const int b = __builtin_amdgcn_readfirstlane(blockIdx.x);
   if (b < has_p) {
     {
       const int64_t ldx = ld;
-      constexpr bool SYNC = false;
-      int* Fl = nullptr;
 #include "potf2_body.inc"
     }
     // publish: every wave's stores have left it -> barrier -> one agent-scope release -> flag
@@ -927,19 +908,10 @@ int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_
     trace_push(ctx, 1, st, trace_off(ctx, A), trace_off(ctx, Xp), ld);
     return TGP_OK;
   }
-  if (ctx->potf2_sync != 0) {
-    if (Xp != nullptr)
-      hipLaunchKernelGGL((potf2_kernel<T, true, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                         pivot_base, Xp, ldx);
-    else
-      hipLaunchKernelGGL((potf2_kernel<T, false, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                         pivot_base, Xp, ldx);
-  } else if (Xp != nullptr)
-    hipLaunchKernelGGL((potf2_kernel<T, true, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                       pivot_base, Xp, ldx);
+  if (Xp != nullptr)
+    hipLaunchKernelGGL((potf2_kernel<T, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info, pivot_base, Xp, ldx);
   else
-    hipLaunchKernelGGL((potf2_kernel<T, false, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info,
-                       pivot_base, Xp, ldx);
+    hipLaunchKernelGGL((potf2_kernel<T, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info, pivot_base, Xp, ldx);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }

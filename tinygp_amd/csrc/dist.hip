@@ -10,7 +10,7 @@
 //
 // Step k.  The owner factors panel k in place with the single-GPU panel chain (chol.hip,
 // potf2 / trsm / in-panel updates on the priority stream) and PACKS it -- [dinv of its 128-
-// blocks | rows k*nb.. x nb, ld = rows] -- into ring slot k mod 2.  The host (Python,
+// blocks | rows k*nb.. x nb, ld = rows] -- into ring slot k mod 3.  The host (Python,
 // tinygp_amd/distributed.py) broadcasts that slot with RCCL.  Every rank then
 //   * runs forward-substitution step k of the (replicated) right-hand side straight from the
 //     received panel on the solve stream -- log_probability needs no further exchange,

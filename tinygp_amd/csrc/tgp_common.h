@@ -111,7 +111,6 @@ struct tgp_ctx {
   // the block-column update between two chains (the `gate`) is issued column block 0 | 1 | 2..: the chain starts
   // behind the first piece and meets the others at its second and third block (fused panel step only)
   int64_t gate_split = 1;
-  int64_t potf2_sync = 0;  // potf2 with the diagonal block's read / write-back order enforced by LDS flags (staged, untested)
   int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
   uint32_t* d_step_flag = nullptr;  // the flag potf2's workgroup publishes; value = step_epoch of the launch
   uint32_t step_epoch = 0;

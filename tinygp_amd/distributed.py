@@ -214,6 +214,7 @@ class BlockCyclicCholesky:
         ops.setup(P, diag, nb, self.G, self.rank)
         self.info = 0
         self.factored = self.solved = self.have_alpha = False
+        self._resid = None
         self.bytes_received = 0  # panel bytes this rank received in the last factorisation
         # A process group of one still sends its panels through the collective (the same code path as
         # with peers; 30.9 vs 30.8 ms at N = 16 384 since the driver keeps to three streams of its own
@@ -270,6 +271,7 @@ class BlockCyclicCholesky:
         v = float(t.item())
         self.info = 0 if v >= 2**52 else int(v)
         self.factored, self.solved, self.have_alpha = True, resid is not None, False
+        self._resid = None if r is None else r.copy()  # the right-hand side the cached solves belong to
         return self.info
 
     def log_probability(self, resid, kernel=None) -> float:
@@ -286,8 +288,11 @@ class BlockCyclicCholesky:
         """``K^-1 resid`` replicated on every rank (reference gp.py:330-334): the forward solve
         rode along with the factorisation; the backward substitution walks the block columns
         from the last to the first, the owner solves its ``nb`` slice and broadcasts it."""
-        if not (self.factored and self.solved):
-            self.factor(resid)
+        r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
+        # the forward solve rides in the factorisation, so a DIFFERENT right-hand side means another pass
+        # (x holds L^-1 r_old, or K^-1 r_old after the backward substitution -- never reuse those)
+        if not (self.factored and self.solved and self._resid is not None and np.array_equal(self._resid, r)):
+            self.factor(r)
         if not self.have_alpha:
             ops = self.ops
             for k in reversed(range(self.nblk)):

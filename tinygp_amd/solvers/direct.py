@@ -94,7 +94,8 @@ class DirectSolver(Solver):
         kernels), so that neither off-diagonal noise nor a stale matrix is ever factored."""
         if kernel is None:
             return
-        self.kernel = kernel
+        # validate first, commit kernel / program / host matrix together: a ValueError must leave the
+        # solver exactly as it was (round-2 advisor finding)
         try:
             prog, Xdev = kernel._lower(self.X)
             if not np.array_equal(_device.points(Xdev, self.dtype), self._P):
@@ -102,12 +103,11 @@ class DirectSolver(Solver):
                                  "transformed coordinates are resident on the device")
         except NotImplementedError:
             prog = None
-        self._prog = prog
         if prog is not None and isinstance(self.noise, Diagonal):
-            self._covariance_value = None
+            cov = None
         else:
-            self._covariance_value = np.ascontiguousarray(kernel(self.X, self.X) + self.noise,
-                                                          dtype=self.dtype)
+            cov = np.ascontiguousarray(kernel(self.X, self.X) + self.noise, dtype=self.dtype)
+        self.kernel, self._prog, self._covariance_value = kernel, prog, cov
 
     def refactor(self, kernel=None, *, covariance=None) -> int:
         """(Re-)assemble and (re-)factor in place with new hyper-parameters (same X / noise):
@@ -253,10 +253,13 @@ class DirectSolver(Solver):
         A = self.solve_triangular(np.asarray(kernel(self.X, Xt), dtype=self.dtype))
         if var_only:
             out = np.asarray(kernel(Xt), dtype=self.dtype) - np.sum(A * A, axis=0)
-            return out if noise_diag is None else out + noise_diag
-        out = np.asarray(kernel(Xt, Xt), dtype=self.dtype) - A.T @ A
-        if noise_diag is not None:
-            out[np.diag_indices(out.shape[0])] += noise_diag
+            out = out if noise_diag is None else out + noise_diag
+        else:
+            out = np.asarray(kernel(Xt, Xt), dtype=self.dtype) - A.T @ A
+            if noise_diag is not None:
+                out[np.diag_indices(out.shape[0])] += noise_diag
+        if self.info:  # a failed factorisation poisons every result, as on the device path (gp.py:316)
+            out = np.full_like(out, np.nan)
         return out
 
     def _cond(self, kernel, X_test, noise_diag, var_only: bool):
