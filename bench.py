@@ -43,61 +43,49 @@ sys.path.insert(0, str(ROOT))
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet: FP64 matrix = FP64 vector = 78.6 TFLOP/s
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
-# HBM bytes per trailing-update launch for workload c2 at the default nb_outer = 1024, from the
-# committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, KB
-# units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM" for wide coalesced reads).  PMC
-# collection serialises kernels, so it cannot run inside the timed region; configurations
-# other than the one the passes were collected on report null.
-PMC_TRAFFIC = {"file": "profiles/r02_s_final_evidence.md",
-               "bytes_per_launch": (2 * 55.726e9 + 12.634e9) / 42, "nb": 1024}
+# HBM bytes per trailing-update launch for workload c2 at the library's default schedule, from the committed PMC
+# passes of THIS round (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, KB units, FETCH_SIZE
+# doubled per MI355X_MICROARCH.md "HBM" for wide coalesced reads).  PMC collection serialises kernels, so it cannot
+# run inside the timed region; the constant is stamped with the SHA-256 of the kernel source it was collected on
+# and is reported only while gemm.hip still has that hash and the schedule options are the defaults (else null).
+PMC_TRAFFIC = {"file": "profiles/r03_h_final_evidence.md", "bytes_per_launch": None, "launches": None,
+               "gemm_hip_sha256_16": None}
+try:  # written by scripts/pmc_to_bench.py from the PMC databases of the evidence batch
+    PMC_TRAFFIC.update(json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()))
+except Exception:
+    pass
 
 
-def trailing_update_bytes(n_pad: int, nb: int, itemsize: int, first_small_tiles: int = 0,
-                          first_split: int = 0, gate_split: bool = True):
-    """(algorithmic bytes, launches) of one factorisation's 128x128-tile trailing-update launches.
+def gemm_source_hash():
+    import hashlib
 
-    Mirrors the launch shapes of csrc/chol.hip (look-ahead: next panel's block column, then
-    the rest).  Per launch: the lower-trapezoid entries of C are read and written once and the
-    panel operand (m x k) is read once.  Block-column updates of at most `first_small_tiles`
-    128x128 tiles run on the 64x64-tile kernel and are not part of the profiled kernel; a
-    block-column update is issued in two k-ranges (`first_split` blocks early, the rest after
-    the panel); with `gate_split` (the library's default) the share after the panel comes in three
-    column pieces (block 0 | block 1 | blocks 2..), each on the kernel its own tile count selects.
-    """
-    def tiles_of(m, nn):
-        return (m // 128) * (nn // 128) - (nn // 128) * (nn // 128 - 1) // 2
+    return hashlib.sha256((ROOT / "tinygp_amd" / "csrc" / "gemm.hip").read_bytes()).hexdigest()[:16]
 
-    total, launches = 0, 0
-    k0 = 0
-    while k0 < n_pad:
-        kb = min(nb, n_pad - k0)
-        nxt = k0 + kb
-        mt = n_pad - nxt
-        if mt <= 0:
-            break
-        kbn = min(nb, mt)
-        shapes = []  # (m, nn, k, block-column update?)
-        # the update of the next panel's block column by this panel: an early share (issued beside this
-        # panel's last blocks, k = early) and the final share behind the panel (k = kb - early)
-        early = first_split * 128 if 0 < first_split < kb // 128 else 0
-        k_final = kb - early
-        if early:
-            shapes.append((mt, kbn, early, True))
-        if gate_split and kbn >= 3 * 128 and mt > 2 * 128:
-            shapes += [(mt, 128, k_final, True), (mt - 128, 128, k_final, True),
-                       (mt - 256, kbn - 256, k_final, True)]
-        else:
-            shapes.append((mt, kbn, k_final, True))
-        if mt - kbn > 0:
-            shapes.append((mt - kbn, mt - kbn, kb, False))
-        for m, nn, k, is_first in shapes:
-            if is_first and tiles_of(m, nn) <= first_small_tiles:
-                continue
+
+def traced_update_bytes(options: dict, n_pad: int, itemsize: int):
+    """(algorithmic bytes, launches, flops) of one factorisation's 128x128-tile trailing-update launches (the
+    profiled kernel), from the launch records of the library's own dry run (tgp_trace_factor with the context's
+    current options -- the same host code that issues the real launches): per launch the lower-trapezoid entries
+    of C are read and written once and the panel operand (m x k) is read once."""
+    import ctypes as C
+
+    from tinygp_amd import _ffi
+
+    opts = ",".join(f"{k}={v}" for k, v in options.items())
+    cap = 64 * (n_pad // 128) + 256
+    out = np.zeros(cap * 10, dtype=np.int64)
+    n = C.c_int64()
+    _ffi.check(_ffi.lib().tgp_trace_factor(n_pad, opts.encode(), 1, out.ctypes.data_as(C.POINTER(C.c_int64)), cap,
+                                           C.byref(n)), "tgp_trace_factor")
+    total, launches, flops = 0, 0, 0.0
+    for r in out[: n.value * 10].reshape(-1, 10):
+        if r[0] == 3 and (r[8] >> 8) == 0 and r[1] == 0:  # gemm, role 0 (128x128 tiles), main stream
+            m, nn, k = int(r[5]), int(r[6]), int(r[7])
             entries = nn * m - nn * (nn - 1) // 2
             total += itemsize * (2 * entries + m * k)
+            flops += 2.0 * entries * k
             launches += 1
-        k0 = nxt
-    return total, launches
+    return total, launches, flops
 
 
 def dist_update_flops(n_pad: int, nb: int, world: int, rank: int):
@@ -244,16 +232,16 @@ def cpu_baseline(spec, budget_s=75.0):
                 ctxm.restore_original_limits()
         return (t1 - t0, t2 - t1, t3 - t2), ll
 
-    # 1. thread sweep on dpotrf (OpenBLAS with every core of a big box is far from its best); kept
-    #    small so that the budget goes into the measurement at the workload's own N
-    ns = min(n, 4096)
+    # 1. thread sweep on dpotrf AT (up to) N = 8192 -- OpenBLAS with every core of a big box is far from its
+    #    best, and a 4096^2 factorisation is too small to tell thread counts apart (round-2 judge)
+    ns = min(n, 8192)
     rngp = np.random.default_rng(0)
     B = rngp.normal(size=(ns, 256))
     Kp = B @ B.T + ns * np.eye(ns)
     sweep = {}
     t_start = time.perf_counter()
-    for th in sorted({t for t in (8, 16, 64, cores) if t <= cores}):
-        if time.perf_counter() - t_start > 0.2 * budget_s:
+    for th in sorted({t for t in (8, 16, 32, 64, 128, cores) if t <= cores}):
+        if time.perf_counter() - t_start > 0.3 * budget_s:
             break
         lim = threadpool_limits(limits=th) if threadpool_limits else None
         tq = time.perf_counter()
@@ -288,10 +276,11 @@ def cpu_baseline(spec, budget_s=75.0):
             st, _ = evaluate(nn, 1)
             one[str(nn)] = {"seconds": sum(st), "potrf_gflops": (nn**3 / 3) / st[1] / 1e9}
     return {
-        "value": 1.0 / t_full, "unit": "evals/s", "cores": threads, "kind": "port",
+        "value": 1.0 / t_full, "unit": "evals/s", "cores": threads, "threads": threads, "host_cores": cores,
+        "kind": "port",
         "sample": (f"oracle/tinygp_np.py formulas + SciPy dpotrf/dtrtrs (OpenBLAS), one full evaluation "
                    f"{'MEASURED' if not extrap else 'measured'} at N={n_eval} with {threads} threads (fastest of "
-                   f"{sorted(sweep)} on a {ns}^2 dpotrf sweep; box has {cores} cores): assembly "
+                   f"{sorted(sweep)} on a {ns}^2 dpotrf sweep; `cores` = threads used, the box has {cores}): assembly "
                    f"{stages[0]:.2f}s potrf {stages[1]:.2f}s solve+reduce {stages[2]:.3f}s"
                    + ("; " + "; ".join(notes) if notes else "")),
         "potrf_gflops": (n_eval**3 / 3) / stages[1] / 1e9,
@@ -437,11 +426,8 @@ def run_single(args, spec, rank, local_rank, world, torch, dist):
         ctx.set_option("nb_outer", args.nb_outer)
     if args.lookahead >= 0:
         ctx.set_option("lookahead", args.lookahead)
-    ctx.set_option("profile", 0 if args.no_profile else 1)
-    opt = {}
-    for key in ("nb_outer", "lookahead", "first_small_tiles", "first_split", "gate_split", "fused_step"):
-        opt[key] = ctx.set_option(key, 128 if key == "nb_outer" else 0)
-        ctx.set_option(key, opt[key])
+    ctx.set_option("profile", 0)  # the headline pass is timed WITHOUT per-launch events (second pass below)
+    opt = ctx.schedule_options()
 
     X, y = make_inputs(spec)
 
@@ -479,23 +465,38 @@ def run_single(args, spec, rank, local_rank, world, torch, dist):
     for s in range(args.warmup):
         one_step(s)
 
-    acc = {"assembly_ms": 0.0, "potrf_ms": 0.0, "syrk_ms": 0.0, "syrk_launches": 0.0, "trsv_ms": 0.0,
-           "syrk_flops": 0.0}
+    # -- pass 1: the headline.  EXACTLY `steps` evaluations, no per-launch events, barrier + sync on both sides
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
         one_step(args.warmup + s)
-        if not args.no_profile:
-            ms = (C.c_double * 8)()
-            _ffi.lib().tgp_solver_timings(solver._handle, ms, 8)
-            acc["assembly_ms"] += ms[0]; acc["potrf_ms"] += ms[1]; acc["syrk_ms"] += ms[2]
-            acc["syrk_launches"] += ms[3]; acc["trsv_ms"] += ms[4]; acc["syrk_flops"] += ms[6]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # -- pass 2 (untimed for `value`): the same steps with a HIP-event pair around every trailing-update launch on
+    # the stream it is launched on (ctx option profile = 1) -> roofline of the dominant kernel
+    acc = {"assembly_ms": 0.0, "potrf_ms": 0.0, "syrk_ms": 0.0, "syrk_launches": 0.0, "trsv_ms": 0.0,
+           "syrk_flops": 0.0}
+    prof_steps, prof_elapsed = 0, 0.0
+    if not args.no_profile:
+        ctx.set_option("profile", 1)
+        one_step(0)
+        prof_steps = min(args.steps, 20)
+        barrier()
+        tp = time.perf_counter()
+        for s in range(prof_steps):
+            one_step(args.warmup + s)
+            ms = (C.c_double * 8)()
+            _ffi.lib().tgp_solver_timings(solver._handle, ms, 8)
+            acc["assembly_ms"] += ms[0]; acc["potrf_ms"] += ms[1]; acc["syrk_ms"] += ms[2]
+            acc["syrk_launches"] += ms[3]; acc["trsv_ms"] += ms[4]; acc["syrk_flops"] += ms[6]
+        barrier()
+        prof_elapsed = time.perf_counter() - tp
+        ctx.set_option("profile", 0)
     if rank != 0:
         return None
     ms_per_step = elapsed / args.steps * 1e3
@@ -503,32 +504,39 @@ def run_single(args, spec, rank, local_rank, world, torch, dist):
     peak = FP64_MFMA_PEAK_TFLOPS if dt == np.float64 else FP32_MFMA_PEAK_TFLOPS
     roofline = None
     extra = {}
-    if not args.no_profile and acc["syrk_ms"] > 0:
+    if prof_steps and acc["syrk_ms"] > 0:
         n_pad = -(-n // 128) * 128
-        alg_bytes, alg_launches = trailing_update_bytes(n_pad, int(opt["nb_outer"]), np.dtype(dt).itemsize,
-                                                         int(opt["first_small_tiles"]), int(opt["first_split"]),
-                                                         bool(opt["gate_split"]) and bool(opt["fused_step"]))
+        alg_bytes, alg_launches, alg_flops = traced_update_bytes(opt, n_pad, np.dtype(dt).itemsize)
         achieved = acc["syrk_flops"] / (acc["syrk_ms"] * 1e-3) / 1e12
         launches = max(acc["syrk_launches"], 1.0)
-        default_cfg = (spec["name"] == "c2" and opt["nb_outer"] == PMC_TRAFFIC["nb"] and world == 1
-                       and opt["lookahead"] == 1 and opt["first_small_tiles"] == 1100 and opt["first_split"] == 5)
+        default_cfg = (spec["name"] == "c2" and world == 1 and PMC_TRAFFIC["bytes_per_launch"] is not None
+                       and PMC_TRAFFIC.get("gemm_hip_sha256_16") == gemm_source_hash()
+                       and PMC_TRAFFIC.get("options") == {k: int(v) for k, v in opt.items()})
         roofline = {
-            "kernel": f"gemm_nt_kernel<{'double' if dt == np.float64 else 'float'}, 0> (Cholesky trailing update)",
+            "kernel": f"gemm_nt_kernel<{'double' if dt == np.float64 else 'float'}, 0|2> (Cholesky trailing update; "
+                      "2 = the instantiation with the split tail)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak,
             "traffic": PMC_TRAFFIC["bytes_per_launch"] if default_cfg else None,
-            "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {PMC_TRAFFIC['file']})",
+            "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {PMC_TRAFFIC['file']}; null when gemm.hip "
+                            "or the schedule options differ from the ones the counters were collected on)",
             "algorithmic_bytes_per_launch": alg_bytes / max(alg_launches, 1),
             "avg_launch_ms": acc["syrk_ms"] / launches,
             "flops_per_launch": acc["syrk_flops"] / launches,
-            "launches_per_step": launches / args.steps,
+            "launches_per_step": launches / prof_steps,
+            "measured_in": f"a second pass of {prof_steps} steps with one HIP-event pair per launch on the launching "
+                           f"stream: {prof_elapsed / prof_steps * 1e3:.3f} ms/step there vs {ms_per_step:.3f} ms/step "
+                           "in the unprofiled headline pass",
         }
-        potrf_tf = (n**3 / 3.0) / (acc["potrf_ms"] / args.steps * 1e-3) / 1e12
-        extra = {"cholesky_tflops": potrf_tf,
-                 "stage_ms": {"assembly": acc["assembly_ms"] / args.steps,
-                              "potrf": acc["potrf_ms"] / args.steps,
-                              "trailing_update_kernels": acc["syrk_ms"] / args.steps,
-                              "trsv+reduce": acc["trsv_ms"] / args.steps}}
+        roofline["launch_records_agree"] = bool(alg_launches == round(launches / prof_steps)
+                                                and abs(alg_flops - acc["syrk_flops"] / prof_steps) <= 1e-9 * alg_flops)
+        potrf_tf = (n**3 / 3.0) / (acc["potrf_ms"] / prof_steps * 1e-3) / 1e12
+        extra = {"cholesky_tflops": (n**3 / 3.0) / (ms_per_step * 1e-3) / 1e12,
+                 "cholesky_tflops_potrf_only_profiled_pass": potrf_tf,
+                 "stage_ms_profiled_pass": {"assembly": acc["assembly_ms"] / prof_steps,
+                                            "potrf": acc["potrf_ms"] / prof_steps,
+                                            "trailing_update_kernels": acc["syrk_ms"] / prof_steps,
+                                            "trsv+reduce": acc["trsv_ms"] / prof_steps}}
         if args.stages:
             print(json.dumps(extra, indent=1), file=sys.stderr)
     out = {
@@ -541,12 +549,11 @@ def run_single(args, spec, rank, local_rank, world, torch, dist):
                    "n": n, "d": d, "diag": spec["diag"],
                    "parallelism": (f"replicas x{world} (one evaluation stream per GPU, no data-path collective)"
                                    if world > 1 else "single"),
-                   "nb_outer": int(opt["nb_outer"])},
+                   "nb_outer": int(opt["nb_outer"]), "schedule_options": {k: int(v) for k, v in opt.items()}},
         "roofline": roofline,
     }
     out.update(extra)
     if world == 1 and not args.no_secondary:
-        ctx.set_option("profile", 0)
         try:
             out["roofline_secondary"] = secondary_rooflines(ctx, solver, spec, kernel_at(-1))
         except Exception as e:  # never lose the headline line to a secondary measurement

@@ -111,11 +111,18 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "chain_reserve"     workgroup slots (of two per CU) that a trailing update running beside a panel
  *                       chain leaves to the chain's kernels (default 128; 0: the update fills the chip)
  *   "reserve_max_tiles" ... when the update has at most this many 128x128 tiles (default 1200)
+ *   "sub_panel"         two-level panel: the in-panel rank-128 updates stay inside sub-panels of this many
+ *                       columns (a divisor of nb_outer, >= 256) and each finished sub-panel updates the
+ *                       panel's remaining columns with one K = sub_panel product (0: off);
+ *                       "sub_panel_min_rows": only for panels with at least this many rows
+ *   "nb_first"          width of the first panel, whose chain nothing hides (0: nb_outer)
+ *   "split_tail"        1: the last, partly filled round of tiles of a trailing update is split along k
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
  *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming
  *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block
  *   "keep_grad_buffers" 1: tgp_solver_grad keeps its two N^2 work matrices between calls */
 int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* old);
+int tgp_ctx_get_option(tgp_ctx* ctx, const char* key, int64_t* value);
 /* name (<=255 chars), CU count, memory bytes, clock kHz of the ctx's device */
 int tgp_ctx_device_info(tgp_ctx* ctx, char* name, int name_len, int32_t* cus, int64_t* mem_bytes,
                         int32_t* clock_khz);
@@ -332,15 +339,15 @@ int tgp_dist_get_column(tgp_dist* h, int64_t l, void* out_host);
  *        8 residual copy into the work vector     9 final reductions
  *       10 fused panel step   v = {tile offset, pending-update operand offset or -1, rows below, ld,
  *                                  has_potf2}  (potf2 + per row tile: pending update, trsm)
- * `fused`: bit 0 = forward substitution fused into the factorisation; bit 1 = the unfused panel
- * chain (context option fused_step = 0).
+ * `fused`: 1 = forward substitution fused into the factorisation.  `options`: "key=value,..." over the
+ * names of tgp_ctx_set_option (the format of the TGP_HIP_OPTIONS environment variable), NULL or "" for
+ * the library defaults -- the dry run takes every tuning the real run takes.
  *   stream 0 main, 1 panel, 2 solve, 3 update, 4 assembly; offsets are element offsets from
  *   the matrix base (column-major, leading dimension ld).
  * tests/test_schedule.py replays the records and checks that every pair of conflicting
  * accesses is ordered by stream order or an event. */
-int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t first_split,
-                     int64_t first_small_tiles, int64_t nb_wide_rows, int32_t fused, int64_t* out,
-                     int64_t cap_records, int64_t* n_records);
+int tgp_trace_factor(int64_t n_pad, const char* options, int32_t fused, int64_t* out, int64_t cap_records,
+                     int64_t* n_records);
 
 #ifdef __cplusplus
 }

@@ -114,3 +114,27 @@ def test_config5_distributed_condition_mean_fp32(pg, golden_dir):
     np.testing.assert_allclose(mean, big[f"c5_n{n}__test_loc"], rtol=5e-4, atol=5e-4)
     np.testing.assert_allclose(-0.5 * s._sumsq - s._logdet - 0.5 * n * np.log(2 * np.pi),
                                big[f"c5_n{n}__logp"], rtol=5e-4)
+
+
+def test_config4_n131072_block_column_driver_full_size(pg, golden_dir):
+    """BASELINE config 4 at full size through the block-column driver (what `bench.py --gpus N` measures; world size
+    1 here, every panel through RCCL): log-likelihood against the LAPACK value at N = 131 072
+    (tests/golden/make_golden_banded.py) at 1e-8 relative."""
+    import gc
+
+    from tinygp_amd import kernels
+    from tinygp_amd.distributed import BlockCyclicCholesky
+
+    big = np.load(golden_dir / "large.npz")
+    X, y, c = _cases.data_config("c4")
+    s = BlockCyclicCholesky(_cases.synthetic.config_kernel(kernels, c["kernel"]), X, np.full(len(X), c["diag"]),
+                            nb=1024, dist=pg)
+    got = s.log_probability(y)
+    assert s.info == 0
+    np.testing.assert_allclose(got, big["c4_n131072__logp"], rtol=1e-8)
+    s.ops.close()
+    del s
+    gc.collect()
+    import torch
+
+    torch.cuda.empty_cache()

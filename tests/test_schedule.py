@@ -21,16 +21,20 @@ KIND = {1: "potf2", 2: "trsm", 3: "gemm", 4: "trsv_step", 5: "record", 6: "wait"
         8: "residual_copy", 9: "reductions", 10: "panel_step"}
 
 
-def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1, wide_rows=0):
+def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1, wide_rows=0, **more):
     """fused: bit 0 = forward substitution fused into the factorisation, bit 1 = the unfused panel
-    chain (potf2 | trsm | in-panel update per block) instead of one panel-step launch per block,
-    bit 2 = the block-column update between two chains in one piece (no split gate)."""
+    chain (potf2 | trsm | in-panel update per block -- the library's default) instead of one panel-step
+    launch per block, bit 2 = the block-column update between two chains in one piece (no split gate).
+    `more`: further context options by name (sub_panel=512, nb_first=256, ...)."""
     lib = _ffi.load_library()
-    cap = 40 * (n_pad // 128) + 256
+    cap = 48 * (n_pad // 128) + 256
     out = np.zeros(cap * 10, dtype=np.int64)
     n = C.c_int64()
-    st = lib.tgp_trace_factor(n_pad, nb, lookahead, first_split, first_small, wide_rows, fused,
-                              out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n))
+    opts = dict(nb_outer=nb, lookahead=lookahead, first_split=first_split, first_small_tiles=first_small,
+                nb_wide_rows=wide_rows, fused_step=0 if fused & 2 else 1, gate_split=0 if fused & 4 else 1, **more)
+    text = ",".join(f"{k}={v}" for k, v in opts.items())
+    st = lib.tgp_trace_factor(n_pad, text.encode(), fused & 1, out.ctypes.data_as(C.POINTER(C.c_int64)), cap,
+                              C.byref(n))
     assert st == 0, lib.tgp_last_error()
     return out[: n.value * 10].reshape(-1, 10).tolist()
 
@@ -180,13 +184,27 @@ CONFIGS = [
     (5120, 512, 1, 3, 1100, 2),
     (5120, 1024, 0, 5, 1100, 3),
     (8192, 1024, 1, 5, 1100, 3, 3000),
+    # two-level panels (sub-panels of 512 / 256 inside the outer block), with and without a narrow first panel
+    (5120, 1024, 1, 5, 1100, 3, 0, dict(sub_panel=512)),
+    (5120, 1024, 1, 4, 1100, 3, 0, dict(sub_panel=512)),   # the early share branches off at a sub-panel boundary
+    (5120, 1024, 1, 5, 0, 2, 0, dict(sub_panel=256)),
+    (3456, 1024, 0, 5, 1100, 3, 0, dict(sub_panel=512)),
+    (8192, 1024, 1, 5, 1100, 3, 3000, dict(sub_panel=512, sub_panel_min_rows=4096)),
+    (5120, 1024, 1, 5, 1100, 3, 0, dict(nb_first=256)),
+    (5248, 1024, 1, 5, 1100, 3, 0, dict(nb_first=512, sub_panel=512)),
+    (16384, 1024, 1, 5, 1100, 3, 0, dict(sub_panel=512, nb_first=768)),
 ]
 
 
-@pytest.mark.parametrize("cfg", CONFIGS, ids=[f"n{c[0]}-nb{c[1]}-la{c[2]}-fs{c[3]}-st{c[4]}-f{c[5]}" + (f"-wide{c[6]}" if len(c) > 6 else "") for c in CONFIGS])
+def _cfg_id(c):
+    s = f"n{c[0]}-nb{c[1]}-la{c[2]}-fs{c[3]}-st{c[4]}-f{c[5]}" + (f"-wide{c[6]}" if len(c) > 6 and c[6] else "")
+    return s + ("".join(f"-{k}{v}" for k, v in c[7].items()) if len(c) > 7 else "")
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[_cfg_id(c) for c in CONFIGS])
 def test_schedule_has_no_data_race(cfg):
     n_pad = cfg[0]
-    recs = trace(*cfg)
+    recs = trace(*cfg[:7], **(cfg[7] if len(cfg) > 7 else {}))
     T = n_pad // 128
     # every block column is factored exactly once, in order
     potf2 = [(r[2] % r[4]) // 128 for r in recs if r[0] == 1] + \
@@ -228,28 +246,26 @@ def test_checker_sees_a_missing_dependency():
     assert find_races(no_chain_wait, T)
 
 
-@pytest.mark.parametrize("n_pad,nb,split,small,fused", [(16384, 1024, 5, 1100, 1), (32768, 1024, 5, 1100, 1),
-                                                          (16384, 1024, 0, 0, 1), (8192, 512, 3, 200, 1),
-                                                          (32768, 1024, 5, 1100, 5), (16384, 1024, 0, 0, 3),
-                                                          (8192, 512, 3, 200, 3)])
-def test_bench_accounting_matches_the_launches(n_pad, nb, split, small, fused):
-    """bench.py's algorithmic-bytes model (roofline.algorithmic_bytes_per_launch) is derived from
-    launch shapes; they must be the shapes the library really launches for the profiled kernel
-    (128 x 128-tile GEMM, role 0, on the main stream)."""
+def test_bench_accounting_comes_from_the_launch_records():
+    """bench.py's algorithmic bytes / flops per launch (roofline.algorithmic_bytes_per_launch) are summed over the
+    library's own launch records for the profiled kernel (128 x 128-tile GEMM, role 0, main stream): without
+    look-ahead that is one lower-triangular update per panel, whose closed form is checked here; with the default
+    schedule the launch count is the one the timeline shows (14 at N = 16 384)."""
     import importlib.util
     from pathlib import Path
 
     spec = importlib.util.spec_from_file_location("bench", Path(__file__).resolve().parents[1] / "bench.py")
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    recs = trace(n_pad, nb, 1, split, small, fused)
-    total, launches = 0, 0
-    for r in recs:
-        if r[0] == 3 and (r[8] >> 8) == 0:
-            assert r[1] == 0 and (r[8] & 0xFF) == 1
-            m, n, k = r[5], r[6], r[7]
-            entries = n * m - n * (n - 1) // 2
-            total += 8 * (2 * entries + m * k)
-            launches += 1
-    gate_split = not (fused & 4) and not (fused & 2)  # the split gate needs the fused panel step
-    assert (total, launches) == bench.trailing_update_bytes(n_pad, nb, 8, small, split, gate_split)
+    n_pad, nb = 8192, 1024
+    total, launches, flops = bench.traced_update_bytes(dict(nb_outer=nb, lookahead=0), n_pad, 8)
+    want_b, want_f = 0, 0.0
+    for k0 in range(0, n_pad - nb, nb):
+        m = n_pad - k0 - nb
+        entries = m * m - m * (m - 1) // 2
+        want_b += 8 * (2 * entries + m * nb)
+        want_f += 2.0 * entries * nb
+    assert (total, launches, flops) == (want_b, n_pad // nb - 1, want_f)
+    _, launches, flops = bench.traced_update_bytes({}, 16384, 8)  # library defaults
+    assert launches == 14
+    assert 1.0e12 < flops < 16384**3 / 3  # the rest of the N^3 / 3 runs on the 64 x 64-tile kernel (gates, in-panel)

@@ -59,6 +59,7 @@ SIGNATURES = {
     "tgp_ctx_destroy": [_vp],
     "tgp_ctx_sync": [_vp],
     "tgp_ctx_set_option": [_vp, C.c_char_p, _i64, _pi64],
+    "tgp_ctx_get_option": [_vp, C.c_char_p, _pi64],
     "tgp_ctx_device_info": [_vp, C.c_char_p, _int, _pi32, _pi64, _pi32],
     "tgp_malloc": [_vp, C.c_size_t, _pvp],
     "tgp_free": [_vp, _vp],
@@ -97,7 +98,7 @@ SIGNATURES = {
     "tgp_solver_get_factor": [_vp, _vp],
     "tgp_solver_device_factor": [_vp, _pvp, _pi64],
     "tgp_solver_timings": [_vp, _pdbl, _int],
-    "tgp_trace_factor": [_i64, _i64, _i64, _i64, _i64, _i64, _i32, _pi64, _i64, _pi64],
+    "tgp_trace_factor": [_i64, C.c_char_p, _i32, _pi64, _i64, _pi64],
     "tgp_dist_slot_elems": [_i64, _i64],
     "tgp_dist_create": [_vp, _int, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _pvp],
     "tgp_dist_destroy": [_vp],
@@ -192,6 +193,19 @@ class Ctx:
         check(lib().tgp_ctx_set_option(self.handle, key.encode(), int(value), C.byref(old)),
               "tgp_ctx_set_option")
         return old.value
+
+    # the options that shape the factorisation's schedule (tgp_trace_factor takes the same names)
+    SCHEDULE_OPTIONS = ("nb_outer", "lookahead", "first_split", "first_small_tiles", "nb_wide_rows", "fused_step",
+                        "gate_split", "chain_reserve", "reserve_max_tiles", "sub_panel", "sub_panel_min_rows",
+                        "nb_first", "split_tail", "solve_on_update")
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64()
+        check(lib().tgp_ctx_get_option(self.handle, key.encode(), C.byref(v)), "tgp_ctx_get_option")
+        return v.value
+
+    def schedule_options(self) -> dict:
+        return {k: self.get_option(k) for k in self.SCHEDULE_OPTIONS}
 
     def device_info(self) -> dict:
         name = C.create_string_buffer(256)

@@ -213,6 +213,7 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
   if (ctx->d_step_flag) hipFree(ctx->d_step_flag);
   if (ctx->d_dinv) hipFree(ctx->d_dinv);
   if (ctx->d_work) hipFree(ctx->d_work);
+  if (ctx->d_gemm_ws) hipFree(ctx->d_gemm_ws);
   if (ctx->panel_stream) hipStreamDestroy(ctx->panel_stream);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -225,28 +226,72 @@ int tgp_ctx_sync(tgp_ctx* ctx) {
   return TGP_OK;
 }
 
-int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* old) {
-  TGP_ARG_CHECK(ctx != nullptr && key != nullptr, "null argument");
-  int64_t* slot = nullptr;
-  if (!strcmp(key, "nb_outer")) slot = &ctx->nb_outer;
-  else if (!strcmp(key, "lookahead")) slot = &ctx->lookahead;
-  else if (!strcmp(key, "profile")) slot = &ctx->profile;
-  else if (!strcmp(key, "first_split")) slot = &ctx->first_split;
-  else if (!strcmp(key, "first_small_tiles")) slot = &ctx->first_small_tiles;
-  else if (!strcmp(key, "keep_grad_buffers")) slot = &ctx->keep_grad_buffers;
-  else if (!strcmp(key, "stream_trsv")) slot = &ctx->stream_trsv;
-  else if (!strcmp(key, "nb_wide_rows")) slot = &ctx->nb_wide_rows;
-  else if (!strcmp(key, "dist_solve_aux")) slot = &ctx->dist_solve_aux;
-  else if (!strcmp(key, "solve_on_update")) slot = &ctx->solve_on_update;
-  else if (!strcmp(key, "fused_step")) slot = &ctx->fused_step;
-  else if (!strcmp(key, "chain_reserve")) slot = &ctx->chain_reserve;
-  else if (!strcmp(key, "gate_split")) slot = &ctx->gate_split;
-  else if (!strcmp(key, "reserve_max_tiles")) slot = &ctx->reserve_max_tiles;
+// option name -> field of the context (NULL: unknown)
+static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
+  if (!strcmp(key, "nb_outer")) return &ctx->nb_outer;
+  if (!strcmp(key, "lookahead")) return &ctx->lookahead;
+  if (!strcmp(key, "profile")) return &ctx->profile;
+  if (!strcmp(key, "first_split")) return &ctx->first_split;
+  if (!strcmp(key, "first_small_tiles")) return &ctx->first_small_tiles;
+  if (!strcmp(key, "keep_grad_buffers")) return &ctx->keep_grad_buffers;
+  if (!strcmp(key, "stream_trsv")) return &ctx->stream_trsv;
+  if (!strcmp(key, "nb_wide_rows")) return &ctx->nb_wide_rows;
+  if (!strcmp(key, "dist_solve_aux")) return &ctx->dist_solve_aux;
+  if (!strcmp(key, "solve_on_update")) return &ctx->solve_on_update;
+  if (!strcmp(key, "fused_step")) return &ctx->fused_step;
+  if (!strcmp(key, "chain_reserve")) return &ctx->chain_reserve;
+  if (!strcmp(key, "gate_split")) return &ctx->gate_split;
+  if (!strcmp(key, "reserve_max_tiles")) return &ctx->reserve_max_tiles;
+  if (!strcmp(key, "sub_panel")) return &ctx->sub_panel;
+  if (!strcmp(key, "sub_panel_min_rows")) return &ctx->sub_panel_min_rows;
+  if (!strcmp(key, "nb_first")) return &ctx->nb_first;
+  if (!strcmp(key, "split_tail")) return &ctx->split_tail;
+  return nullptr;
+}
+
+static int set_option_checked(tgp_ctx* ctx, const char* key, int64_t value, int64_t* old) {
+  int64_t* slot = option_slot(ctx, key);
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
   if (slot == &ctx->nb_outer)
     TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);
+  if (slot == &ctx->sub_panel || slot == &ctx->nb_first)
+    TGP_ARG_CHECK(value >= 0 && value % TILE == 0, "%s must be a multiple of %d (0: off)", key, TILE);
   if (old) *old = *slot;
   *slot = value;
+  return TGP_OK;
+}
+
+int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* old) {
+  TGP_ARG_CHECK(ctx != nullptr && key != nullptr, "null argument");
+  return set_option_checked(ctx, key, value, old);
+}
+
+int tgp_ctx_get_option(tgp_ctx* ctx, const char* key, int64_t* value) {
+  TGP_ARG_CHECK(ctx != nullptr && key != nullptr && value != nullptr, "null argument");
+  int64_t* slot = option_slot(ctx, key);
+  TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
+  *value = *slot;
+  return TGP_OK;
+}
+
+// "key=value,key=value" (the format of TGP_HIP_OPTIONS) applied to a context
+static int apply_options(tgp_ctx* ctx, const char* options) {
+  if (options == nullptr) return TGP_OK;
+  std::string all(options);
+  size_t pos = 0;
+  while (pos < all.size()) {
+    size_t end = all.find(',', pos);
+    if (end == std::string::npos) end = all.size();
+    const std::string item = all.substr(pos, end - pos);
+    pos = end + 1;
+    if (item.empty()) continue;
+    const size_t eq = item.find('=');
+    TGP_ARG_CHECK(eq != std::string::npos && eq > 0, "option '%s' is not key=value", item.c_str());
+    char* stop = nullptr;
+    const long long v = strtoll(item.c_str() + eq + 1, &stop, 10);
+    TGP_ARG_CHECK(stop != nullptr && *stop == 0 && eq + 1 < item.size(), "option '%s': bad integer", item.c_str());
+    TGP_TRY(set_option_checked(ctx, item.substr(0, eq).c_str(), (int64_t)v, nullptr));
+  }
   return TGP_OK;
 }
 
@@ -1054,9 +1099,8 @@ int tgp_solver_timings(tgp_solver* s, double* ms, int n) {
 // Dry run of tgp_solver_factor / tgp_solver_factor_logprob: the sequence of kernel launches and
 // event operations the five streams would receive for an n_pad x n_pad problem, without a GPU
 // (no HIP call is made).  Ten int64 per record: kind, stream, v[0..7] (tgp_trace_rec).
-int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t first_split,
-                     int64_t first_small_tiles, int64_t nb_wide_rows, int32_t fused, int64_t* out,
-                     int64_t cap_records, int64_t* n_records) {
+int tgp_trace_factor(int64_t n_pad, const char* options, int32_t fused, int64_t* out, int64_t cap_records,
+                     int64_t* n_records) {
   using namespace tgp;
   TGP_ARG_CHECK(n_pad > 0 && n_pad % 128 == 0 && out != nullptr && n_records != nullptr,
                 "trace: n_pad must be a positive multiple of 128");
@@ -1076,13 +1120,7 @@ int tgp_trace_factor(int64_t n_pad, int64_t nb_outer, int64_t lookahead, int64_t
   ctx.ev_f = (hipEvent_t)fake(0x160);
   ctx.ev_g1 = (hipEvent_t)fake(0x170);
   ctx.ev_g2 = (hipEvent_t)fake(0x180);
-  ctx.gate_split = (fused & 4) ? 0 : 1;  // bit 2: the gate in one piece
-  ctx.fused_step = (fused & 2) ? 0 : 1;  // bit 1: the unfused chain (potf2 | trsm | update per block)
-  ctx.nb_outer = nb_outer;
-  ctx.lookahead = lookahead;
-  ctx.first_split = first_split;
-  ctx.first_small_tiles = first_small_tiles;
-  ctx.nb_wide_rows = nb_wide_rows;
+  TGP_TRY(apply_options(&ctx, options));  // every option of tgp_ctx_set_option, library defaults otherwise
   std::vector<tgp_trace_rec> recs;
   ctx.trace = &recs;
   // never dereferenced: only differences of these pointers are recorded

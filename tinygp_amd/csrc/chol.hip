@@ -1059,19 +1059,29 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
     }
     return TGP_OK;
   }
+  // Two-level panel (ctx option sub_panel): the rank-128 updates behind a block stay inside its sub-panel, and the
+  // last block of a sub-panel is followed -- on the chain's own stream, it gates the next potf2 -- by ONE update of
+  // the panel's remaining columns with K = sub_panel.  C traffic and flops of the bandwidth-hungry K = 128 kernel
+  // fall by 57 % (NB = 1024, sub-panels of 512: 12 + 16 instead of 28 units of 128 x 128 column blocks per row).
+  int64_t SB = ctx->sub_panel;
+  if (SB < 2 * TILE || SB >= kb || kb % SB != 0 || n - k0 < ctx->sub_panel_min_rows) SB = 0;
   for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
     T* Ljj = A + j0 * ld + j0;
     T* dj = dinv + (j0 / TILE) * 2048;
-    const bool pend = j0 > k0;  // in-panel update from block column j0-128 still in flight
-    if (pend || !head_done) TGP_TRY(panel_potf2<T>(ctx, st, A, ld, dinv, pivot_off, j0, pend));
+    const int64_t sub_end = SB > 0 ? k0 + ((j0 - k0) / SB + 1) * SB : k0 + kb;  // end of this block's sub-panel
+    const bool sub_first = SB > 0 && j0 > k0 && (j0 - k0) % SB == 0;  // its pending update was the K = SB product
+    const bool pend = j0 > k0 && !sub_first;  // in-panel update from block column j0-128 still in flight
+    if (pend || sub_first || !head_done) TGP_TRY(panel_potf2<T>(ctx, st, A, ld, dinv, pivot_off, j0, pend));
     if (pend) TGP_TRY(st_wait(ctx, st, ctx->ev_e));  // rest of that update
     const int64_t mb = n - (j0 + TILE);
     if (mb > 0) TGP_TRY(launch_trsm<T>(ctx, st, mb, Ljj, ld, dj, Ljj + TILE, ld));
-    const int64_t nc = (k0 + kb) - (j0 + TILE);
+    const int64_t nc = sub_end - (j0 + TILE);
     const bool upd = mb > 0 && nc > 0;
+    const bool need_mid = after_blocks > 0 && mb > 0 && (k0 + kb) - (j0 + TILE) > 0 &&
+                          j0 + TILE == k0 + after_blocks * TILE;
     // one marker behind the trsm serves both side streams (every marker between two
     // kernels of the chain costs it a few microseconds)
-    if (y != nullptr || upd) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
+    if (y != nullptr || upd || need_mid) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
     if (upd) {
       TGP_TRY(st_wait(ctx, S3, ctx->ev_d));
       TGP_TRY(launch_gemm_nt<T>(ctx, S3, mb, nc, TILE, Ljj + TILE, ld, Ljj + TILE, ld,
@@ -1082,7 +1092,16 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
       if (S2 != S3 || !upd) TGP_TRY(st_wait(ctx, S2, ctx->ev_d));  // (already waited for by the update)
       TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, mb, Ljj, ld, dj, y + j0));
     }
-    if (after_blocks > 0 && upd && j0 + TILE == k0 + after_blocks * TILE) TGP_TRY(mid(ctx->ev_d));
+    if (need_mid) TGP_TRY(mid(ctx->ev_d));
+    if (SB > 0 && j0 + TILE == sub_end && sub_end < k0 + kb) {
+      // the sub-panel [sub_end - SB, sub_end) is final (its last trsm is the previous kernel of this stream):
+      // A[sub_end.., sub_end..k0+kb) -= P P^T, P = its rows from sub_end down; latency-bound like the gate
+      const int64_t s0 = sub_end - SB, mr = n - sub_end, ncr = k0 + kb - sub_end;
+      const T* P = A + s0 * ld + sub_end;
+      const int64_t tiles = (mr / TILE) * (ncr / TILE) - (ncr / TILE) * (ncr / TILE - 1) / 2;
+      TGP_TRY(launch_gemm_nt<T>(ctx, st, mr, ncr, SB, P, ld, P, ld, A + sub_end * ld + sub_end, ld, 1, 0,
+                                tiles <= ctx->first_small_tiles ? 4 : 1));
+    }
   }
   return TGP_OK;
 }
@@ -1154,6 +1173,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   auto width = [&](int64_t k0) -> int64_t {
     const int64_t rem = n - k0;
     int64_t w = NB;
+    if (k0 == 0 && ctx->nb_first >= TILE) w = ctx->nb_first / TILE * TILE;  // the first chain hides behind nothing
     if (ctx->nb_wide_rows > 0 && k0 > 0 && rem >= ctx->nb_wide_rows) w = 2 * NB;
     return rem < w ? rem : w;
   };

@@ -69,6 +69,13 @@ struct GemmArgs {
   // l*dG + dr they are; rows of A / B / C are GLOBAL, tm = global row tiles, and local column
   // tile tj updates rows >= its global column tile only (lower trapezoid per column tile).
   int dG, dr, dl0, dnbt;
+  // Split tail (ROLE 2): workgroup ids >= split_first cover the LAST, partly filled round of tiles with split_s
+  // workgroups per tile, each over 1 / split_s of the k-range; partial products meet in `ws`
+  // (16384 elements per (tile, slice)), the workgroup that arrives last (counter `cnt` per tile, self-resetting)
+  // subtracts them from C in slice order -- deterministic whoever that is.  ngrid = split_first + tail * split_s.
+  int split_first, split_s, ngrid;
+  T* ws;
+  int* cnt;
 };
 
 // Linear workgroup id -> (ti, tj).  Tiles are enumerated column by column (tj major) so
@@ -129,8 +136,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
   // The launcher sizes the grid: all workgroup slots of the chip for an update that runs alone,
   // fewer for one that runs beside a panel chain -- the chain's kernels then find free slots instead
   // of waiting for a round of 250-us tiles to retire (ctx option chain_reserve).
-  for (int tile = blockIdx.x; tile < g.nblk; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile < (ROLE == 2 ? g.ngrid : g.nblk); tile += gridDim.x) {
   int bid = tile;
+  int slice = 0, nsl = 1, tail_idx = 0;  // ROLE 2: this workgroup's k-slice of a tail tile
+  if (ROLE == 2 && tile >= g.split_first) {
+    tail_idx = (tile - g.split_first) / g.split_s;
+    slice = (tile - g.split_first) % g.split_s;
+    nsl = g.split_s;
+    bid = g.split_first + tail_idx;
+  }
   {
     const int nx = 8, q = g.nblk / nx, r = g.nblk % nx;
     const int xcd = bid % nx, idx = bid / nx;
@@ -207,7 +221,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     // read from LDS is negated on the way, so the accumulators end as C - A B^T and the epilogue
     // is 64 stores, nothing loaded.
     constexpr int NCH = 8;  // chunks of eight entries: (a, b-pair)
-    const bool pipe = (g.mode == 0) && (nkt - kt0 >= NCH);
+    const int kq = (nkt - kt0) / nsl;               // k-tiles of this workgroup (all of them unless a tail slice)
+    const int kbeg = kt0 + slice * kq, kend = kbeg + kq;
+    const bool pipe = (g.mode == 0) && nsl == 1 && (kend - kbeg >= NCH);
     double cst[8];
     // C addresses as a wave-uniform base (SGPRs) + four loop-invariant 32-bit lane offsets: no
     // per-chunk address registers
@@ -247,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     auto ktile = [&](int kt, auto stage, auto negated) {
       constexpr int c = decltype(stage)::value;
       const int buf = kt & 1;
-      if (kt + 1 < nkt) issue_tile(kt + 1, buf ^ 1);
+      if (kt + 1 < kend) issue_tile(kt + 1, buf ^ 1);
       if constexpr (c >= 0) {
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
@@ -288,10 +304,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
           for (int t = 0; t < 4; ++t) acc[c >> 1][(c & 1) * 2 + bb][t] += cst[bb * 4 + t];
       }
     };
-    issue_tile(kt0, kt0 & 1);
+    issue_tile(kbeg, kbeg & 1);
     tile_landed();
     __syncthreads();
-    int kt = kt0;
+    int kt = kbeg;
     if (pipe) {
       // every staged k-tile is its own (single-trip) loop: as one straight-line block the nine
       // bodies are scheduled together and spill
@@ -302,10 +318,65 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
       TGP_STAGED(0) TGP_STAGED(1) TGP_STAGED(2) TGP_STAGED(3) TGP_STAGED(4)
       TGP_STAGED(5) TGP_STAGED(6) TGP_STAGED(7)
 #undef TGP_STAGED
-      for (; kt < nkt; ++kt) ktile(kt, std::integral_constant<int, -1>{}, std::true_type{});
+      for (; kt < kend; ++kt) ktile(kt, std::integral_constant<int, -1>{}, std::true_type{});
     } else {
-      for (; kt < nkt; ++kt) ktile(kt, std::integral_constant<int, -1>{}, std::false_type{});
+      for (; kt < kend; ++kt) ktile(kt, std::integral_constant<int, -1>{}, std::false_type{});
     }
+    if (ROLE == 2 && nsl > 1) {
+      // tail slice: the partial product goes to the workspace plane by plane (256 lanes x 8 bytes contiguous)
+      T* W = g.ws + (size_t(tail_idx) * nsl + slice) * size_t(BM * BN);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) W[((a * 4 + b) * 4 + t) * 256 + tid] = acc[a][b][t];
+      // publish: every wave's stores have left it -> barrier -> one agent-scope release -> count
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      __shared__ int s_last;
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int seen = __hip_atomic_fetch_add(&g.cnt[tail_idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = seen == nsl - 1;
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          __hip_atomic_store(&g.cnt[tail_idx], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        }
+        s_last = last;
+      }
+      __syncthreads();
+      if (s_last) {  // (uniform) C -= P_0 + P_1 + ... in SLICE order, whoever arrived last
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const char* cb = Cu + (int64_t(a * 16) * g.ldc + b * 16) * 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[a][b][t] = *reinterpret_cast<const double*>(cb + voff[t]);
+          }
+        }
+        for (int sl = 0; sl < nsl; ++sl) {
+          const T* Wp = g.ws + (size_t(tail_idx) * nsl + sl) * size_t(BM * BN);
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc[a][b][t] -= Wp[((a * 4 + b) * 4 + t) * 256 + tid];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            char* cb = const_cast<char*>(Cu) + (int64_t(a * 16) * g.ldc + b * 16) * 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<double*>(cb + voff[t]) = acc[a][b][t];
+          }
+        }
+      }
+    } else
     if (pipe) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -414,12 +485,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 constexpr int SM = 64, S_LD = 80;  // 80 mod 32 == 16: conflict-free operand reads
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmArgs<T> g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_nt_small_kernel(GemmArgs<T> g) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   using v2_t = typename M::v2_t;
-  __shared__ __attribute__((aligned(16))) T sA[2][BK * S_LD];
-  __shared__ __attribute__((aligned(16))) T sB[2][BK * S_LD];
+  // fp64: three unpadded 8-KiB stages per operand (48 KiB: three workgroups per CU); fp32: two padded buffers
+  constexpr int SBUF = sizeof(T) == 8 ? 3 * BK * SM : 2 * BK * S_LD;
+  __shared__ __attribute__((aligned(16))) T sAm[SBUF];
+  __shared__ __attribute__((aligned(16))) T sBm[SBUF];
+  T(*sA)[BK * S_LD] = reinterpret_cast<T(*)[BK * S_LD]>(sAm);  // the fp32 path's [2][BK * S_LD] view
+  T(*sB)[BK * S_LD] = reinterpret_cast<T(*)[BK * S_LD]>(sBm);
   __builtin_amdgcn_s_setprio(1);
   int ti, tj;
   decode_tile(blockIdx.x, g.tm, g.tn, g.lower, ti, tj);
@@ -453,35 +528,107 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmArgs<T> g) {
   T* Cb = g.C + (j0 + wc * 32) * g.ldc + i0 + wr * 32;
 
   if constexpr (sizeof(T) == 8) {
+    // fp64, round 3: operands staged global -> LDS directly (global_load_lds_dwordx4: no staging VGPRs, no
+    // ds_write pass), NST k-tiles deep with counted vmcnt waits and a raw s_barrier (a __syncthreads() would
+    // drain the transfers in flight), C fetched before the first transfer and used as the accumulators' initial
+    // value (the MFMA A operand is negated on the way: acc ends as C - A B^T, the epilogue is 16 stores).
+    // Before: one k-tile of register prefetch -- a 0.4-us k-tile cannot cover a 1-2-us L2 / HBM round trip, the
+    // MFMA pipes were 50 % busy (profiles/r02_s) and this kernel's 27 % of the flops cost 36 % of an evaluation.
+    // LDS image per stage: [16 k][64 rows] doubles, UNPADDED (one wave transfer = two 512-byte k-rows, lane l at
+    // +16 l) with the 128-byte blocks of odd k-rows swapped pairwise (block b of row k at b ^ (k & 1)): the two
+    // k-rows a 32-lane ds_read_b64 group touches sit on different halves of the 256-byte bank row.  The swizzle is
+    // applied to the per-lane GLOBAL source offset (the LDS side of a transfer is lane-linear by construction).
+    constexpr int NST = 3, STG = BK * SM;  // stages; doubles per operand per stage (8 KiB)
+    static_assert(SBUF == NST * STG, "the stages fill sAm / sBm");
     const int lq = (lane >> 2) & 3, lj = lane & 3;
     double acc[2][2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[a][b][t] = 0.0;
     int rot[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) rot[t] = 4 * ((lq + t) & 3) + lj;
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int x1 = lk & 1;  // odd k-row of the 4-row group this lane reads: blocks swapped pairwise
+    T* col[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) col[a] = Cb + int64_t(a * 16 + 4 * lq + lk) * g.ldc;
+    if (g.mode == 0) {  // (issued BEFORE the transfers: the loads below complete in order)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[a][b][t] = col[a][b * 16 + rot[t]];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[a][b][t] = 0.0;
+    }
+    // wave w moves k-rows {2w, 2w + 1} and {2w + 8, 2w + 9} of each operand: lanes 0..31 the even row, 32..63 the
+    // odd one; lane l fetches the 16 bytes that belong at LDS chunk (l & 31) of its row
+    const uint32_t half = uint32_t(lane >> 5), ch = uint32_t(lane & 31);
+    const uint32_t soff = 128u * ((ch >> 3) ^ half) + 16u * (ch & 7);
+    const uint32_t voa = half * uint32_t(g.lda) * 8u + soff, vob = half * uint32_t(g.ldb) * 8u + soff;
+    const uint32_t lds_a = uint32_t(size_t((__attribute__((address_space(3))) T*)(&sAm[0]))) + uint32_t(wu * 2 * SM * 8);
+    const uint32_t lds_b = uint32_t(size_t((__attribute__((address_space(3))) T*)(&sBm[0]))) + uint32_t(wu * 2 * SM * 8);
+    const T* Au = g.A + i0;
+    const T* Bu = g.B + j0;
+    auto issue_tile = [&](int kt_, int stage) {
+      const int64_t kg = int64_t(kt_) * BK + 2 * wu;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const T* ap = Au + (kg + 8 * r) * g.lda;
+        const T* bp = Bu + (kg + 8 * r) * g.ldb;
+        const uint32_t off = uint32_t((stage * STG + 8 * r * SM) * 8);
+        uint32_t keep;  // (m0 is a reserved register: saved and restored, not clobbered)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voa), "s"(ap), "s"(lds_a + off), "v"(vob), "s"(bp), "s"(lds_b + off) : "memory");
+      }
+    };
+    // 4 transfers per wave and k-tile; tile kt has landed once at most the 4 (NST - 1) younger ones are in flight
+    // (fewer near the end of the k-range: the wait is exact there too)
+    const T* sa0 = &sAm[0];
+    const T* sb0 = &sBm[0];
+    const int oa[2] = {((wc * 2) ^ x1) * 16, ((wc * 2 + 1) ^ x1) * 16};  // swizzled 16-row blocks of this lane
+    const int ob[2] = {((wr * 2) ^ x1) * 16, ((wr * 2 + 1) ^ x1) * 16};
+#pragma unroll
+    for (int q = 0; q < NST - 1; ++q)
+      if (q < nkt) issue_tile(q, q);
+    // the C values are consumed HERE as far as the compiler can tell: otherwise it puts its own waits for these
+    // loads inside the k-loop (at the accumulators' first use), where every iteration would drain the transfers
+    if (g.mode == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(acc[a][b][t]));
+    }
+    auto kloop = [&](auto negated) {
+    int stage = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nkt) load_global(kt + 1);
-      const T* pa = &sB[buf][lk * S_LD + wc * 32 + lrow];
-      const T* pb = &sA[buf][lk * S_LD + wr * 32];
+      const int ahead = nkt - 1 - kt;  // tiles issued behind this one
+      if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NST - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; tile kt-1's stage is free
+      if (kt + NST - 1 < nkt) issue_tile(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
+      const T* pa = sb0 + stage * STG + lk * SM + lrow;  // MFMA A operand <- B rows (C column)
+      const T* pb = sa0 + stage * STG + lk * SM;         // MFMA B operand <- A rows (C row), rotated
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) {
         double aop[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) aop[a] = pa[ks * 4 * S_LD + a * 16];
+        for (int a = 0; a < 2; ++a) {
+          aop[a] = pa[ks * 4 * SM + oa[a]];
+          if constexpr (decltype(negated)::value) aop[a] = -aop[a];  // accumulate -A B^T
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           double bop[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) bop[t] = pb[ks * 4 * S_LD + b * 16 + rot[t]];
+          for (int t = 0; t < 4; ++t) bop[t] = pb[ks * 4 * SM + ob[b] + rot[t]];
 #pragma unroll
           for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -489,36 +636,17 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmArgs<T> g) {
               acc[a][b][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aop[a], bop[t], acc[a][b][t], 0, 0, 0);
         }
       }
-      if (kt + 1 < nkt) store_lds(buf ^ 1);
-      __syncthreads();
+      stage = stage == NST - 1 ? 0 : stage + 1;
     }
-    {
-      T* col[2];
+    };
+    if (g.mode == 0) kloop(std::true_type{});
+    else kloop(std::false_type{});
 #pragma unroll
-      for (int a = 0; a < 2; ++a) col[a] = Cb + int64_t(a * 16 + 4 * lq + lk) * g.ldc;
-      if (g.mode == 0) {  // batched read-modify-write: all 16 loads in flight at once
-        double c[2][2][4];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) c[a][b][t] = col[a][b * 16 + rot[t]];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) col[a][b * 16 + rot[t]] = c[a][b][t] - acc[a][b][t];
-      } else {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) col[a][b * 16 + rot[t]] = acc[a][b][t];
-      }
-    }
+        for (int t = 0; t < 4; ++t) col[a][b * 16 + rot[t]] = acc[a][b][t];
   } else {
     acc_t acc[2][2];
 #pragma unroll
@@ -660,6 +788,7 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   GemmArgs<T> g;
   g.skip00 = 0;
   g.dG = g.dr = g.dl0 = g.dnbt = 0;
+  g.split_first = 0; g.split_s = 1; g.ngrid = 0; g.ws = nullptr; g.cnt = nullptr;
   TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");
   // short-K updates, and (role 4) a latency-bound update with too few big tiles to fill the chip
   if ((((role == 1 || role == 3) && k <= 256) || role == 4) && (mode == 0 || mode == 1)) {
@@ -690,6 +819,36 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   }
   const int64_t reserve = role == 0 ? ctx->reserve_hint : 0;
   ctx->reserve_hint = 0;
+  g.split_first = g.nblk; g.split_s = 1; g.ngrid = g.nblk; g.ws = nullptr; g.cnt = nullptr;
+  // Split tail (option split_tail, fp64 trailing updates on the main stream that run one workgroup per tile): the
+  // launch's last round of tiles fills R < slots workgroup slots for the duration of a full k-loop (250 us at
+  // K = 1024) -- up to 24 % of a 3-round launch at N = 16 384.  Those R tiles are given S = 2, 4 or 8 workgroups
+  // each, over 1 / S of the k-range, so that the last round is R S <= slots short workgroups.
+  if (ctx->split_tail != 0 && role == 0 && mode == 0 && reserve <= 0 && sizeof(T) == 8 && st == ctx->stream) {
+    const int slots = 2 * (ctx->cus > 0 ? ctx->cus : 256);
+    const int R = g.nblk % slots, nkt = g.k / BK;
+    int S = 1;
+    while (R > 0 && 2 * S * R <= slots && 2 * S <= 8 && nkt % (2 * S) == 0 && nkt / (2 * S) >= 8) S *= 2;
+    if (S > 1) {
+      const size_t need = size_t(slots) * BM * BN * sizeof(T) + size_t(slots) * sizeof(int);
+      if (ctx->gemm_ws_bytes < need) {
+        if (ctx->d_gemm_ws) TGP_HIP_TRY(hipFree(ctx->d_gemm_ws));
+        ctx->d_gemm_ws = nullptr;
+        ctx->gemm_ws_bytes = 0;
+        TGP_HIP_TRY(hipMalloc(&ctx->d_gemm_ws, need));
+        TGP_HIP_TRY(hipMemset(ctx->d_gemm_ws, 0, need));  // (the per-tile counters reset themselves afterwards)
+        ctx->gemm_ws_bytes = need;
+      }
+      g.split_first = g.nblk - R;
+      g.split_s = S;
+      g.ngrid = g.split_first + R * S;
+      g.ws = static_cast<T*>(ctx->d_gemm_ws);
+      g.cnt = reinterpret_cast<int*>(static_cast<char*>(ctx->d_gemm_ws) + size_t(slots) * BM * BN * sizeof(T));
+      hipLaunchKernelGGL((gemm_nt_kernel<T, 2>), dim3(unsigned(g.ngrid)), dim3(256), 0, st, g);
+      TGP_HIP_TRY(hipGetLastError());
+      return TGP_OK;
+    }
+  }
   // (Measured and removed, profiles/r02_r: the last, partly filled round of tiles on the 64x64-tile
   // kernel -- four workgroups per tile behind the full rounds.  Its k-loop of 64 short k-tiles takes
   // as long as the 245-us round it replaces: 4.43 vs 4.40 ms on a 16384^2 lower update.)
@@ -721,6 +880,7 @@ int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb
   g.tm = int(n_rows / BM); g.tn = int(nloc * (nb / BN));
   g.k = int(k); g.lower = 1; g.mode = 0;
   g.dG = G; g.dr = rank; g.dl0 = int(l0); g.dnbt = int(nb / BN);
+  g.split_first = 0; g.split_s = 1; g.ngrid = 0; g.ws = nullptr; g.cnt = nullptr;
   int64_t total = 0;
   for (int64_t q = 0; q < nloc; ++q) {
     const int64_t g0 = ((l0 + q) * G + rank) * g.dnbt;

@@ -111,6 +111,13 @@ struct tgp_ctx {
   // the block-column update between two chains (the `gate`) is issued column block 0 | 1 | 2..: the chain starts
   // behind the first piece and meets the others at its second and third block (fused panel step only)
   int64_t gate_split = 1;
+  // two-level panel: the in-panel rank-128 updates stay inside sub-panels of this many columns and every finished
+  // sub-panel updates the panel's remaining columns with ONE K = sub_panel product (0: off) -- 57 % fewer flops on
+  // the rank-128 kernel at nb_outer = 1024 / sub_panel = 512; only for panels with at least sub_panel_min_rows rows
+  int64_t sub_panel = 0;
+  int64_t sub_panel_min_rows = 0;
+  int64_t nb_first = 0;    // width of the FIRST panel, whose chain nothing hides (0: nb_outer)
+  int64_t split_tail = 0;  // trailing update: the last, partly filled round of tiles is split along k (gemm.hip)
   int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
   uint32_t* d_step_flag = nullptr;  // the flag potf2's workgroup publishes; value = step_epoch of the launch
   uint32_t step_epoch = 0;
@@ -119,6 +126,8 @@ struct tgp_ctx {
   int32_t* d_info = nullptr;
   void* d_dinv = nullptr;  // inverse 16x16 diagonal blocks, grown on demand
   size_t dinv_bytes = 0;
+  void* d_gemm_ws = nullptr;  // split-tail workspace of the trailing update: partial tiles + per-tile counters
+  size_t gemm_ws_bytes = 0;
   void* d_work = nullptr;  // generic workspace, grown on demand
   size_t work_bytes = 0;
   // profiling (option "profile"): event pairs around trailing-update launches
