@@ -135,6 +135,8 @@ def parse_args():
     p.add_argument("--replicas", action="store_true",
                    help="at --gpus N > 1: independent evaluations per rank instead of one matrix")
     p.add_argument("--nb-dist", type=int, default=1024, help="block-column width of the distributed path")
+    p.add_argument("--no-strong-table", action="store_true",
+                   help="at --gpus N > 1: skip the N = 16 384 / 65 536 strong-scaling entries and the one-GPU references")
     return p.parse_args()
 
 
@@ -412,6 +414,9 @@ def run_distributed(args, spec, rank, local_rank, world, torch, tdist, replicas_
             "replicas": replicas_value,
             "cpu_baseline": None,
         }
+    solver.ops.close()
+    del solver
+    torch.cuda.empty_cache()
     return result
 
 
@@ -608,12 +613,53 @@ def main():
             # the other sharding of the path, as a secondary entry: config 2 replicas
             a2 = argparse.Namespace(**vars(args))
             a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_secondary = 5, 2, True, True
-            r = run_single(a2, workload_spec("c2"), rank, local_rank, world, torch, dist)
+            r = run_single(a2, workload_spec("n2048" if rehearsal and os.environ.get("TGP_BENCH_SMALL") == "1"
+                                             else "c2"), rank, local_rank, world, torch, dist)
             if r is not None:
                 replicas_value = {"value": r["value"], "unit": "evals/s", "scaling": "weak",
                                   "workload": r["config"]["workload"], "ms_per_step": r["ms_per_step"]}
-        spec = workload_spec(args.workload or ("c4" if world > 1 else "c2"))
+        # (rehearsal only: TGP_BENCH_SMALL=1 shrinks the default N > 1 line's sizes so that the whole code path --
+        # primary line, strong-scaling rows, one-GPU references -- runs in seconds on a shared test GPU)
+        small = rehearsal and os.environ.get("TGP_BENCH_SMALL") == "1"
+        sizes = ("n2048", "n4096", "n8192") if small else ("c2", "n65536", "c4")
+        spec = workload_spec(args.workload or (sizes[2] if world > 1 else "c2"))
         out = run_distributed(args, spec, rank, local_rank, world, torch, dist, replicas_value)
+        if world > 1 and not args.workload and not args.no_strong_table:
+            # north_star's table in ONE run: the same block-column path at N = 16 384 and 65 536 (plus the primary
+            # line's N = 131 072), each next to the single-GPU driver's time for that size measured on rank 0 of
+            # this very run (the other ranks wait at a barrier) -> speed-up at this world size
+            table = []
+            a3 = argparse.Namespace(**vars(args))
+            a3.steps, a3.warmup = min(args.steps, 5), min(args.warmup, 2)
+            for name in sizes[:2]:
+                r = run_distributed(a3, workload_spec(name), rank, local_rank, world, torch, dist)
+                if r is not None:
+                    table.append({"n": r["config"]["n"], "ms_per_step": r["ms_per_step"], "evals_per_s": r["value"],
+                                  "aggregate_cholesky_tflops": r["aggregate_cholesky_tflops"],
+                                  "panel_broadcast_bytes_received_per_rank": r["panel_broadcast_bytes_received_per_rank"]})
+            if out is not None:
+                table.append({"n": out["config"]["n"], "ms_per_step": out["ms_per_step"], "evals_per_s": out["value"],
+                              "aggregate_cholesky_tflops": out["aggregate_cholesky_tflops"],
+                              "panel_broadcast_bytes_received_per_rank": out["panel_broadcast_bytes_received_per_rank"]})
+            dist.barrier()
+            if rank == 0:
+                a1 = argparse.Namespace(**vars(args))
+                a1.no_cpu_baseline, a1.no_secondary, a1.no_profile = True, True, True
+                for row, (name, st, wu) in zip(table, ((sizes[0], 5, 2), (sizes[1], 2, 1), (sizes[2], 1, 1))):
+                    a1.steps, a1.warmup = st, wu
+                    try:
+                        ref = run_single(a1, workload_spec(name), 0, local_rank, 1, torch, None)
+                        row["single_gpu_ms_per_step"] = ref["ms_per_step"]
+                        row["speedup_vs_1_gpu"] = ref["ms_per_step"] / row["ms_per_step"]
+                        row["fraction_of_fp64_mfma_peak_all_gpus"] = row["aggregate_cholesky_tflops"] / (
+                            world * FP64_MFMA_PEAK_TFLOPS)
+                    except Exception as e:  # never lose the line to a reference measurement
+                        row["single_gpu_error"] = repr(e)
+                out["strong_scaling"] = {"gpus": world, "path": "1-D block-cyclic block columns, RCCL panel broadcast",
+                                         "rows": table,
+                                         "note": "single_gpu_ms_per_step: tinygp_amd's single-GPU driver on rank 0 of "
+                                                 "this run (N = 131 072 fits one MI355X: 137 GB)"}
+            dist.barrier()
     else:
         spec = workload_spec(args.workload or "c2")
         out = run_single(args, spec, rank, local_rank, world, torch, dist if world > 1 else None)

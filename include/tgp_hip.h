@@ -284,9 +284,16 @@ int tgp_solver_timings(tgp_solver* s, double* ms, int n);
  *
  * ring0..ring2 (tgp_dist_slot_elems(n, nb) elements each) and x (n_pad = ceil(n/nb)*nb elements)
  * are device buffers of the CALLER (torch tensors, so that torch.distributed can send them):
- *   ring slot of panel k = ring[k % 3] = [(nb/128)*2048 inverse 16x16 diagonal blocks |
- *                                         (n_pad - k nb) x nb panel, column-major, ld = rows]
- *   x: the replicated right-hand side: residual -> L^-1 r (after tgp_dist_end) -> K^-1 r. */
+ *   ring slot of panel k = ring[k % 3] = [(n_pad - k nb) x nb panel, column-major, ld = rows |
+ *                                         (nb/128)*2048 inverse 16x16 diagonal blocks]
+ *   (the panel first: a column chunk -- and the last chunk with the inverses -- is ONE contiguous message)
+ *   x: the replicated right-hand side: residual -> L^-1 r (after tgp_dist_end) -> K^-1 r.
+ * Per step k the host calls (tinygp_amd/distributed.py, BlockCyclicCholesky.factor):
+ *   priority stream   owner of k+1: [RCCL wait for panel k] tgp_dist_lookahead(k), then per column chunk c
+ *                     tgp_dist_panel_chunk(k+1, c, nch) + broadcast of the chunk; receivers of k+1:
+ *                     tgp_dist_slot_ready(k+1) + the same broadcasts
+ *   main stream       [RCCL wait for panel k] tgp_dist_arrived(k), tgp_dist_fwd_step(k),
+ *                     tgp_dist_pre_update(k), tgp_dist_rest(k). */
 typedef struct tgp_dist tgp_dist;
 int64_t tgp_dist_slot_elems(int64_t n, int64_t nb);
 int tgp_dist_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X_host,
@@ -300,16 +307,27 @@ int tgp_dist_stream(tgp_dist* h, int which, void** stream_out);
 int tgp_dist_assemble(tgp_dist* h, const tgp_kop* prog, int nops);
 /* start of a factorisation; resid_host (n,) != NULL: also forward-substitute it (gp.py:318-320) */
 int tgp_dist_begin(tgp_dist* h, const void* resid_host);
-/* owner of panel 0: factor + pack it (no-op on the other ranks) */
+/* every rank: assembly of its remaining block columns (behind tgp_dist_panel_chunk(0, 0, ..) on the owner of
+ * panel 0, so that it hides beside the first chain) */
 int tgp_dist_first_panel(tgp_dist* h);
-/* panel k has arrived in its ring slot (the main stream already waits for it); on the owner of
- * panel k+1: the look-ahead update of that block column, its chain and its pack */
-int tgp_dist_after_recv(tgp_dist* h, int64_t k);
+/* owner of panel k: column chunk c of nch (nch divides nb / 128) of its chain (potf2 / trsm / in-panel updates,
+ * priority stream) and the pack of that chunk into the ring slot (the last chunk packs the inverses too) */
+int tgp_dist_panel_chunk(tgp_dist* h, int64_t k, int64_t c, int64_t nch);
+/* receiver of panel k: the priority stream waits until the slot's previous panel (k - 3) has been read */
+int tgp_dist_slot_ready(tgp_dist* h, int64_t k);
+/* owner of panel k+1, priority stream (already waiting for panel k's arrival): panel k applied to block
+ * column k+1, behind tgp_dist_pre_update(k-1) */
+int tgp_dist_lookahead(tgp_dist* h, int64_t k);
+/* panel k has arrived and the main stream waits for it: the marker tgp_dist_fwd_step(k) depends on */
+int tgp_dist_arrived(tgp_dist* h, int64_t k);
 /* forward-substitution step k of the replicated right-hand side (solvers/direct.py:66-70 on the
- * received panel) and sum log L_ii of panel k (direct.py:61-64); call after the broadcast of
- * panel k+1 has been started and before tgp_dist_rest(k) */
+ * received panel) and sum log L_ii of panel k (direct.py:61-64), on the update stream */
 int tgp_dist_fwd_step(tgp_dist* h, int64_t k);
-/* update of all remaining owned block columns by panel k: one fp64/fp32 MFMA launch */
+/* main stream, owner of block column k+2 only: panel k applied to that block column first (the next gate waits
+ * for this launch, not for the big update: the chain pipeline runs two panels ahead of the updates) */
+int tgp_dist_pre_update(tgp_dist* h, int64_t k);
+/* update of all other owned block columns (> k+2) by panel k: one fp64/fp32 MFMA launch, which leaves
+ * workgroup slots free when a chain of this rank runs beside it */
 int tgp_dist_rest(tgp_dist* h, int64_t k);
 /* joins the streams; *info = this rank's potrf info (host: MIN over ranks of the non-zero
  * ones), *sumsq = |L^-1 r|^2, *logdet_half = sum log L_ii (direct.py:61-64), identical on

@@ -2,7 +2,7 @@
 block-cyclic schedule (ownership, look-ahead order, ring slots, panel broadcasts, replicated
 forward solve, slice broadcasts of the backward solve, the (M,) all-reduce) can run under `gloo`
 on CPUs.  Same methods and the same buffer layout as csrc/dist.hip -- local block columns side
-by side in one column-major matrix with GLOBAL rows, ring slot = [dinv | rows x nb panel] --
+by side in one column-major matrix with GLOBAL rows, ring slot = [rows x nb panel | dinv] --
 torch CPU tensors as the buffers the collectives see, the oracle's kernel evaluation for
 assembly.  Never imported by the product."""
 import contextlib
@@ -26,7 +26,7 @@ class NumpyBlockOps:
         self.nloc = len(range(rank, self.nblk, world))
         self.nd = (nb // 128) * 2048
         tdt = torch.float64 if P.dtype == np.float64 else torch.float32
-        self.ring = [torch.zeros(self.nd + self.npad * nb, dtype=tdt) for _ in range(3)]
+        self.ring = [torch.zeros(self.npad * nb + self.nd, dtype=tdt) for _ in range(3)]
         self.x = torch.zeros(self.npad, dtype=tdt)
         self.xn = self.x.numpy()  # shares memory
         self.A = np.zeros((self.npad, max(self.nloc, 1) * nb), dtype=P.dtype, order="F")
@@ -36,7 +36,12 @@ class NumpyBlockOps:
         return contextlib.nullcontext()
 
     def slot(self, k, rows):
-        return self.ring[k % 3][: self.nd + rows * self.nb]
+        return self.ring[k % 3][: rows * self.nb + self.nd]
+
+    def slot_chunk(self, k, rows, c, nch):
+        cw = self.nb // nch
+        end = rows * self.nb + self.nd if c == nch - 1 else (c + 1) * cw * rows
+        return self.ring[k % 3][c * cw * rows: end]
 
     def x_slice(self, k):
         return self.x[k * self.nb:(k + 1) * self.nb]
@@ -46,7 +51,7 @@ class NumpyBlockOps:
 
     def _panel_view(self, k):
         rows = self.npad - k * self.nb
-        return self.ring[k % 3].numpy()[self.nd: self.nd + rows * self.nb].reshape((rows, self.nb), order="F")
+        return self.ring[k % 3].numpy()[: rows * self.nb].reshape((rows, self.nb), order="F")
 
     def _col(self, l):
         return self.A[:, l * self.nb:(l + 1) * self.nb]
@@ -96,18 +101,43 @@ class NumpyBlockOps:
         self._panel_view(k)[:] = M
 
     def first_panel(self):
-        if 0 % self.G == self.rank:
-            self._factor_and_pack(0)
+        self.calls.append(("first_panel",))
 
-    def after_recv(self, k):
-        self.calls.append(("after_recv", k))
+    def panel_chunk(self, k, c, nch):
+        """The whole panel is factored and packed with its first chunk (a synchronous stand-in has nothing to
+        overlap); the later chunks are already in place when the host sends them."""
+        assert k % self.G == self.rank and 0 <= c < nch and (self.nb // 128) % nch == 0
+        self.calls.append(("chunk", k, c))
+        if c == 0:
+            self._factor_and_pack(k)
+
+    def slot_ready(self, k):
+        assert k % self.G != self.rank
+        self.calls.append(("slot_ready", k))
+
+    def lookahead(self, k):
+        self.calls.append(("lookahead", k))
         nb = self.nb
         P = self._panel_view(k)
         k1 = k + 1
-        if k1 < self.nblk and k1 % self.G == self.rank:
-            C = self._col(k1 // self.G)[k1 * nb:]
-            C -= P[nb:] @ P[nb:2 * nb].T
-            self._factor_and_pack(k1)
+        assert k1 < self.nblk and k1 % self.G == self.rank
+        # the gate must find block column k+1 updated by every panel < k: pre_update(k-1) ran on this rank
+        assert k == 0 or ("pre_update*", k - 1) in self.calls
+        C = self._col(k1 // self.G)[k1 * nb:]
+        C -= P[nb:] @ P[nb:2 * nb].T
+
+    def arrived(self, k):
+        self.calls.append(("arrived", k))
+
+    def pre_update(self, k):
+        k2 = k + 2
+        if k2 >= self.nblk or k2 % self.G != self.rank:
+            return
+        self.calls.append(("pre_update*", k))
+        nb = self.nb
+        P = self._panel_view(k)
+        off = 2 * nb
+        self._col(k2 // self.G)[k2 * nb:] -= P[off:] @ P[off:off + nb].T
 
     def fwd_step(self, k):
         self.calls.append(("fwd_step", k))
@@ -127,7 +157,7 @@ class NumpyBlockOps:
         P = self._panel_view(k)
         for l in range(self.nloc):
             j = l * self.G + self.rank
-            if j <= k or j == k + 1:
+            if j <= k + 2:  # k+1: the gate (lookahead); k+2: pre_update
                 continue
             off = (j - k) * nb
             self._col(l)[j * nb:] -= P[off:] @ P[off:off + nb].T

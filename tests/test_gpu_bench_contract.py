@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _launch(nproc, extra, port):
-    env = dict(os.environ, TGP_BENCH_ONE_GPU="1", OMP_NUM_THREADS="4")
+def _launch(nproc, extra, port, **more_env):
+    env = dict(os.environ, TGP_BENCH_ONE_GPU="1", OMP_NUM_THREADS="4", **more_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
            "--gpus", str(nproc), "--steps", "2", "--warmup", "1"] + extra
@@ -49,3 +49,19 @@ def test_replicas_line_at_two_ranks():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     # whole-job aggregate: two evaluations per step time
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2.0) < 1e-6
+
+
+def test_default_multi_gpu_line_carries_the_strong_scaling_table():
+    """The driver's N > 1 line with NO workload override: primary = the block-column path (BASELINE config 4),
+    `replicas` = the other sharding, `strong_scaling.rows` = N in {16 384, 65 536, 131 072} through the same path,
+    each with the single-GPU driver's time measured on rank 0 of the same run -- rehearsed here at shrunken sizes
+    (TGP_BENCH_SMALL=1: 2 048 / 4 096 / 8 192) so that it takes seconds."""
+    d = _launch(2, ["--no-cpu-baseline"], 29815, TGP_BENCH_SMALL="1")
+    assert d["rehearsal"] is True and d["scaling"] == "strong" and d["config"]["n"] == 8192
+    assert d["replicas"]["scaling"] == "weak" and d["replicas"]["value"] > 0
+    rows = d["strong_scaling"]["rows"]
+    assert [r["n"] for r in rows] == [2048, 4096, 8192] and d["strong_scaling"]["gpus"] == 2
+    for r in rows:
+        assert r["ms_per_step"] > 0 and r["single_gpu_ms_per_step"] > 0
+        assert abs(r["speedup_vs_1_gpu"] - r["single_gpu_ms_per_step"] / r["ms_per_step"]) < 1e-9
+    assert rows[2]["ms_per_step"] == d["ms_per_step"]

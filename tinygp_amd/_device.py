@@ -13,7 +13,16 @@ import numpy as np
 
 from tinygp_amd import _ffi
 
-__all__ = ["points", "common_dtype", "kmat", "kdiag", "kmat_gemv"]
+__all__ = ["points", "common_dtype", "kmat", "kdiag", "kmat_gemv", "DeviceLimit", "MAX_DIM"]
+
+MAX_DIM = 16  # TGP_MAX_DIM of include/tgp_hip.h: input dimensions of the HIP kernel evaluator
+
+
+class DeviceLimit(NotImplementedError):
+    """An input the reference accepts but the device kernel evaluator does not hold (D > 16, a kernel tree of
+    more than 32 ops / stack depth 8): such a kernel MATRIX is evaluated on the host and handed to the solver
+    through the reference's own ``covariance=`` channel (solvers/direct.py:44-52), like ``kernels.Custom``; the
+    O(N^3) / O(N^2) linear algebra still runs on the device."""
 
 
 def common_dtype(*arrays) -> np.dtype:
@@ -26,8 +35,9 @@ def common_dtype(*arrays) -> np.dtype:
     return np.dtype(np.float64)
 
 
-def points(X, dtype=None) -> np.ndarray:
-    """Coordinates as a C-contiguous (N, D) array: (N,) -> (N, 1)."""
+def points(X, dtype=None, *, limit: bool = True) -> np.ndarray:
+    """Coordinates as a C-contiguous (N, D) array: (N,) -> (N, 1).  ``limit``: D must fit the device evaluator
+    (:class:`DeviceLimit` otherwise, which every caller answers with the host-evaluated route)."""
     if isinstance(X, (dict, list, tuple)):
         raise NotImplementedError(
             "pytree inputs need a custom kernel evaluated on the host; the HIP path takes "
@@ -39,8 +49,8 @@ def points(X, dtype=None) -> np.ndarray:
         X = X[:, None]
     if X.ndim != 2:
         raise ValueError(f"coordinates must have shape (N,) or (N, D); got ndim={X.ndim}")
-    if X.shape[1] > 16:
-        raise ValueError("the HIP kernel evaluator supports at most D = 16 input dimensions")
+    if limit and X.shape[1] > MAX_DIM:
+        raise DeviceLimit(f"the HIP kernel evaluator holds at most D = {MAX_DIM} input dimensions (got {X.shape[1]})")
     dtype = common_dtype(X) if dtype is None else dtype
     return np.ascontiguousarray(X, dtype=dtype)
 

@@ -107,7 +107,11 @@ SIGNATURES = {
     "tgp_dist_begin": [_vp, _vp],
     "tgp_dist_first_panel": [_vp],
     "tgp_dist_fwd_step": [_vp, _i64],
-    "tgp_dist_after_recv": [_vp, _i64],
+    "tgp_dist_panel_chunk": [_vp, _i64, _i64, _i64],
+    "tgp_dist_slot_ready": [_vp, _i64],
+    "tgp_dist_lookahead": [_vp, _i64],
+    "tgp_dist_arrived": [_vp, _i64],
+    "tgp_dist_pre_update": [_vp, _i64],
     "tgp_dist_rest": [_vp, _i64],
     "tgp_dist_end": [_vp, _pi32, _pdbl, _pdbl],
     "tgp_dist_bwd_step": [_vp, _i64],

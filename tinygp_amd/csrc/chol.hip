@@ -1016,10 +1016,17 @@ int panel_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int64_t
 template <typename T>
 int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* dinv,
                 int64_t pivot_off, int64_t k0, int64_t kb, bool head_done, T* y,
-                int64_t after_blocks, const std::function<int(hipEvent_t)>& mid) {
+                int64_t after_blocks, const std::function<int(hipEvent_t)>& mid, int64_t blk_begin,
+                int64_t blk_end) {
+  // [blk_begin, blk_end): the 128-column blocks of the panel to run NOW (default: all).  The block-column driver
+  // factors a panel in column chunks so that the broadcast of a finished chunk overlaps the rest of the chain;
+  // the in-panel updates of a block always cover the whole rest of the panel (resp. of its sub-panel), and the
+  // marker of the update in flight (ev_e) carries over from one call to the next.
+  const int64_t j_first = k0 + blk_begin * TILE;
+  const int64_t j_stop = blk_end < 0 ? k0 + kb : std::min<int64_t>(k0 + kb, k0 + blk_end * TILE);
   hipStream_t S3 = ctx->update_stream;
   hipStream_t S2 = ctx->solve_on_update != 0 ? S3 : ctx->solve_stream;  // behind the update of the same block
-  if (ctx->fused_step != 0) {
+  if (ctx->fused_step != 0 && blk_begin == 0 && blk_end < 0) {
     // One launch per block (panel_step_kernel).  The rows' workgroups apply the update of THIS column
     // block from the previous one themselves, so the separate in-panel update of block j covers the
     // column blocks j+2.. only and is not needed before step j+2: two alternating markers.
@@ -1065,7 +1072,7 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
   // fall by 57 % (NB = 1024, sub-panels of 512: 12 + 16 instead of 28 units of 128 x 128 column blocks per row).
   int64_t SB = ctx->sub_panel;
   if (SB < 2 * TILE || SB >= kb || kb % SB != 0 || n - k0 < ctx->sub_panel_min_rows) SB = 0;
-  for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
+  for (int64_t j0 = j_first; j0 < j_stop; j0 += TILE) {
     T* Ljj = A + j0 * ld + j0;
     T* dj = dinv + (j0 / TILE) * 2048;
     const int64_t sub_end = SB > 0 ? k0 + ((j0 - k0) / SB + 1) * SB : k0 + kb;  // end of this block's sub-panel
@@ -1450,7 +1457,7 @@ int tri_inverse_t(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* din
   template int compute_dinv<T>(tgp_ctx*, int64_t, const T*, int64_t, T*);                        \
   template int panel_potf2<T>(tgp_ctx*, hipStream_t, T*, int64_t, T*, int64_t, int64_t, bool);   \
   template int panel_chain<T>(tgp_ctx*, hipStream_t, int64_t, T*, int64_t, T*, int64_t, int64_t, \
-                              int64_t, bool, T*, int64_t, const std::function<int(hipEvent_t)>&); \
+                              int64_t, bool, T*, int64_t, const std::function<int(hipEvent_t)>&, int64_t, int64_t); \
   template int potrf<T>(tgp_ctx*, int64_t, T*, int64_t, T*, int32_t*, T*);                           \
   template int trsv<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, int, T*, const T*);       \
   template int compute_winv<T>(tgp_ctx*, int64_t, const T*, int64_t, T*);                        \

@@ -8,18 +8,20 @@
 // meaningful (full-height storage costs 2x the minimum and buys plain pointer arithmetic:
 // config 4 is 17 GB per GPU of 288).
 //
-// Step k.  The owner factors panel k in place with the single-GPU panel chain (chol.hip,
-// potf2 / trsm / in-panel updates on the priority stream) and PACKS it -- [dinv of its 128-
-// blocks | rows k*nb.. x nb, ld = rows] -- into ring slot k mod 3.  The host (Python,
-// tinygp_amd/distributed.py) broadcasts that slot with RCCL.  Every rank then
-//   * runs forward-substitution step k of the (replicated) right-hand side straight from the
-//     received panel on the solve stream -- log_probability needs no further exchange,
-//   * updates its block column k+1 first if it owns it (look-ahead) and starts that panel's
-//     chain on the priority stream,
-//   * updates the rest of its block columns with ONE MFMA launch over all of them
-//     (gemm_nt's block-cyclic tile map).
-// The collectives are the host's; this file only orders its streams around the two points
-// where the host calls RCCL (after tgp_dist_panel / tgp_dist_after_recv, before tgp_dist_rest).
+// Step k (round 3: the chain pipeline lives on the priority stream, two panels ahead of the big updates).
+//   * The owner of panel k+1 -- as soon as panel k has ARRIVED, whatever the main stream is still doing -- applies
+//     panel k to block column k+1 (the gate), factors it with the single-GPU panel chain and PACKS it into ring
+//     slot (k+1) mod 3 = [rows (k+1) nb.. x nb, ld = rows | dinv of its 128-blocks], in column CHUNKS: a chunk is
+//     contiguous in the column-major panel, and it is final (and its broadcast can start) while the chain is still
+//     factoring the columns to its right.  All of that on the priority stream.
+//   * The host (tinygp_amd/distributed.py) broadcasts each chunk with RCCL.
+//   * Every rank, on the main stream: forward-substitution step k of the (replicated) right-hand side straight
+//     from the received panel (update stream) -- log_probability needs no further exchange --, then panel k
+//     applied to block column k+2 on ITS owner first (so that the gate of the next step never waits for the big
+//     update), then to all other owned block columns with ONE MFMA launch (gemm_nt's block-cyclic tile map),
+//     which leaves workgroup slots free when a chain of this rank runs beside it.
+// A slot is rewritten (pack or RCCL) only behind the last readers of the panel it held three steps ago.
+// The collectives are the host's; this file only orders its streams around them.
 #include <cmath>
 
 #include "tgp_common.h"
@@ -39,7 +41,13 @@ struct tgp_dist {
   void* ring[3] = {nullptr, nullptr, nullptr};  // caller-owned broadcast slots (panel k in slot k mod 3)
   hipEvent_t ev_solve[3] = {nullptr, nullptr, nullptr};  // forward step that read the slot has finished
   bool ev_solve_set[3] = {false, false, false};
-  hipEvent_t ev_arrived = nullptr;  // panel k is in its slot (recorded on the main stream by after_recv)
+  hipEvent_t ev_arrived = nullptr;  // panel k is in its slot (recorded on the main stream by tgp_dist_arrived)
+  hipEvent_t ev_rest[3] = {nullptr, nullptr, nullptr};  // main-stream readers of the slot (pre-update, rest) have finished
+  bool ev_rest_set[3] = {false, false, false};
+  hipEvent_t ev_pre[2] = {nullptr, nullptr};  // block column j (parity j & 1) carries every panel < j - 1 ... see pre_update
+  bool ev_pre_set[2] = {false, false};
+  hipEvent_t ev_asm_done = nullptr;  // every owned block column is assembled (main stream)
+  bool s1_saw_asm = false;           // the priority stream has waited for it in this factorisation
   void* x = nullptr;       // caller-owned replicated vector (n_pad): residual -> L^-1 r -> K^-1 r
   void* Xown = nullptr;    // coordinates of the owned columns, compacted (cond-mean partial)
   void* aown = nullptr;    // alpha at the owned columns, compacted
@@ -54,6 +62,12 @@ namespace {
 
 inline size_t esz(int dtype) { return dtype == TGP_F64 ? 8 : 4; }
 inline int64_t slot_dinv_elems(const tgp_dist* h) { return (h->nb / TILE) * 2048; }
+// slot of panel k: [rows x nb panel, ld = rows | dinv]: the panel first, so that a column chunk -- and the last
+// chunk together with the inverses -- is one contiguous message
+template <typename T>
+inline const T* slot_dinv(const tgp_dist* h, int64_t k) {
+  return (const T*)h->ring[k % tgp_dist::NSLOT] + (h->npad - k * h->nb) * h->nb;
+}
 inline int64_t rows_of(const tgp_dist* h, int64_t k) { return h->npad - k * h->nb; }
 inline int owner_of(const tgp_dist* h, int64_t k) { return int(k % h->G); }
 
@@ -104,29 +118,47 @@ int join_assembly(tgp_dist* h) {
   return TGP_OK;
 }
 
-// chain of the owned panel k on the priority stream + pack into its ring slot.  `head_done`:
-// the first 128-block's potf2 is already on the main stream (behind the look-ahead update).
+// The priority stream must not overwrite slot k mod 3 before the readers of the panel it held (k - 3) are done:
+// that panel's forward step (update stream) and its main-stream updates.  (Its gate, if this rank ran one, was an
+// earlier kernel of the priority stream itself.)
+inline int wait_slot_free(tgp_dist* h, int64_t k) {
+  hipStream_t S1 = h->ctx->panel_stream;
+  const int sl = int(k % tgp_dist::NSLOT);
+  if (h->ev_solve_set[sl]) TGP_HIP_TRY(hipStreamWaitEvent(S1, h->ev_solve[sl], 0));
+  if (h->ev_rest_set[sl]) TGP_HIP_TRY(hipStreamWaitEvent(S1, h->ev_rest[sl], 0));
+  return TGP_OK;
+}
+
+// Column chunk c of nch of the owned panel k on the priority stream: its blocks of the chain, then the pack of
+// its columns (the last chunk also packs the inverses).  Chunk 0 of panel 0 branches off the main stream behind
+// the assembly of block column 0; every other chain follows its gate on the priority stream.
 template <typename T>
-int factor_and_pack(tgp_dist* h, int64_t k, bool head_done) {
+int chain_chunk_and_pack(tgp_dist* h, int64_t k, int64_t c, int64_t nch) {
   tgp_ctx* ctx = h->ctx;
   hipStream_t S0 = ctx->stream, S1 = ctx->panel_stream;
-  const int64_t l = k / h->G, rows = rows_of(h, k), ld = h->npad;
+  const int64_t l = k / h->G, rows = rows_of(h, k), ld = h->npad, nblk_p = h->nb / TILE;
+  TGP_ARG_CHECK(nch >= 1 && nch <= nblk_p && nblk_p % nch == 0 && c >= 0 && c < nch, "bad panel chunk");
   T* Ap = (T*)h->A + l * h->nb * ld + k * h->nb;
   T* dk = (T*)h->dinv + (k * h->nb / TILE) * 2048;
-  // everything the main stream has queued so far (look-ahead update of this column, the reads of
-  // the slot's previous panel) precedes the chain and the pack
-  TGP_HIP_TRY(hipEventRecord(ctx->ev_a, S0));
-  TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
+  const int64_t bpc = nblk_p / nch, cw = bpc * TILE;
+  if (c == 0) {
+    if (k == 0) {  // (later panels: the gate that precedes this call is already on the priority stream)
+      TGP_HIP_TRY(hipEventRecord(ctx->ev_a, S0));
+      TGP_HIP_TRY(hipStreamWaitEvent(S1, ctx->ev_a, 0));
+    }
+    TGP_TRY(wait_slot_free(h, k));
+  }
   const std::function<int(hipEvent_t)> no_mid = [](hipEvent_t) { return TGP_OK; };
-  TGP_TRY(panel_chain<T>(ctx, S1, rows, Ap, ld, dk, k * h->nb, 0, h->nb, head_done, (T*)nullptr, 0, no_mid));
+  TGP_TRY(panel_chain<T>(ctx, S1, rows, Ap, ld, dk, k * h->nb, 0, h->nb, false, (T*)nullptr, 0, no_mid, c * bpc,
+                         (c + 1) * bpc));
   T* slot = (T*)h->ring[k % tgp_dist::NSLOT];
-  const int64_t nd = slot_dinv_elems(h);
-  TGP_HIP_TRY(hipMemcpyAsync(slot, dk, size_t(nd) * sizeof(T), hipMemcpyDeviceToDevice, S1));
   unsigned gx = (unsigned)((rows / (16 / sizeof(T)) + 255) / 256);
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL((pack_panel_kernel<T>), dim3(gx, (unsigned)h->nb), dim3(256), 0, S1, Ap, ld,
-                     slot + nd, rows);
+  hipLaunchKernelGGL((pack_panel_kernel<T>), dim3(gx, (unsigned)cw), dim3(256), 0, S1, Ap + c * cw * ld, ld,
+                     slot + c * cw * rows, rows);
   TGP_HIP_TRY(hipGetLastError());
+  if (c == nch - 1)
+    TGP_HIP_TRY(hipMemcpyAsync(slot + rows * h->nb, dk, size_t(slot_dinv_elems(h)) * sizeof(T), hipMemcpyDeviceToDevice, S1));
   return TGP_OK;
 }
 
@@ -204,6 +236,9 @@ int tgp_dist_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X
   D_TRY(hipMalloc((void**)&h->d_logdet, size_t(h->nblk + 1) * sizeof(double)));
   for (auto& e : h->ev_solve) D_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   D_TRY(hipEventCreateWithFlags(&h->ev_arrived, hipEventDisableTiming));
+  D_TRY(hipEventCreateWithFlags(&h->ev_asm_done, hipEventDisableTiming));
+  for (auto& e : h->ev_rest) D_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : h->ev_pre) D_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   D_TRY(hipMemcpyAsync(h->X, X_host, size_t(n) * d * es, hipMemcpyHostToDevice, ctx->stream));
   D_TRY(hipMemcpyAsync(h->diag, noise_diag_host, size_t(n) * es, hipMemcpyHostToDevice, ctx->stream));
   // compacted coordinates of the owned columns (for the conditional-mean partial products)
@@ -237,6 +272,11 @@ int tgp_dist_destroy(tgp_dist* h) {
   for (void* b : bufs)
     if (b) hipFree(b);
   if (h->ev_arrived) hipEventDestroy(h->ev_arrived);
+  if (h->ev_asm_done) hipEventDestroy(h->ev_asm_done);
+  for (auto e : h->ev_rest)
+    if (e) hipEventDestroy(e);
+  for (auto e : h->ev_pre)
+    if (e) hipEventDestroy(e);
   for (auto e : h->ev_solve)
     if (e) hipEventDestroy(e);
   delete h;
@@ -276,84 +316,105 @@ int tgp_dist_begin(tgp_dist* h, const void* resid_host) {
       TGP_HIP_TRY(hipMemsetAsync((char*)h->x + size_t(h->n) * es, 0, size_t(h->npad - h->n) * es, ctx->stream));
   }
   for (bool& b : h->ev_solve_set) b = false;
+  for (bool& b : h->ev_rest_set) b = false;
+  for (bool& b : h->ev_pre_set) b = false;
+  h->s1_saw_asm = false;
   return TGP_OK;
 }
 
-// Owner of panel 0: its chain + pack.  Every rank: the rest of its block columns is assembled now.
-// (Later panels are started by tgp_dist_after_recv.)
+// Every rank: the rest of its block columns is assembled now -- on the main stream, BEHIND the point where the
+// first panel's chain branched off (tgp_dist_panel_chunk(0, 0, ..)), so that it hides beside that chain.
 int tgp_dist_first_panel(tgp_dist* h) {
   DIST_GUARD(h);
   return ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
-    if (owner_of(h, 0) == h->rank) TGP_TRY(factor_and_pack<T>(h, 0, false));
     if (h->asm_deferred) {
       h->asm_deferred = false;
       TGP_TRY(assemble_columns<T>(h, 1, h->nloc));
     }
+    TGP_HIP_TRY(hipEventRecord(h->ev_asm_done, h->ctx->stream));
     return TGP_OK;
   });
 }
 
-// Panel k sits in its ring slot on this rank and the MAIN stream has been made to wait for
-// its arrival by the caller (RCCL work.wait()).  If this rank owns panel k+1: the look-ahead
-// update of that block column, its first potf2, its chain (priority stream) and its pack.
-// The host then starts the broadcast of panel k+1 and calls tgp_dist_fwd_step(k).
-int tgp_dist_after_recv(tgp_dist* h, int64_t k) {
+// Owner of panel k: column chunk c of nch (nch divides nb / 128) of its chain, and the pack of that chunk into
+// the ring slot; the host broadcasts the chunk right behind this call.  Panel 0: the first call branches off the
+// main stream; k >= 1: call tgp_dist_lookahead(k - 1) first.
+int tgp_dist_panel_chunk(tgp_dist* h, int64_t k, int64_t c, int64_t nch) {
   DIST_GUARD(h);
-  TGP_ARG_CHECK(k >= 0 && k < h->nblk, "panel index out of range");
-  tgp_ctx* ctx = h->ctx;
-  hipStream_t S0 = ctx->stream;
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk && owner_of(h, k) == h->rank, "panel_chunk: not the owner of panel %lld",
+                (long long)k);
   return ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
-    const int64_t rows = rows_of(h, k), nb = h->nb, nd = slot_dinv_elems(h);
-    const int sl = int(k % tgp_dist::NSLOT), sl_next = int((k + 1) % tgp_dist::NSLOT);
-    const T* slot = (const T*)h->ring[sl];
-    const T* P = slot + nd;  // rows x nb, ld = rows, row 0 = global row k*nb
-    TGP_HIP_TRY(hipEventRecord(h->ev_arrived, S0));
-    // The slot panel k+1 will be written into (by the owner's pack or by RCCL, both ordered
-    // behind the main stream from here on) was last read by the forward step of panel k-2:
-    // two panels of slack for the forward solve, which shares the chip with the updates.
-    if (h->ev_solve_set[sl_next]) TGP_HIP_TRY(hipStreamWaitEvent(S0, h->ev_solve[sl_next], 0));
-    const int64_t k1 = k + 1;
-    if (k1 < h->nblk && owner_of(h, k1) == h->rank) {
-      TGP_TRY(join_assembly<T>(h));
-      const int64_t l1 = k1 / h->G, m = rows_of(h, k1), ld = h->npad;
-      T* C = (T*)h->A + l1 * nb * ld + k1 * nb;
-      const int64_t tiles = (m / TILE) * (nb / TILE) - (nb / TILE) * (nb / TILE - 1) / 2;
-      const int role = tiles <= ctx->first_small_tiles ? 4 : 0;
-      TGP_TRY(launch_gemm_nt<T>(ctx, S0, m, nb, nb, P + nb, rows, P + nb, rows, C, ld, 1, 0, role));
-      // the panel's first potf2 goes in front of the big update on the main stream: issued
-      // beside it, it waits a whole round of tiles for a free CU
-      TGP_TRY(panel_potf2<T>(ctx, S0, C, ld, (T*)h->dinv + (k1 * nb / TILE) * 2048, k1 * nb, 0, false));
-      TGP_TRY(factor_and_pack<T>(h, k1, true));
-    }
-    return TGP_OK;
+    return chain_chunk_and_pack<T>(h, k, c, nch);
   });
+}
+
+// A rank that RECEIVES panel k: the priority stream (under which the host issues the collective) waits until the
+// slot's previous panel has been read.
+int tgp_dist_slot_ready(tgp_dist* h, int64_t k) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk, "panel index out of range");
+  return wait_slot_free(h, k);
+}
+
+// Owner of panel k+1, on the PRIORITY stream, which the host has made wait for the arrival of panel k: the gate
+// -- panel k applied to block column k+1 -- behind the pre-update that brought that block column up to panel k-1
+// (tgp_dist_pre_update(k-1) on the main stream).  tgp_dist_panel_chunk(k+1, ..) follows.
+int tgp_dist_lookahead(tgp_dist* h, int64_t k) {
+  DIST_GUARD(h);
+  const int64_t k1 = k + 1;
+  TGP_ARG_CHECK(k >= 0 && k1 < h->nblk && owner_of(h, k1) == h->rank, "lookahead: not the owner of panel %lld",
+                (long long)k1);
+  tgp_ctx* ctx = h->ctx;
+  hipStream_t S1 = ctx->panel_stream;
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int64_t rows = rows_of(h, k), nb = h->nb;
+    const T* P = (const T*)h->ring[k % tgp_dist::NSLOT];  // rows x nb, ld = rows, row 0 = global row k*nb
+    if (!h->s1_saw_asm) {
+      TGP_HIP_TRY(hipStreamWaitEvent(S1, h->ev_asm_done, 0));
+      h->s1_saw_asm = true;
+    }
+    if (h->ev_pre_set[k1 & 1]) TGP_HIP_TRY(hipStreamWaitEvent(S1, h->ev_pre[k1 & 1], 0));
+    const int64_t l1 = k1 / h->G, m = rows_of(h, k1), ld = h->npad;
+    T* C = (T*)h->A + l1 * nb * ld + k1 * nb;
+    const int64_t tiles = (m / TILE) * (nb / TILE) - (nb / TILE) * (nb / TILE - 1) / 2;
+    const int role = tiles <= ctx->first_small_tiles ? 4 : 1;
+    return launch_gemm_nt<T>(ctx, S1, m, nb, nb, P + nb, rows, P + nb, rows, C, ld, 1, 0, role);
+  });
+}
+
+// Panel k sits in its ring slot on this rank and the MAIN stream has been made to wait for its arrival by the
+// caller (RCCL work.wait()): the marker the forward step waits for.
+int tgp_dist_arrived(tgp_dist* h, int64_t k) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk, "panel index out of range");
+  TGP_HIP_TRY(hipEventRecord(h->ev_arrived, h->ctx->stream));
+  return TGP_OK;
 }
 
 // Forward-substitution step k of the replicated right-hand side (and sum log L_ii of panel k),
-// straight from the received panel, on the solve stream.  A separate entry point so that the host
-// can start the broadcast of panel k+1 first.
+// straight from the received panel, on the update stream (behind the in-panel updates of a chain of this rank;
+// the steps have two panels of slack), so that a rank uses three streams of its own.
 int tgp_dist_fwd_step(tgp_dist* h, int64_t k) {
   DIST_GUARD(h);
   TGP_ARG_CHECK(k >= 0 && k < h->nblk, "panel index out of range");
   tgp_ctx* ctx = h->ctx;
-  // stream: the update stream (behind the in-panel updates of the chain that was queued just before;
-  // the steps have two panels of slack), so that a rank uses three streams of its own
   if (ctx->dist_solve_aux == 0) TGP_TRY(ensure_solve_stream(ctx));
   hipStream_t S2 = ctx->dist_solve_aux != 0 ? ctx->update_stream : ctx->solve_stream;
   return ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
-    const int64_t rows = rows_of(h, k), nb = h->nb, nd = slot_dinv_elems(h);
+    const int64_t rows = rows_of(h, k), nb = h->nb;
     const int sl = int(k % tgp_dist::NSLOT);
-    const T* slot = (const T*)h->ring[sl];
-    const T* P = slot + nd;
+    const T* P = (const T*)h->ring[sl];
+    const T* dv = slot_dinv<T>(h, k);
     TGP_HIP_TRY(hipStreamWaitEvent(S2, h->ev_arrived, 0));
     if (h->solving) {
       T* xk = (T*)h->x + k * nb;
       for (int64_t j = 0; j < nb; j += TILE)
         TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, rows - (j + TILE), P + j * rows + j, rows,
-                                        slot + (j / TILE) * 2048, xk + j));
+                                        dv + (j / TILE) * 2048, xk + j));
     }
     TGP_TRY(launch_sum_log_diag_at<T>(ctx, S2, nb, P, rows, h->d_logdet + k));
     TGP_HIP_TRY(hipEventRecord(h->ev_solve[sl], S2));
@@ -362,8 +423,29 @@ int tgp_dist_fwd_step(tgp_dist* h, int64_t k) {
   });
 }
 
-// The rest of step k: every owned block column right of k (and of k+1, done by the look-ahead)
-// in one MFMA launch.
+// Panel k applied to block column k+2 on its owner, FIRST on the main stream: the gate of step k+1 (priority
+// stream) waits for this launch only, not for the big update behind it -- the chain pipeline runs two panels
+// ahead of the updates.  No-op on the other ranks.
+int tgp_dist_pre_update(tgp_dist* h, int64_t k) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk, "panel index out of range");
+  const int64_t k2 = k + 2;
+  if (k2 >= h->nblk || owner_of(h, k2) != h->rank) return TGP_OK;
+  tgp_ctx* ctx = h->ctx;
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int64_t rows = rows_of(h, k), nb = h->nb;
+    const T* P = (const T*)h->ring[k % tgp_dist::NSLOT];
+    TGP_TRY(launch_gemm_nt_dist<T>(ctx, ctx->stream, h->npad, nb, nb, P - k * nb, rows, (T*)h->A, h->npad,
+                                   h->G, h->rank, k2 / h->G, 1, ctx->chain_reserve));
+    TGP_HIP_TRY(hipEventRecord(h->ev_pre[k2 & 1], ctx->stream));
+    h->ev_pre_set[k2 & 1] = true;
+    return TGP_OK;
+  });
+}
+
+// The rest of step k: every owned block column right of k+2 (k+1: the gate on the priority stream; k+2: the
+// pre-update) in one MFMA launch, which leaves workgroup slots to a chain of this rank that runs beside it.
 int tgp_dist_rest(tgp_dist* h, int64_t k) {
   DIST_GUARD(h);
   TGP_ARG_CHECK(k >= 0 && k < h->nblk, "panel index out of range");
@@ -371,16 +453,21 @@ int tgp_dist_rest(tgp_dist* h, int64_t k) {
   return ddispatch(h->dtype, [&](auto tag) {
     using T = decltype(tag);
     const int64_t rows = rows_of(h, k), nb = h->nb;
-    const T* P = (const T*)h->ring[k % tgp_dist::NSLOT] + slot_dinv_elems(h);
-    // first owned block column j = l*G + rank with j > k, skipping k+1 (look-ahead)
-    int64_t l0 = (k + 1 - h->rank + h->G - 1) / h->G;
+    const T* P = (const T*)h->ring[k % tgp_dist::NSLOT];
+    const int sl = int(k % tgp_dist::NSLOT);
+    // first owned block column j = l*G + rank with j > k+2
+    int64_t l0 = (k + 3 - h->rank + h->G - 1) / h->G;
     if (l0 < 0) l0 = 0;
-    if (l0 * h->G + h->rank == k + 1) ++l0;
     const int64_t cnt = h->nloc - l0;
-    if (cnt <= 0) return TGP_OK;
-    TGP_TRY(join_assembly<T>(h));
-    return launch_gemm_nt_dist<T>(ctx, ctx->stream, h->npad, nb, nb, P - k * nb, rows, (T*)h->A, h->npad,
-                                  h->G, h->rank, l0, cnt);
+    if (cnt > 0) {
+      const bool chain_beside = (k + 1 < h->nblk && owner_of(h, k + 1) == h->rank) ||
+                                (k + 2 < h->nblk && owner_of(h, k + 2) == h->rank);
+      TGP_TRY(launch_gemm_nt_dist<T>(ctx, ctx->stream, h->npad, nb, nb, P - k * nb, rows, (T*)h->A, h->npad,
+                                     h->G, h->rank, l0, cnt, chain_beside ? ctx->chain_reserve : 0));
+    }
+    TGP_HIP_TRY(hipEventRecord(h->ev_rest[sl], ctx->stream));  // the main stream is done with this slot
+    h->ev_rest_set[sl] = true;
+    return TGP_OK;
   });
 }
 

@@ -125,8 +125,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   using v2_t = typename M::v2_t;
-  __shared__ __attribute__((aligned(16))) T sA[2][BK * LDS_LD];
-  __shared__ __attribute__((aligned(16))) T sB[2][BK * LDS_LD];
+  // fp64: two padded [16 k][144] images per operand (73.7 KB); fp32: three unpadded [16 k][128] stages (48 KB)
+  constexpr int SBUF = sizeof(T) == 8 ? 2 * BK * LDS_LD : 3 * BK * BM;
+  __shared__ __attribute__((aligned(16))) T sAm[SBUF];
+  __shared__ __attribute__((aligned(16))) T sBm[SBUF];
+  T(*sA)[BK * LDS_LD] = reinterpret_cast<T(*)[BK * LDS_LD]>(sAm);  // the fp64 path's [2][BK * LDS_LD] view
+  T(*sB)[BK * LDS_LD] = reinterpret_cast<T(*)[BK * LDS_LD]>(sBm);
 
   if (ROLE == 1) __builtin_amdgcn_s_setprio(1);  // in-panel update: on the critical path
   // XCD-aware remap: hardware places workgroup b on XCD b % 8; give every XCD a contiguous
@@ -420,59 +424,112 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
       }
     }
   } else {
-    acc_t acc[4][4];
+    // fp32, round 3 (BASELINE config 5's arithmetic): v_mfma_f32_32x32x2_f32 (the fp32 instruction that reaches
+    // the 157 TFLOP/s peak; 16x16x4 tops out at 139), operands staged global -> LDS directly, three k-tiles deep
+    // with counted vmcnt waits and a raw s_barrier, C fetched first and used as the accumulators' initial value
+    // (the MFMA A operand is negated on the way: the epilogue is 64 stores).  Round 1-2's loop -- register
+    // staging one k-tile ahead, read-modify-write epilogue -- ran at 117 of 157 TFLOP/s.
+    // LDS stage: [16 k][128 rows] floats, unpadded: a k-row is 512 bytes = half a wave transfer, and a 32-lane
+    // ds_read_b32 group reads 128 contiguous bytes of ONE k-row -- no conflicts, no swizzle.
+    // Lane map of the 32x32x2 instruction: lane l supplies A[m = l & 31][k = l >> 5] and B[k][n = l & 31];
+    // accumulator register r of lane l is D[m = 8 (r >> 2) + 4 (l >> 5) + (r & 3)][n = l & 31].  As in the fp64
+    // path the MFMA "A" operand is fed with rows of B (m <-> C column) and "B" with rows of A (n <-> C row):
+    // 32 consecutive lanes hold 32 consecutive rows of one C column -- 128-byte stores.
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    constexpr int NST = 3, STG = BK * BM;  // floats per operand per stage (8 KiB)
+    static_assert(SBUF == NST * STG, "the stages fill sAm / sBm");
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int l32 = lane & 31, lh = lane >> 5;
+    f16v acc[2][2];  // [a: 32 columns][b: 32 rows] of the wave's 64 x 64
+    // this lane's C entries: row i0 + wr*64 + b*32 + l32, column j0 + wc*64 + a*32 + 8 (r >> 2) + 4 lh + (r & 3)
+    T* cbase = g.C + (j0 + (wu & 1) * 64 + 4 * lh) * g.ldc + i0 + (wu >> 1) * 64 + l32;
+    auto centry = [&](int a, int b, int r) -> T* {
+      return cbase + int64_t(a * 32 + 8 * (r >> 2) + (r & 3)) * g.ldc + b * 32;
+    };
+    __builtin_amdgcn_s_barrier();  // (persistent loop: the previous tile's last stage is still being read)
+    if (g.mode == 0) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
-
-    load_global(kt0);
-    store_lds(kt0 & 1);
-    __syncthreads();
-    for (int kt = kt0; kt < nkt; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nkt) load_global(kt + 1);
-      const T* pa = &sB[buf][lk * LDS_LD + wc * 64 + lrow];  // MFMA A operand <- B rows (C col)
-      const T* pb = &sA[buf][lk * LDS_LD + wr * 64 + lrow];  // MFMA B operand <- A rows (C row)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks) {
-        T aop[4], bop[4];
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = *centry(a, b, r);
+    } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          aop[t] = pa[ks * 4 * LDS_LD + t * 16];
-          bop[t] = pb[ks * 4 * LDS_LD + t * 16];
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    }
+    // wave w moves k-rows {2w, 2w + 1} and {2w + 8, 2w + 9} of each operand: lanes 0..31 the even row, 32..63
+    // the odd one, 16 bytes per lane
+    const uint32_t voa = uint32_t(lh) * uint32_t(g.lda) * 4u + uint32_t(l32) * 16u;
+    const uint32_t vob = uint32_t(lh) * uint32_t(g.ldb) * 4u + uint32_t(l32) * 16u;
+    const uint32_t lds_a = uint32_t(size_t((__attribute__((address_space(3))) T*)(&sAm[0]))) + uint32_t(wu * 2 * BM * 4);
+    const uint32_t lds_b = uint32_t(size_t((__attribute__((address_space(3))) T*)(&sBm[0]))) + uint32_t(wu * 2 * BM * 4);
+    const T* Au = g.A + i0;
+    const T* Bu = g.B + int64_t(gt) * BN;
+    auto issue_tile = [&](int kt_, int stage) {
+      const int64_t kg = int64_t(kt_) * BK + 2 * wu;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const T* ap = Au + (kg + 8 * r) * g.lda;
+        const T* bp = Bu + (kg + 8 * r) * g.ldb;
+        const uint32_t off = uint32_t((stage * STG + 8 * r * BM) * 4);
+        uint32_t keep;  // (m0 is a reserved register: saved and restored, not clobbered)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voa), "s"(ap), "s"(lds_a + off), "v"(vob), "s"(bp), "s"(lds_b + off) : "memory");
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < NST - 1; ++q)
+      if (kt0 + q < nkt) issue_tile(kt0 + q, q);
+    // the C values are consumed HERE as far as the compiler can tell (else its waits for these loads land inside
+    // the k-loop, where every iteration would drain the transfers in flight)
+    if (g.mode == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(acc[a][b]));
+    }
+    auto kloop = [&](auto negated) {
+      int stage = 0;
+      for (int kt = kt0; kt < nkt; ++kt) {
+        const int ahead = nkt - 1 - kt;  // tiles issued behind this one
+        if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NST - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; tile kt-1's stage is free
+        if (kt + NST - 1 < nkt) issue_tile(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
+        const T* pa = &sBm[stage * STG + lh * BM + wc * 64 + l32];  // MFMA A operand <- B rows (C column)
+        const T* pb = &sAm[stage * STG + lh * BM + wr * 64 + l32];  // MFMA B operand <- A rows (C row)
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+          T aop[2], bop[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            aop[t] = pa[ks * 2 * BM + t * 32];
+            if constexpr (decltype(negated)::value) aop[t] = -aop[t];  // accumulate -A B^T
+            bop[t] = pb[ks * 2 * BM + t * 32];
+          }
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[a], bop[b], acc[a][b], 0, 0, 0);
         }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = M::mma(aop[a], bop[b], acc[a][b]);
+        stage = stage == NST - 1 ? 0 : stage + 1;
       }
-      if (kt + 1 < nkt) store_lds(buf ^ 1);
-      __syncthreads();
-    }
-    // epilogue: C[i0 + wr*64 + b*16 + lrow, j0 + wc*64 + a*16 + drow(lane, r)]
+    };
+    if (g.mode == 0) kloop(std::true_type{});
+    else kloop(std::false_type{});
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      T* col[4];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) col[r] = Cb + lrow + int64_t(a * 16 + M::drow(lane, r)) * g.ldc;
-      if (g.mode == 0) {  // batched read-modify-write: 16 loads in flight
-        T c[4][4];
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) c[r][b] = col[r][b * 16];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) col[r][b * 16] = c[r][b] - acc[a][b][r];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) col[r][b * 16] = acc[a][b][r];
-      }
-    }
+        for (int r = 0; r < 16; ++r) *centry(a, b, r) = acc[a][b][r];
   }
   }  // tiles of this workgroup
 }
@@ -868,7 +925,7 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
 template <typename T>
 int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb, int64_t k,
                         const T* P, int64_t ldp, T* Cloc, int64_t ldc, int G, int rank, int64_t l0,
-                        int64_t nloc) {
+                        int64_t nloc, int64_t reserve) {
   TGP_ARG_CHECK(n_rows % BM == 0 && nb % BN == 0 && k % BK == 0 && k > 0 && G >= 1 && rank >= 0 &&
                     rank < G && l0 >= 0,
                 "gemm_nt_dist: bad shape");
@@ -889,7 +946,11 @@ int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb
   }
   TGP_ARG_CHECK(total < (int64_t(1) << 31), "gemm_nt_dist: too many tiles");
   g.nblk = int(total);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3(persistent_grid(ctx, g.nblk, 0)), dim3(256), 0, st, g);
+  // `reserve`: workgroup slots left to a panel chain of this rank that runs beside the update (ctx chain_reserve)
+  // -- as in the single-GPU driver only when the update is the shorter of the two (a long update on 3/4 of the
+  // slots loses more than the chain gains: N = 65 536 at world size 1 was 27 % slower with the reserve always on)
+  if (g.nblk > ctx->reserve_max_tiles) reserve = 0;
+  hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3(persistent_grid(ctx, g.nblk, reserve)), dim3(256), 0, st, g);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -939,7 +1000,7 @@ int ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops) {
 
 #define TGP_INST(T)                                                                              \
   template int launch_gemm_nt_dist<T>(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const T*, \
-                                      int64_t, T*, int64_t, int, int, int64_t, int64_t);         \
+                                      int64_t, T*, int64_t, int, int, int64_t, int64_t, int64_t); \
   template int launch_gemm_nt<T>(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const T*,     \
                                  int64_t, const T*, int64_t, T*, int64_t, int, int, int);
 TGP_INST(float)

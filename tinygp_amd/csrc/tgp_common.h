@@ -229,7 +229,7 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
 template <typename T>
 int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb, int64_t k,
                         const T* P, int64_t ldp, T* Cloc, int64_t ldc, int G, int rank, int64_t l0,
-                        int64_t nloc);
+                        int64_t nloc, int64_t reserve = 0);
 
 template <typename T>
 int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_t* info,
@@ -249,7 +249,8 @@ int panel_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int64_t
 template <typename T>
 int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* dinv,
                 int64_t pivot_off, int64_t k0, int64_t kb, bool head_done, T* y,
-                int64_t after_blocks, const std::function<int(hipEvent_t)>& mid);
+                int64_t after_blocks, const std::function<int(hipEvent_t)>& mid, int64_t blk_begin = 0,
+                int64_t blk_end = -1);
 template <typename T>
 int launch_trsv_fwd_step(tgp_ctx* ctx, hipStream_t st, int64_t m_below, const T* Ljj, int64_t ld,
                          const T* dj, T* yj);

@@ -11,10 +11,14 @@ The reference has no multi-device code at all; this is new design for MI355X + R
   stream and packs it into a ring slot; the slot is **broadcast** (``torch.distributed.broadcast``
   = ``ncclBroadcast`` over xGMI); every rank updates its own block columns with ONE MFMA launch
   over all of them;
-* look-ahead: the owner of panel ``k+1`` updates that block column first and runs its chain
-  beside the big update of step ``k``; the broadcast of panel ``k+1`` is enqueued BEFORE that
-  update, so the transfer hides under it as well (three ring slots: the replicated forward
-  solve may lag two panels behind the updates);
+* look-ahead of depth 2 (round 3): the CHAIN PIPELINE -- arrival of panel ``k`` -> gate (panel ``k`` applied to
+  block column ``k+1``) -> chain of panel ``k+1`` -> pack -> broadcast -- lives on the owner's priority stream
+  and depends on the main stream only through the small *pre-update* that brought block column ``k+1`` up to
+  panel ``k-1``; the big updates of steps ``k-1`` and ``k`` may still be running (three ring slots: a slot is
+  rewritten only behind the readers of the panel it held three steps earlier);
+* a panel is packed and broadcast in column CHUNKS (contiguous in the column-major slot): a chunk is final
+  while the chain still factors the columns to its right, so the transfer of a big panel overlaps its own
+  factorisation instead of following it;
 * ``log_probability`` needs no other exchange: every rank receives every panel, so the forward
   substitution of the (replicated) right-hand side and ``sum log L_ii`` run redundantly on each
   rank straight from the received panels, on a side stream, under the updates;
@@ -29,9 +33,10 @@ that lets the same schedule run under ``gloo`` on CPUs.
 
 Stream contract with RCCL (``torch.distributed`` makes a collective wait for the CURRENT
 stream at call time, and ``work.wait()`` makes the current stream wait for the collective):
-the owner issues the broadcast under the PANEL stream (behind the pack), the receivers
-under the MAIN stream (behind the last reader of that ring slot), everyone waits under the
-MAIN stream.
+every rank issues the broadcast of a chunk under its PANEL stream -- the owner behind the pack of
+that chunk, a receiver behind the last readers of the slot (``slot_ready``); the owner of the NEXT
+panel waits for the arrival under its PANEL stream (gate + chain), everyone under the MAIN stream
+(forward step, updates).
 """
 
 from __future__ import annotations
@@ -111,8 +116,14 @@ class HipBlockOps:
         return self.torch.cuda.stream(self.streams[which])
 
     def slot(self, k: int, rows: int):
-        """The broadcast buffer of panel k: [dinv | rows x nb panel]."""
-        return self.ring[k % 3][: self.nd + rows * self.nb]
+        """The broadcast buffer of panel k: [rows x nb panel, ld = rows | dinv]."""
+        return self.ring[k % 3][: rows * self.nb + self.nd]
+
+    def slot_chunk(self, k: int, rows: int, c: int, nch: int):
+        """Column chunk c of nch of that buffer (contiguous); the last one carries the inverses."""
+        cw = self.nb // nch
+        end = rows * self.nb + self.nd if c == nch - 1 else (c + 1) * cw * rows
+        return self.ring[k % 3][c * cw * rows: end]
 
     def x_slice(self, k: int):
         return self.x[k * self.nb:(k + 1) * self.nb]
@@ -134,8 +145,20 @@ class HipBlockOps:
     def first_panel(self):
         _ffi.check(self.lib.tgp_dist_first_panel(self.h), "tgp_dist_first_panel")
 
-    def after_recv(self, k: int):
-        _ffi.check(self.lib.tgp_dist_after_recv(self.h, k), "tgp_dist_after_recv")
+    def panel_chunk(self, k: int, c: int, nch: int):
+        _ffi.check(self.lib.tgp_dist_panel_chunk(self.h, k, c, nch), "tgp_dist_panel_chunk")
+
+    def slot_ready(self, k: int):
+        _ffi.check(self.lib.tgp_dist_slot_ready(self.h, k), "tgp_dist_slot_ready")
+
+    def lookahead(self, k: int):
+        _ffi.check(self.lib.tgp_dist_lookahead(self.h, k), "tgp_dist_lookahead")
+
+    def arrived(self, k: int):
+        _ffi.check(self.lib.tgp_dist_arrived(self.h, k), "tgp_dist_arrived")
+
+    def pre_update(self, k: int):
+        _ffi.check(self.lib.tgp_dist_pre_update(self.h, k), "tgp_dist_pre_update")
 
     def fwd_step(self, k: int):
         _ffi.check(self.lib.tgp_dist_fwd_step(self.h, k), "tgp_dist_fwd_step")
@@ -215,6 +238,7 @@ class BlockCyclicCholesky:
         self.info = 0
         self.factored = self.solved = self.have_alpha = False
         self._resid = None
+        self._err = None
         self.bytes_received = 0  # panel bytes this rank received in the last factorisation
         # A process group of one still sends its panels through the collective (the same code path as
         # with peers; 30.9 vs 30.8 ms at N = 16 384 since the driver keeps to three streams of its own
@@ -232,15 +256,47 @@ class BlockCyclicCholesky:
         return r if self.group is None else self.dist.get_global_rank(self.group, r)
 
     # -- the schedule -----------------------------------------------------------------------
+    CHUNK_MIN_BYTES = 32 << 20  # a panel is sent in pieces once a piece is at least this big
+
+    def chunks(self, k: int) -> int:
+        """Column chunks of panel k's broadcast: the same on every rank (a function of shapes only)."""
+        per = self.rows(k) * self.nb * self.dtype.itemsize
+        nblk_p = self.nb // 128
+        nch = 1
+        while nch * 2 <= min(4, nblk_p) and nblk_p % (nch * 2) == 0 and per // (nch * 2) >= self.CHUNK_MIN_BYTES:
+            nch *= 2
+        return nch
+
+    def _guard(self, fn, *a):
+        """A rank-local failure (a HIP error, the device-side hand-off timeout) must not leave the peers hanging
+        in the next collective: it is remembered, this rank keeps issuing its collectives on whatever the buffers
+        hold, and every rank raises together behind the agreed all-reduce at the end of the factorisation."""
+        if self._err is None:
+            try:
+                return fn(*a)
+            except Exception as e:  # noqa: BLE001
+                self._err = e
+        return None
+
     def _bcast_panel(self, k: int):
+        """Panel k from its owner to everyone, chunk by chunk under the PANEL stream; the owner factors and packs
+        each chunk right in front of its broadcast.  Returns the work handles."""
         own = self.owner(k) == self.rank
-        buf = self.ops.slot(k, self.rows(k))
+        nch = self.chunks(k)
         if not own:
-            self.bytes_received += buf.numel() * buf.element_size()
-        if self.G == 1 and not self.self_broadcast:
-            return _Done(self.ops, PANEL)  # nobody to send to: only the stream dependency remains
-        with self.ops.stream(PANEL if own else MAIN):
-            return self.dist.broadcast(buf, src=self._src(self.owner(k)), group=self.group, async_op=True)
+            self._guard(self.ops.slot_ready, k)
+            self.bytes_received += self.ops.slot(k, self.rows(k)).numel() * self.ops.slot(k, self.rows(k)).element_size()
+        works = []
+        for c in range(nch):
+            if own:
+                self._guard(self.ops.panel_chunk, k, c, nch)
+            if self.G == 1 and not self.self_broadcast:
+                works.append(_Done(self.ops, PANEL))  # nobody to send to: only the stream dependency remains
+                continue
+            buf = self.ops.slot_chunk(k, self.rows(k), c, nch)
+            with self.ops.stream(PANEL):
+                works.append(self.dist.broadcast(buf, src=self._src(self.owner(k)), group=self.group, async_op=True))
+        return works
 
     def factor(self, resid=None, kernel=None) -> int:
         """Assemble K + noise and factor it; with ``resid`` (= y - mean) also ``L^-1 resid``,
@@ -252,23 +308,41 @@ class BlockCyclicCholesky:
         if resid is not None:
             r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
         self.bytes_received = 0
-        ops.assemble(self.prog)
-        ops.begin(r)
-        ops.first_panel()
-        work = self._bcast_panel(0)
+        self._err = None
+        self._guard(ops.assemble, self.prog)
+        self._guard(ops.begin, r)
+        works = self._bcast_panel(0)   # owner of 0: its chain branches off behind the assembly of block column 0
+        self._guard(ops.first_panel)   # everyone: the other block columns, beside that chain
         for k in range(self.nblk):
-            with ops.stream(MAIN):
-                work.wait()  # RCCL: a stream dependency, not a host block
-            ops.after_recv(k)  # owner of k+1: look-ahead update + chain + pack
+            # -- priority stream: the chain pipeline.  Only the owner of k+1 needs panel k here.
+            nxt = None
             if k + 1 < self.nblk:
-                work = self._bcast_panel(k + 1)  # enqueued before the big update: overlaps it
-            ops.fwd_step(k)  # forward-substitution step k from the received panel
-            ops.rest(k)
-        info, self._sumsq, self._logdet = ops.end()
-        # agree on the first failing pivot (LAPACK convention), 0 if none
-        t = ops.scalar(float(info) if info else float(2**52))
+                if self.owner(k + 1) == self.rank:
+                    with ops.stream(PANEL):
+                        for w in works:
+                            w.wait()  # RCCL: a stream dependency, not a host block
+                    self._guard(ops.lookahead, k)  # gate: panel k -> block column k+1
+                nxt = self._bcast_panel(k + 1)     # (owner: chain + pack per chunk, each right before its send)
+            # -- main stream: forward step, then the updates; block column k+2 first on its owner
+            with ops.stream(MAIN):
+                for w in works:
+                    w.wait()
+            self._guard(ops.arrived, k)
+            self._guard(ops.fwd_step, k)
+            self._guard(ops.pre_update, k)
+            self._guard(ops.rest, k)
+            works = nxt
+        out = self._guard(ops.end)
+        info, self._sumsq, self._logdet = out if out is not None else (0, math.nan, math.nan)
+        # agree on the first failing pivot (LAPACK convention), 0 if none; a rank-local error travels as -1
+        t = ops.scalar(-1.0 if self._err is not None else (float(info) if info else float(2**52)))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         v = float(t.item())
+        if v < 0:
+            self.factored = self.solved = self.have_alpha = False
+            if self._err is not None:
+                raise self._err
+            raise _ffi.TgpError("block-column driver: another rank failed during the factorisation")
         self.info = 0 if v >= 2**52 else int(v)
         self.factored, self.solved, self.have_alpha = True, resid is not None, False
         self._resid = None if r is None else r.copy()  # the right-hand side the cached solves belong to
@@ -296,9 +370,11 @@ class BlockCyclicCholesky:
         if not self.have_alpha:
             ops = self.ops
             for k in reversed(range(self.nblk)):
-                ops.bwd_step(k)
-                with ops.stream(MAIN):
-                    self.dist.broadcast(ops.x_slice(k), src=self._src(self.owner(k)), group=self.group)
+                ops.bwd_step(k)  # owner: x_k on the main stream (needs the slices below it: waited for underneath)
+                with ops.stream(MAIN):  # asynchronous: issued behind bwd_step, the next step waits on the stream
+                    w = self.dist.broadcast(ops.x_slice(k), src=self._src(self.owner(k)), group=self.group,
+                                            async_op=True)
+                    w.wait()
             self.have_alpha = True
         return self.ops.x
 

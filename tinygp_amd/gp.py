@@ -64,7 +64,7 @@ class GaussianProcess:
             self.mean_function = means.Mean(mean)
 
         if mean_value is None:
-            P = _device.points(X)
+            P = _device.points(X, limit=False)
             mean_value = means.evaluate_mean(self.mean_function, X, P.shape[0], P.dtype)
         mean_value = np.asarray(mean_value)
         if mean_value.dtype.kind != "f":
@@ -186,7 +186,7 @@ class GaussianProcess:
                 kernel = self.kernel
             mean_value = self._kernel_matvec(kernel, X_test, alpha)
             if include_mean:
-                P = _device.points(X_test, self.dtype)
+                P = _device.points(X_test, self.dtype, limit=False)
                 mean_value = mean_value + means.evaluate_mean(self.mean_function, X_test,
                                                               P.shape[0], self.dtype)
         return alpha, log_prob, np.asarray(mean_value, dtype=self.dtype)

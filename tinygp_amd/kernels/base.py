@@ -44,13 +44,13 @@ class Kernel:
         ops: list = []
         self._emit(ops)
         if len(ops) > KPROG_MAX:
-            raise ValueError(f"kernel expression too large: {len(ops)} ops > {KPROG_MAX}")
+            raise _device.DeviceLimit(f"kernel expression too large for the device evaluator: {len(ops)} ops > {KPROG_MAX}")
         depth = peak = 0
         for op, *_ in ops:
             depth += -1 if op in (K_ADD, K_MUL) else 1
             peak = max(peak, depth)
         if peak > KSTACK_MAX:
-            raise ValueError(f"kernel expression too deep: stack {peak} > {KSTACK_MAX}")
+            raise _device.DeviceLimit(f"kernel expression too deep for the device evaluator: stack {peak} > {KSTACK_MAX}")
         return ops
 
     def _slots(self, out: list) -> None:
@@ -67,8 +67,13 @@ class Kernel:
 
     def _lower(self, X):
         """``(program, coordinates)`` for evaluation at ``X``.  Plain kernels pass ``X``
-        through; :mod:`tinygp_amd.transforms` fold their input map into the coordinates."""
-        return self.program(), X
+        through; :mod:`tinygp_amd.transforms` fold their input map into the coordinates.
+        Raises ``NotImplementedError`` (:class:`tinygp_amd._device.DeviceLimit` for inputs beyond the device
+        evaluator's limits) when the kernel has to be evaluated on the host instead."""
+        prog = self.program()
+        if not isinstance(X, (dict, list, tuple)) and np.ndim(X) == 2 and np.shape(X)[1] > _device.MAX_DIM:
+            raise _device.DeviceLimit(f"D = {np.shape(X)[1]} input dimensions > {_device.MAX_DIM}")
+        return prog, X
 
     # -- reference protocol ----------------------------------------------------
     def evaluate(self, X1, X2):
@@ -182,7 +187,13 @@ def _lower_binary(node, op, X):
             "in one device pass; evaluate on the host and pass covariance_value=")
     ops = p1 + p2 + [(op, 0, 0.0, 0.0)]
     if len(ops) > KPROG_MAX:
-        raise ValueError(f"kernel expression too large: {len(ops)} ops > {KPROG_MAX}")
+        raise _device.DeviceLimit(f"kernel expression too large for the device evaluator: {len(ops)} ops > {KPROG_MAX}")
+    depth = peak = 0
+    for o, *_ in ops:
+        depth += -1 if o in (K_ADD, K_MUL) else 1
+        peak = max(peak, depth)
+    if peak > KSTACK_MAX:
+        raise _device.DeviceLimit(f"kernel expression too deep for the device evaluator: stack {peak} > {KSTACK_MAX}")
     return ops, (X2 if const1 and not const2 else X1)
 
 
@@ -258,6 +269,17 @@ class Constant(Kernel):
 
     def _slots(self, out):
         out.append([(self, "value"), None])
+
+    def _host_matrix(self, X1, X2):  # only reached as an operand of a tree beyond the device limits
+        if np.ndim(self.value) != 0:
+            raise ValueError("The value of a constant kernel must be a scalar")
+        dt = _device.common_dtype(np.asarray(X1), np.asarray(X2))
+        return np.full((np.shape(X1)[0], np.shape(X2)[0]), self.value, dtype=dt)
+
+    def _host_diag(self, X):
+        if np.ndim(self.value) != 0:
+            raise ValueError("The value of a constant kernel must be a scalar")
+        return np.full((np.shape(X)[0],), self.value, dtype=_device.common_dtype(np.asarray(X)))
 
     def __repr__(self):
         return f"Constant({self.value!r})"

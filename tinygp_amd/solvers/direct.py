@@ -55,7 +55,12 @@ class DirectSolver(Solver):
         except NotImplementedError:
             self._prog, Xdev = None, X  # e.g. kernels.Conditioned: needs covariance=
         dt = _device.common_dtype(np.asarray(X), noise_diag, covariance)
-        P = _device.points(Xdev, dt)
+        P = _device.points(Xdev, dt, limit=False)
+        if P.shape[1] > _device.MAX_DIM:
+            # beyond the device evaluator (kernel._lower raised DeviceLimit above): every kernel matrix of this
+            # solver comes from the host; the device never reads the coordinates -- it gets a 1-D placeholder
+            assert self._prog is None
+            P = np.zeros((P.shape[0], 1), dtype=dt)
         self.dtype = dt
         self._P = P
         self.n, self.d = P.shape
@@ -98,7 +103,7 @@ class DirectSolver(Solver):
         # solver exactly as it was (round-2 advisor finding)
         try:
             prog, Xdev = kernel._lower(self.X)
-            if not np.array_equal(_device.points(Xdev, self.dtype), self._P):
+            if not np.array_equal(_device.points(Xdev, self.dtype, limit=False), self._P):
                 raise ValueError("refactor() cannot change the kernel's input transform: the "
                                  "transformed coordinates are resident on the device")
         except NotImplementedError:
@@ -292,7 +297,7 @@ class DirectSolver(Solver):
     def _lower_like_resident(self, kernel):
         """Program of ``kernel`` provided its input transform maps X onto the resident points."""
         prog, Xdev = kernel._lower(self.X)
-        if Xdev is not self.X and not np.array_equal(_device.points(Xdev, self.dtype), self._P):
+        if Xdev is not self.X and not np.array_equal(_device.points(Xdev, self.dtype, limit=False), self._P):
             raise NotImplementedError(
                 "conditioning with a kernel whose input transform differs from the GP's kernel "
                 "needs a host-evaluated covariance")
