@@ -1,26 +1,20 @@
 #!/bin/bash
-# round 3, batch 6: fp32 trailing-update kernel rebuilt (32x32x2 MFMA, LDS-direct 3-stage) -- full parity suite, fp32 sizes,
-# block-column driver at world size 1 after the reserve fix
+# round 3, batch 8: forward streaming solve with tf_b in LDS (pipelined hop) -- parity + timing
 R=$GRAFT_REPO_ROOT
 cd $R
-O=$R/gpurun_out/b06
+O=$R/gpurun_out/b08
 mkdir -p $O
 export TMPDIR=/tmp
 {
 date
-timeout 1200 python -m pytest tests -m gpu -x -q -k "not n131072 and not n262144" 2>&1 | tail -12
-date
-} > $O/pytest.log 2>&1
-B="--no-cpu-baseline --no-secondary"
-{
-date
-for w in n16384f32 n65536f32 n131072f32; do timeout 400 python bench.py --workload $w --steps 2 --warmup 1 $B 2>/dev/null | tail -1 | python -c "
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_gp.py -m gpu -x -q -k "streaming or solver_protocol or predict or condition or n6144 or golden" 2>&1 | tail -5
+timeout 200 python scripts/time_paths.py 16384 4096 2>&1 | tail -8
+timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile 2>/dev/null | tail -1 | python -c "
 import sys,json
-for l in sys.stdin:
-    d=json.loads(l); r=d.get('roofline') or {}
-    print(json.dumps({'n':d['config']['n'],'ms':round(d['ms_per_step'],2),'chol_TF':round(d.get('cholesky_tflops',0),2),'update_TF':round(r.get('achieved',0),2),'frac':round(r.get('frac',0),3),'avg_launch_ms':r.get('avg_launch_ms')}))
-"; done
-for w in c2 n65536; do timeout 300 python bench.py --distributed --workload $w --steps 3 --warmup 1 $B 2>/dev/null | tail -1 | cut -c1-330; done
+d=json.loads(sys.stdin.read()); print(json.dumps(d['roofline_secondary'])[:1500])"
+timeout 200 python bench.py --workload n65536 --steps 1 --warmup 1 --no-cpu-baseline --no-profile 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print(json.dumps(d['roofline_secondary'])[:1500])"
 date
-} > $O/bench.log 2>&1
-cat $O/pytest.log; cat $O/bench.log
+} > $O/log.txt 2>&1
+cat $O/log.txt

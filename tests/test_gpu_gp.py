@@ -285,6 +285,39 @@ def test_host_evaluated_kernels_factor_on_the_device():
     assert _loaded_native()
 
 
+def test_inputs_beyond_the_device_evaluator_still_factor_on_the_device():
+    """Drop-in edges (reference kernels/distance.py:41-59, kernels/base.py:84-103 have no such limits): D = 20 > 16
+    input dimensions, and a kernel tree of 41 ops > 32.  The kernel MATRIX comes from the host route (for the
+    long tree: sub-trees that fit run on the device, the combination on the host), the factorisation, the solves
+    and the conditioning run on the device through covariance= -- results at the usual tolerances."""
+    rng = np.random.default_rng(12)
+    n = 300
+    X = rng.uniform(-2, 2, (n, 20))
+    y = np.sin(X[:, 0]) + 0.1 * rng.normal(size=n)
+    Xt = rng.uniform(-2, 2, (17, 20))
+    k, ko = 1.3 * kernels.Matern52(6.0) + 0.5 * kernels.ExpSquared(9.0), 1.3 * o.Matern52(6.0) + 0.5 * o.ExpSquared(9.0)
+    gp, ref = GaussianProcess(k, X, diag=0.05), o.GaussianProcess(ko, X, diag=0.05)
+    assert gp.solver._prog is None and _loaded_native()
+    np.testing.assert_allclose(gp.log_probability(y), ref.log_probability(y), rtol=LL_RTOL)
+    c, r = gp.condition(y, Xt), ref.condition(y, Xt)
+    np.testing.assert_allclose(c.gp.loc, r.gp.loc, **TOL)
+    np.testing.assert_allclose(c.gp.variance, r.gp.variance, **TOL)
+    np.testing.assert_allclose(c.gp.covariance, r.gp.covariance, **TOL)
+    # the optimiser step with new hyper-parameters: the host matrix is rebuilt, never a stale one
+    k2, k2o = 1.1 * kernels.Matern52(5.0) + 0.5 * kernels.ExpSquared(9.0), 1.1 * o.Matern52(5.0) + 0.5 * o.ExpSquared(9.0)
+    np.testing.assert_allclose(gp.solver.factor_log_probability(y, k2),
+                               o.GaussianProcess(k2o, X, diag=0.05).log_probability(y), rtol=LL_RTOL)
+    # 41 ops in 2-D
+    x2 = rng.uniform(-2, 2, (200, 2))
+    y2 = np.sin(x2[:, 0])
+    kl, klo = kernels.Exp(1.0), o.Exp(1.0)
+    for i in range(20):
+        kl, klo = kl + (0.1 + 0.01 * i) * kernels.Matern32(1.0 + 0.1 * i), klo + (0.1 + 0.01 * i) * o.Matern32(1.0 + 0.1 * i)
+    gpl, refl = GaussianProcess(kl, x2, diag=0.1), o.GaussianProcess(klo, x2, diag=0.1)
+    np.testing.assert_allclose(gpl.log_probability(y2), refl.log_probability(y2), rtol=LL_RTOL)
+    np.testing.assert_allclose(gpl.predict(y2, x2[:9] + 0.05), refl.predict(y2, x2[:9] + 0.05), **TOL)
+
+
 def test_numerical_failure_never_raises():
     # gp.py:316: non-finite log-likelihood -> -inf; the factor holds NaNs like jax's cholesky
     x = np.linspace(0, 1, 200)

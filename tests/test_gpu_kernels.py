@@ -199,20 +199,19 @@ def test_panel_chain_variants_agree(n, opts):
     np.testing.assert_allclose(L, Llap, rtol=0, atol=1e-11 * np.abs(Llap).max())
 
 
-def test_split_tail_and_two_level_at_n8192_deterministic():
+def test_split_tail_and_two_level_at_n6144_deterministic():
     """Round-3 schedule options at a size where the trailing updates have several rounds of tiles: the split tail
     (last round of 128 x 128 tiles cut along k, partial products combined in slice order by whichever workgroup
     arrives last) and the two-level panel agree with the default schedule to rounding and are bit-reproducible."""
-    K = _spd(8192, np.float64, seed=5)
+    K = _spd(6144, np.float64, seed=5)
     Lref, info0 = ll.potrf(K)
     assert info0 == 0
-    for opts in (dict(split_tail=1), dict(sub_panel=512), dict(split_tail=1, sub_panel=512, chain_reserve=0)):
+    for opts in (dict(split_tail=1, chain_reserve=0), dict(split_tail=1, sub_panel=512)):
         L, info = ll.potrf(K, **opts)
         assert info == 0
         np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-12 * np.abs(Lref).max())
-        for _ in range(3):
-            L2, _ = ll.potrf(K, **opts)
-            assert np.array_equal(L, L2), opts
+        L2, _ = ll.potrf(K, **opts)
+        assert np.array_equal(L, L2), opts
 
 
 def test_panel_step_fp32_and_bad_pivot():

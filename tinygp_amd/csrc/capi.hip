@@ -123,7 +123,7 @@ static int assemble_lower(tgp_ctx* ctx, const tgp::KProg& kp, int64_t n, int d, 
 template <typename T>
 static int ensure_winv(tgp_solver* s) {
   if (s->winv_valid) return TGP_OK;
-  if (!s->winv) TGP_HIP_TRY(hipMalloc(&s->winv, 2 * size_t(s->npad / TILE) * 16384 * sizeof(T)));  // W and W^T
+  if (!s->winv) TGP_HIP_TRY(hipMalloc(&s->winv, 3 * size_t(s->npad / TILE) * 16384 * sizeof(T)));  // W, W^T, tf
   TGP_TRY(compute_winv<T>(s->ctx, s->npad, (const T*)s->A, s->npad, (T*)s->winv));
   s->winv_valid = true;
   return TGP_OK;

@@ -632,13 +632,18 @@ __global__ __launch_bounds__(256) void trsv_prep_kernel(int64_t n, T* __restrict
 
 // W_b = L_bb^-1 for every 128 x 128 diagonal block (column-major 128 x 128 each, zeros above the
 // diagonal): column c of W by forward substitution, one thread per column, L and W packed in LDS.
+// Round 3: also the product that takes the LAST off-diagonal tile out of the forward solve's dependent hop,
+//   tf_b = W_b L[b, b-1]          (x_b = W_b (y_b - sum_{c < b-1} L_bc x_c) - tf_b x_{b-1}),
+// 128 x 128 column-major like W (thread j = column j; the tile 64 rows at a time in LDS, W as LDS broadcasts).
+// With it the hop from x_{b-1} to x_b is ONE matrix-vector product and one reduction.
 template <typename T>
-__global__ __launch_bounds__(128) void winv_kernel(const T* __restrict__ L, int64_t ld, T* __restrict__ winv,
-                                                   T* __restrict__ winvT) {
+__global__ __launch_bounds__(128) void winv_kernel(int nblk, const T* __restrict__ L, int64_t ld, T* __restrict__ winv,
+                                                   T* __restrict__ winvT, T* __restrict__ tfwd) {
   __shared__ T Lp[8256];
   __shared__ T Wp[8256];
   const int c = threadIdx.x;
-  const T* Lb = L + int64_t(blockIdx.x) * 128 * ld + int64_t(blockIdx.x) * 128;
+  const int b = blockIdx.x;
+  const T* Lb = L + int64_t(b) * 128 * ld + int64_t(b) * 128;
   for (int k = 0; k < 128; ++k)  // column k of the block: rows k..127, coalesced
     if (c >= k) Lp[c * (c + 1) / 2 + k] = Lb[int64_t(k) * ld + c];
   __syncthreads();
@@ -650,18 +655,43 @@ __global__ __launch_bounds__(128) void winv_kernel(const T* __restrict__ L, int6
       Wp[row + c] = sum / Lp[row + i];
     }
   }
-  T* out = winv + int64_t(blockIdx.x) * 16384 + int64_t(c) * 128;
-  T* outT = winvT + int64_t(blockIdx.x) * 16384 + c;  // W^T (column-major): element (c, i) at i * 128 + c
+  T* out = winv + int64_t(b) * 16384 + int64_t(c) * 128;
+  T* outT = winvT + int64_t(b) * 16384 + c;  // W^T (column-major): element (c, i) at i * 128 + c
   for (int i = 0; i < 128; ++i) {
     const T v = (i >= c) ? Wp[i * (i + 1) / 2 + c] : T(0);
     out[i] = v;
     outT[int64_t(i) * 128] = v;
+  }
+  __syncthreads();  // every column of W is in Wp; Lp is free: it takes 64 rows of a neighbouring tile at a time
+  T* Lt = Lp;  // [64][128]: thread c reads Lt[k * 128 + c] -- conflict-free; W entries are LDS broadcasts
+  if (b >= 1) {  // tf_b[:, c] = W_b L[b, b-1][:, c], in two halves of the inner index k
+    const T* tile = Lb - int64_t(128) * ld;  // tile (b, b-1): element (k, c) at c * ld + k
+    T* o = tfwd + int64_t(b) * 16384 + int64_t(c) * 128;
+    for (int h = 0; h < 2; ++h) {
+      __syncthreads();
+      for (int cc = 0; cc < 128; ++cc)  // column cc, rows 64h .. 64h+63: half the threads, coalesced
+        if (c < 64) Lt[c * 128 + cc] = tile[int64_t(cc) * ld + 64 * h + c];
+      __syncthreads();
+      for (int i = 64 * h; i < 128; ++i) {  // rows above 64h have no entry of W in this half
+        const int row = i * (i + 1) / 2, kend = (i < 64 * h + 63 ? i : 64 * h + 63);
+        T s0 = 0, s1 = 0;
+        int k = 64 * h;
+        for (; k + 1 <= kend; k += 2) {
+          s0 += Wp[row + k] * Lt[(k - 64 * h) * 128 + c];
+          s1 += Wp[row + k + 1] * Lt[(k + 1 - 64 * h) * 128 + c];
+        }
+        if (k <= kend) s0 += Wp[row + k] * Lt[(k - 64 * h) * 128 + c];
+        if (h == 0) o[i] = s0 + s1;
+        else o[i] += s0 + s1;
+      }
+    }
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T* __restrict__ L, int64_t ld,
                                                               const T* __restrict__ winv,
+                                                              const T* __restrict__ tfwd,
                                                               const T* __restrict__ yin, T* __restrict__ x,
                                                               int32_t* __restrict__ ticket) {
   typedef T T2 __attribute__((ext_vector_type(2)));
@@ -673,97 +703,134 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
   __shared__ T sx[2][128];
   __shared__ T red[NG][128];
   __shared__ T sr[128];
+  __shared__ T sp[128];
+  // tf_b lives in LDS (128 KiB in fp64: this kernel runs one workgroup per CU anyway): loaded FIRST, long before
+  // the hop that needs it, and it costs no registers -- as a third register image next to the tile double buffer
+  // it spilled, and fetched after W_b's product its latency sat on the hop (0.53 instead of 0.45 ms at N = 16 384)
+  __shared__ __attribute__((aligned(16))) T sT[128 * 128];
   const int tid = threadIdx.x, rq = tid & 63;
   const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar address math
   if (tid == 0) sb = atomicAdd(ticket, 1);
   __syncthreads();
   const int b = __builtin_amdgcn_readfirstlane(sb);
   if (b >= nblk) return;
+  if (b >= 1) {  // column j of tf_b: 64 lanes x 16 bytes = one wave transfer
+    const T* tb = tfwd + int64_t(b) * 16384 + int64_t(NC * cg) * 128 + 2 * rq;
+    T2 stage[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) stage[j] = *reinterpret_cast<const T2*>(tb + j * 128);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) *reinterpret_cast<T2*>(&sT[(NC * cg + j) * 128 + 2 * rq]) = stage[j];
+  }
   // uniform (SGPR) base + one 32-bit lane offset per load: no per-load address registers
   const T* Lrow = L + int64_t(b) * 128 + int64_t(NC * cg) * ld;  // + (c*128 + j) * ld + 2 rq
   T acc0 = 0, acc1 = 0;
-  T2 bufA[NC], bufB[NC];  // tile double buffer; the idle one takes W_b during the last step
+  T2 bufA[NC], bufB[NC];  // tile double buffer; W_b and tf_b take them over at the end
   auto load_tile = [&](T2 (&buf)[NC], int c) {
     const T* p = Lrow + int64_t(c) * 128 * ld;
 #pragma unroll
     for (int j = 0; j < NC; ++j) buf[j] = *reinterpret_cast<const T2*>(p + int64_t(j) * ld + 2 * rq);
   };
-  // the diagonal block's inverse: this lane's 2 rows x NC columns
-  auto load_w = [&](T2 (&buf)[NC]) {
-    const T* wb = winv + int64_t(b) * 16384 + int64_t(NC * cg) * 128;
+  // a 128 x 128 column-major block of `base` (W_b, tf_b): this lane's 2 rows x NC columns
+  auto load_blk = [&](T2 (&buf)[NC], const T* base) {
+    const T* wb = base + int64_t(b) * 16384 + int64_t(NC * cg) * 128;
 #pragma unroll
     for (int j = 0; j < NC; ++j) buf[j] = *reinterpret_cast<const T2*>(wb + j * 128 + 2 * rq);
   };
   bits_t xb = Sent<T>::value;
-  // next: 0 nothing, 1 tile c+1, 2 W_b -- always issued BEFORE waiting for x_c
-  auto step = [&](int c, T2 (&cur)[NC], T2 (&nxt)[NC], int next) {
-    if (next == 1) load_tile(nxt, c + 1);
-    if (next == 2) load_w(nxt);
+  // wait for block c of the solution (bounded: a lost producer must end in a NaN, never in a hung GPU)
+  auto wait_x = [&](int c, int slot) {
     if (tid < 128) {
-      // bounded: a lost producer must end in a NaN, never in a hung GPU
       for (long spin = 0; xb == Sent<T>::value && spin < (1L << 26); ++spin) {
         if (spin) __builtin_amdgcn_s_sleep(1);
         xb = load_x_bits<T>(x + int64_t(c) * 128 + tid);
       }
-      sx[c & 1][tid] = bits_to<T>(xb);
+      sx[slot][tid] = bits_to<T>(xb);
     }
     __syncthreads();
-    if (tid < 128) xb = (next == 1) ? load_x_bits<T>(x + int64_t(c + 1) * 128 + tid) : Sent<T>::value;
-    const T* xc = &sx[c & 1][NC * cg];
+  };
+  // this wave's 32 columns of a block (in `m`) times 32 entries of an LDS vector
+  auto matvec = [&](T2 (&m)[NC], const T* v, T& o0, T& o1) {
+    o0 = 0;
+    o1 = 0;
 #pragma unroll
     for (int j0 = 0; j0 < NC; j0 += 8) {
 #pragma unroll
       for (int j = j0; j < j0 + 8; ++j) {
-        acc0 += cur[j].x * xc[j];
-        acc1 += cur[j].y * xc[j];
+        o0 += m[j].x * v[j];
+        o1 += m[j].y * v[j];
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the LDS operand reads in chunks (register pressure)
     }
   };
-  // r = y_b - sum over the four column groups (fixed order), then x_b = W_b r, then publish
+  auto sum4 = [&](int i) { return (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]); };
+  auto publish = [&](T xv) {
+    bits_t out;
+    __builtin_memcpy(&out, &xv, sizeof(T));
+    if (out == Sent<T>::value) out ^= 1;  // cannot happen for a computed value; keeps the protocol total
+    __hip_atomic_store(reinterpret_cast<bits_t*>(x + int64_t(b) * 128 + tid), out, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // next: 0 nothing, 1 tile c+1, 2 W_b -- always issued BEFORE waiting for x_c
+  auto step = [&](int c, T2 (&cur)[NC], T2 (&nxt)[NC], int next) {
+    if (next == 1) load_tile(nxt, c + 1);
+    if (next == 2) load_blk(nxt, winv);
+    wait_x(c, c & 1);
+    if (tid < 128) xb = (next == 1) ? load_x_bits<T>(x + int64_t(c + 1) * 128 + tid) : Sent<T>::value;
+    T a0, a1;
+    matvec(cur, &sx[c & 1][NC * cg], a0, a1);
+    acc0 += a0;
+    acc1 += a1;
+  };
+  // r' = y_b - (tiles 0..b-2) x; p = W_b r' (W in `wf`); then the hop: x_b = p - tf_b x_{b-1} (tf_b from LDS).
+  // Only the last product, one reduction and the store sit between x_{b-1} and x_b.
   auto finish = [&](T2 (&wf)[NC]) {
+    if (b >= 1 && tid < 128) xb = load_x_bits<T>(x + int64_t(b - 1) * 128 + tid);  // (usually still the sentinel)
     red[cg][2 * rq] = acc0;
     red[cg][2 * rq + 1] = acc1;
     __syncthreads();
-    if (tid < 128)
-      sr[tid] = yin[int64_t(b) * 128 + tid] - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    if (tid < 128) sr[tid] = yin[int64_t(b) * 128 + tid] - sum4(tid);
     __syncthreads();
-    T p0 = 0, p1 = 0;
-#pragma unroll
-    for (int j0 = 0; j0 < NC; j0 += 8) {
-#pragma unroll
-      for (int j = j0; j < j0 + 8; ++j) {
-        const T rj = sr[NC * cg + j];
-        p0 += wf[j].x * rj;
-        p1 += wf[j].y * rj;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
+    T p0, p1;
+    matvec(wf, &sr[NC * cg], p0, p1);
     red[cg][2 * rq] = p0;
     red[cg][2 * rq + 1] = p1;
     __syncthreads();
-    if (tid < 128) {
-      const T xv = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-      bits_t out;
-      __builtin_memcpy(&out, &xv, sizeof(T));
-      if (out == Sent<T>::value) out ^= 1;  // cannot happen for a computed value; keeps the protocol total
-      __hip_atomic_store(reinterpret_cast<bits_t*>(x + int64_t(b) * 128 + tid), out, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+    if (b == 0) {
+      if (tid < 128) publish(sum4(tid));
+      return;
     }
+    if (tid < 128) sp[tid] = sum4(tid);
+    wait_x(b - 1, 0);  // (its barrier also separates the reads of `red` above from the writes below)
+    T q0 = 0, q1 = 0;
+    {
+      const T* tcol = &sT[(NC * cg) * 128 + 2 * rq];
+      const T* xv = &sx[0][NC * cg];
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const T2 t2 = *reinterpret_cast<const T2*>(tcol + j * 128);
+        q0 += t2.x * xv[j];
+        q1 += t2.y * xv[j];
+      }
+    }
+    red[cg][2 * rq] = q0;
+    red[cg][2 * rq + 1] = q1;
+    __syncthreads();
+    if (tid < 128) publish(sp[tid] - sum4(tid));
   };
-  if (b == 0) {
-    load_w(bufA);
+  const int nt = b - 1;  // tiles (b, 0 .. b-2) are streamed; tile (b, b-1) is inside tf_b
+  if (nt <= 0) {
+    load_blk(bufA, winv);
     finish(bufA);
     return;
   }
   load_tile(bufA, 0);
   int c = 0;
-  for (; c + 2 < b; c += 2) {
+  for (; c + 2 < nt; c += 2) {
     step(c, bufA, bufB, 1);
     step(c + 1, bufB, bufA, 1);
   }
-  if (b - c == 2) {
+  if (nt - c == 2) {
     step(c, bufA, bufB, 1);
     step(c + 1, bufB, bufA, 2);
     finish(bufA);
@@ -1315,12 +1382,13 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   return info > 0 ? info : TGP_OK;
 }
 
-// winv: [W_b, b = 0..n/128) | W_b^T, b = 0..n/128)], 128 x 128 column-major each
+// winv: [W_b | W_b^T | tf_b = W_b L[b, b-1]], each b = 0..n/128), 128 x 128 column-major
 template <typename T>
 int compute_winv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* winv) {
   if (n == 0) return TGP_OK;
-  hipLaunchKernelGGL((winv_kernel<T>), dim3((unsigned)(n / TILE)), dim3(128), 0, ctx->stream, L, ld, winv,
-                     winv + (n / TILE) * 16384);
+  const int64_t sec = (n / TILE) * 16384;
+  hipLaunchKernelGGL((winv_kernel<T>), dim3((unsigned)(n / TILE)), dim3(128), 0, ctx->stream, (int)(n / TILE), L, ld,
+                     winv, winv + sec, winv + 2 * sec);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -1338,7 +1406,7 @@ int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int tra
     hipLaunchKernelGGL((trsv_prep_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, y, tmp, ticket);
     if (!transpose)
       hipLaunchKernelGGL((trsv_fwd_stream_kernel<T>), dim3((unsigned)nb), dim3(256), 0, st, (int)nb, L, ld, winv,
-                         (const T*)tmp, y, ticket);
+                         winv + 2 * nb * 16384, (const T*)tmp, y, ticket);
     else
       hipLaunchKernelGGL((trsv_bwd_stream_kernel<T>), dim3((unsigned)nb), dim3(512), 0, st, (int)nb, L, ld,
                          winv + nb * 16384, (const T*)tmp, y, ticket);
