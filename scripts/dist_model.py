@@ -29,9 +29,11 @@ with open(path) as f:
         rows.append((float(a[0]), float(a[1]), b[0], b[1]))
 # the LAST evaluation in the trace: from the last assembly burst on
 asm = [i for i, r in enumerate(rows) if r[2].startswith(("kmat_fast", "kmat_kernel"))]
+# an evaluation assembles in two bursts (block column 0, then the rest beside the first chain): its start is the
+# assembly launch that follows a reduction kernel (end of the previous evaluation) -- or the very first one
 start = asm[0]
 for i in asm:
-    if i > 0 and not rows[i - 1][2].startswith(("kmat_fast", "kmat_kernel")):
+    if i > 0 and rows[i - 1][2].startswith(("sum_", "__amd")) and any(r[2].startswith("sum_squares") for r in rows[:i]):
         start = i
 ev = rows[start:]
 t0 = ev[0][0]
@@ -43,7 +45,7 @@ out = []
 for k in range(nblk):
     lo = ev[potf2[k * per]][0]
     hi = ev[potf2[(k + 1) * per]][0] if k + 1 < nblk else ev[-1][1]
-    packs = [r for r in ev if r[2].startswith("pack_panel") and lo <= r[0] < hi]
+    packs = [r for r in ev if ("pack_panel" in r[2] or r[2].strip() == "void") and lo <= r[0] < hi]  # ("void": timeline.py cut the name of a kernel in a global anonymous namespace)
     chain_end = max(r[1] for r in packs)
     gate = [r for r in ev if r[2].startswith("gemm_nt") and r[3] == pq and r[1] <= lo + 1 and r[0] >= (out[-1]["chain_end"] if out else 0)]
     gate = [g for g in gate if g[1] - g[0] > 0]

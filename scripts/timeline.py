@@ -25,6 +25,6 @@ with open(out, "w") as f:
         r = list(r)
         r[0] = (r[0] - t0) / 1e3
         r[1] = (r[1] - t0) / 1e3
-        r[2] = r[2].replace("void tgp::(anonymous namespace)::", "").split("(")[0][:48].replace(", ", "_")
+        r[2] = r[2].replace("void tgp::(anonymous namespace)::", "").replace("void (anonymous namespace)::", "").split("(")[0][:48].replace(", ", "_")
         f.write(",".join(str(x) for x in r) + "\n")
 print("wrote", len(rows), "rows")

@@ -246,6 +246,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "sub_panel_min_rows")) return &ctx->sub_panel_min_rows;
   if (!strcmp(key, "nb_first")) return &ctx->nb_first;
   if (!strcmp(key, "split_tail")) return &ctx->split_tail;
+  if (!strcmp(key, "gemm_role")) return &ctx->gemm_role;
   return nullptr;
 }
 
@@ -445,7 +446,7 @@ int tgp_gemm_nt(tgp_ctx* ctx, int dtype, int64_t m, int64_t n, int64_t k, double
   return dispatch(dtype, [&](auto tag) {
     using T = decltype(tag);
     return launch_gemm_nt<T>(ctx, ctx->stream, m, n, k, (const T*)A, lda, (const T*)B, ldb, (T*)C,
-                             ldc, lower, mode, 1);
+                             ldc, lower, mode, (int)ctx->gemm_role);
   });
 }
 

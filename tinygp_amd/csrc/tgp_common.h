@@ -118,6 +118,7 @@ struct tgp_ctx {
   int64_t sub_panel_min_rows = 0;
   int64_t nb_first = 0;    // width of the FIRST panel, whose chain nothing hides (0: nb_outer)
   int64_t split_tail = 0;  // trailing update: the last, partly filled round of tiles is split along k (gemm.hip)
+  int64_t gemm_role = 1;     // role tgp_gemm_nt launches with (measurement hook: 4 = the 64x64-tile kernel at any k)
   int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
   uint32_t* d_step_flag = nullptr;  // the flag potf2's workgroup publishes; value = step_epoch of the launch
   uint32_t step_epoch = 0;
