@@ -318,6 +318,39 @@ def test_inputs_beyond_the_device_evaluator_still_factor_on_the_device():
     np.testing.assert_allclose(gpl.predict(y2, x2[:9] + 0.05), refl.predict(y2, x2[:9] + 0.05), **TOL)
 
 
+def test_pytree_input_with_a_custom_kernel():
+    """Reference gp.py:64-112, 176-191: X as a pytree (time, band label) with a `Custom` kernel -- the tutorials'
+    multi-band pattern.  Kernel matrices on the host, factorisation / solves / conditioning on the device; checked
+    against the textbook formulas in NumPy; X_test with another tree structure raises like the reference."""
+    rng = np.random.default_rng(3)
+    n = 120
+    t, band = np.sort(rng.uniform(0, 6, n)), rng.integers(0, 2, n)
+    y = np.sin(t) + 0.3 * band + 0.05 * rng.normal(size=n)
+    tt, tb = np.linspace(0, 6, 11), np.ones(11, dtype=band.dtype)
+    f = lambda a, b: 1.2 * np.exp(-0.5 * (a[0] - b[0]) ** 2 / 0.8**2) * (1.0 if a[1] == b[1] else 0.6)  # noqa: E731
+
+    def dense(t1, b1, t2, b2):
+        return 1.2 * np.exp(-0.5 * (t1[:, None] - t2[None]) ** 2 / 0.8**2) * np.where(b1[:, None] == b2[None], 1.0, 0.6)
+
+    gp = GaussianProcess(kernels.Custom(f), (t, band), diag=0.01)
+    assert gp.num_data == n and _loaded_native()
+    K = dense(t, band, t, band) + 0.01 * np.eye(n)
+    L = np.linalg.cholesky(K)
+    alpha = np.linalg.solve(K, y)
+    want_ll = -0.5 * y @ alpha - np.sum(np.log(np.diag(L))) - 0.5 * n * np.log(2 * np.pi)
+    np.testing.assert_allclose(gp.log_probability(y), want_ll, rtol=LL_RTOL)
+    c = gp.condition(y, (tt, tb))
+    Ks = dense(t, band, tt, tb)
+    np.testing.assert_allclose(c.gp.loc, Ks.T @ alpha, **TOL)
+    A = np.linalg.solve(L, Ks)
+    np.testing.assert_allclose(c.gp.variance, np.diag(dense(tt, tb, tt, tb)) - np.sum(A * A, axis=0)
+                               + np.sqrt(np.finfo(np.float64).eps), **TOL)
+    with pytest.raises(ValueError):
+        gp.condition(y, (tt, tb, tb))
+    with pytest.raises(ValueError):
+        gp.condition(y, tt)
+
+
 def test_numerical_failure_never_raises():
     # gp.py:316: non-finite log-likelihood -> -inf; the factor holds NaNs like jax's cholesky
     x = np.linspace(0, 1, 200)

@@ -219,3 +219,27 @@ def test_host_evaluated_kernels_need_no_device():
         kernels.Custom(lambda a, b: a - b)(x1, x2)
     with pytest.raises(NotImplementedError):  # no program and no evaluate()
         type("Empty", (kernels.Kernel,), {})()(x1, x2)
+
+
+def test_pytree_inputs_reach_host_evaluated_kernels():
+    """Reference gp.py:64-112: X may be any pytree whose leaves share the leading data axis.  The device evaluator
+    takes arrays only, so a tuple / dict input goes the host route: the kernel (a `Custom` function of one pair of
+    points, each point the pytree of its leaves' rows) is evaluated in Python -- no device involved here."""
+    from tinygp_amd import _device
+
+    t = np.linspace(0.0, 1.0, 9)
+    band = np.arange(9) % 2
+    X = (t, band)
+    f = lambda a, b: np.exp(-0.5 * (a[0] - b[0]) ** 2) * (1.0 if a[1] == b[1] else 0.3)  # noqa: E731
+    k = kernels.Custom(f)
+    K = k(X, X)
+    want = np.exp(-0.5 * (t[:, None] - t[None]) ** 2) * np.where(band[:, None] == band[None], 1.0, 0.3)
+    np.testing.assert_allclose(K, want, rtol=1e-15)
+    np.testing.assert_allclose(k(X), np.ones(9))
+    assert _device.num_points(X) == 9 and _device.num_points({"t": t, "b": band}) == 9
+    assert _device.tree_structure(X) == _device.tree_structure((t[:3], band[:3]))
+    assert _device.tree_structure(X) != _device.tree_structure((t, band, band))
+    with pytest.raises(ValueError):
+        _device.num_points((t, band[:5]))
+    with pytest.raises(NotImplementedError):  # a stationary kernel has no meaning on a pytree
+        kernels.Matern32(1.0)(X, X)

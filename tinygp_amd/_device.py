@@ -35,6 +35,59 @@ def common_dtype(*arrays) -> np.dtype:
     return np.dtype(np.float64)
 
 
+# -- pytree inputs (reference gp.py:64-112: X may be any pytree whose leaves share the leading data axis) ---------
+# The device evaluator takes (N,) / (N, D) arrays only; a tuple / list / dict of arrays is an input for kernels that
+# are arbitrary Python anyway (kernels.Custom, subclasses overriding evaluate()) and goes the host-evaluated route.
+def is_tree(X) -> bool:
+    return isinstance(X, (dict, list, tuple))
+
+
+def tree_leaves(X) -> list:
+    if isinstance(X, dict):
+        return [leaf for k in sorted(X) for leaf in tree_leaves(X[k])]
+    if isinstance(X, (list, tuple)):
+        return [leaf for x in X for leaf in tree_leaves(x)]
+    return [np.asarray(X)]
+
+
+def tree_map(fn, X):
+    if isinstance(X, dict):
+        return {k: tree_map(fn, v) for k, v in X.items()}
+    if isinstance(X, (list, tuple)):
+        return type(X)(tree_map(fn, x) for x in X)
+    return fn(np.asarray(X))
+
+
+def tree_structure(X):
+    """Nested keys / lengths plus the trailing shapes of the leaves (what `condition` compares, gp.py:176-191)."""
+    if isinstance(X, dict):
+        return ("dict", tuple((k, tree_structure(X[k])) for k in sorted(X)))
+    if isinstance(X, (list, tuple)):
+        return (type(X).__name__, tuple(tree_structure(x) for x in X))
+    a = np.asarray(X)
+    return ("leaf", a.ndim, a.shape[1:])
+
+
+def num_points(X) -> int:
+    """Length of the leading data axis (the same for every leaf of a pytree)."""
+    leaves = tree_leaves(X) if is_tree(X) else [np.asarray(X)]
+    if not leaves or any(a.ndim == 0 for a in leaves):
+        raise ValueError("expected coordinates with a leading data axis")
+    n = {a.shape[0] for a in leaves}
+    if len(n) != 1:
+        raise ValueError("the leaves of a pytree input must share their leading dimension")
+    return n.pop()
+
+
+def iter_points(X):
+    """One data point at a time: a row of an array, or the pytree of the leaves' rows."""
+    if not is_tree(X):
+        yield from np.asarray(X)
+        return
+    for i in range(num_points(X)):
+        yield tree_map(lambda a: a[i], X)
+
+
 def points(X, dtype=None, *, limit: bool = True) -> np.ndarray:
     """Coordinates as a C-contiguous (N, D) array: (N,) -> (N, 1).  ``limit``: D must fit the device evaluator
     (:class:`DeviceLimit` otherwise, which every caller answers with the host-evaluated route)."""

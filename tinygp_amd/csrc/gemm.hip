@@ -122,9 +122,6 @@ __device__ __forceinline__ void decode_tile_dist(int b, const GemmArgs<T>& g, in
 // ROLE only changes the kernel's name (rocprof separates the trailing update from the rest)
 template <typename T, int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
-  using M = Mfma<T>;
-  using acc_t = typename M::acc_t;
-  using v2_t = typename M::v2_t;
   // fp64: two padded [16 k][144] images per operand (73.7 KB); fp32: three unpadded [16 k][128] stages (48 KB)
   constexpr int SBUF = sizeof(T) == 8 ? 2 * BK * LDS_LD : 3 * BK * BM;
   __shared__ __attribute__((aligned(16))) T sAm[SBUF];
@@ -165,28 +162,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1;
   const int64_t i0 = int64_t(ti) * BM, j0 = int64_t(tj) * BN;
-
-  // staging: wave w loads k-rows {w, w+4, w+8, w+12}; a lane loads 2 consecutive rows
-  const T* Ag = g.A + i0 + lane * 2;
-  const T* Bg = g.B + int64_t(gt) * BN + lane * 2;
-  v2_t ra[BK / 4], rb[BK / 4];
-
-  auto load_global = [&](int kt) {
-#pragma unroll
-    for (int r = 0; r < BK / 4; ++r) {
-      const int64_t kk = int64_t(kt) * BK + w + 4 * r;
-      ra[r] = *reinterpret_cast<const v2_t*>(Ag + kk * g.lda);
-      rb[r] = *reinterpret_cast<const v2_t*>(Bg + kk * g.ldb);
-    }
-  };
-  auto store_lds = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < BK / 4; ++r) {
-      const int kk = w + 4 * r;
-      *reinterpret_cast<v2_t*>(&sA[buf][kk * LDS_LD + lane * 2]) = ra[r];
-      *reinterpret_cast<v2_t*>(&sB[buf][kk * LDS_LD + lane * 2]) = rb[r];
-    }
-  };
 
   // mode 3 (TRMM): B = L is lower triangular, so column tile tj only needs k < (tj+1)*BN
   const int nkt = (g.mode & 2) ? ((g.k < (tj + 1) * BN ? g.k : (tj + 1) * BN) / BK) : g.k / BK;

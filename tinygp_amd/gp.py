@@ -64,8 +64,13 @@ class GaussianProcess:
             self.mean_function = means.Mean(mean)
 
         if mean_value is None:
-            P = _device.points(X, limit=False)
-            mean_value = means.evaluate_mean(self.mean_function, X, P.shape[0], P.dtype)
+            if _device.is_tree(X):  # pytree input (gp.py:64-112): host-evaluated kernels only
+                n_pts = _device.num_points(X)
+                dt = _device.common_dtype(*_device.tree_leaves(X))
+            else:
+                P = _device.points(X, limit=False)
+                n_pts, dt = P.shape[0], P.dtype
+            mean_value = means.evaluate_mean(self.mean_function, X, n_pts, dt)
         mean_value = np.asarray(mean_value)
         if mean_value.dtype.kind != "f":
             mean_value = mean_value.astype(np.float64)
@@ -186,9 +191,8 @@ class GaussianProcess:
                 kernel = self.kernel
             mean_value = self._kernel_matvec(kernel, X_test, alpha)
             if include_mean:
-                P = _device.points(X_test, self.dtype, limit=False)
                 mean_value = mean_value + means.evaluate_mean(self.mean_function, X_test,
-                                                              P.shape[0], self.dtype)
+                                                              _device.num_points(X_test), self.dtype)
         return alpha, log_prob, np.asarray(mean_value, dtype=self.dtype)
 
     def _kernel_matvec(self, kernel, X_out, alpha):
@@ -201,8 +205,12 @@ class GaussianProcess:
                   include_mean: bool = True, kernel: kernels.Kernel | None = None):
         """Condition the model on observed data ``y``; returns ``ConditionResult``."""
         if X_test is not None:
-            a, b = np.asarray(self.X), np.asarray(X_test)
-            if not (a.ndim == b.ndim and a.shape[1:] == b.shape[1:]):
+            if _device.is_tree(self.X) or _device.is_tree(X_test):
+                same = _device.tree_structure(self.X) == _device.tree_structure(X_test)
+            else:
+                a, b = np.asarray(self.X), np.asarray(X_test)
+                same = a.ndim == b.ndim and a.shape[1:] == b.shape[1:]
+            if not same:
                 raise ValueError(
                     "`X_test` must have the same tree structure as the input `X`, "
                     "and all but the leading dimension must have matching sizes")

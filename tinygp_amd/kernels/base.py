@@ -70,8 +70,10 @@ class Kernel:
         through; :mod:`tinygp_amd.transforms` fold their input map into the coordinates.
         Raises ``NotImplementedError`` (:class:`tinygp_amd._device.DeviceLimit` for inputs beyond the device
         evaluator's limits) when the kernel has to be evaluated on the host instead."""
+        if _device.is_tree(X):
+            raise _device.DeviceLimit("pytree inputs are evaluated on the host (kernels.Custom / evaluate())")
         prog = self.program()
-        if not isinstance(X, (dict, list, tuple)) and np.ndim(X) == 2 and np.shape(X)[1] > _device.MAX_DIM:
+        if np.ndim(X) == 2 and np.shape(X)[1] > _device.MAX_DIM:
             raise _device.DeviceLimit(f"D = {np.shape(X)[1]} input dimensions > {_device.MAX_DIM}")
         return prog, X
 
@@ -128,8 +130,8 @@ class Kernel:
         if type(self).evaluate is Kernel.evaluate:
             raise NotImplementedError(
                 f"{type(self).__name__} has neither a device program nor an evaluate() method")
-        A, B = np.asarray(X1), np.asarray(X2)
-        K = np.asarray([[self.evaluate(a, b) for b in B] for a in A])
+        B = list(_device.iter_points(X2))
+        K = np.asarray([[self.evaluate(a, b) for b in B] for a in _device.iter_points(X1)])
         if K.ndim != 2:
             raise ValueError(
                 "Invalid kernel shape: "
@@ -141,7 +143,7 @@ class Kernel:
         if type(self).evaluate is Kernel.evaluate and type(self).evaluate_diag is Kernel.evaluate_diag:
             raise NotImplementedError(
                 f"{type(self).__name__} has neither a device program nor an evaluate() method")
-        k = np.asarray([self.evaluate_diag(x) for x in np.asarray(X)])
+        k = np.asarray([self.evaluate_diag(x) for x in _device.iter_points(X)])
         if k.ndim != 1:
             raise ValueError(
                 "Invalid kernel diagonal shape: "

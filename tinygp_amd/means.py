@@ -38,7 +38,9 @@ def evaluate_mean(mean: MeanBase, X, n: int, dtype) -> np.ndarray:
         return np.broadcast_to(np.asarray(mean.value, dtype=dtype), (n,) + np.shape(mean.value)).copy()
     if isinstance(mean, Conditioned):
         return mean.batch(X)
-    vals = [mean(x) for x in np.asarray(X)]
+    from tinygp_amd import _device
+
+    vals = [mean(x) for x in _device.iter_points(X)]
     return np.asarray(vals, dtype=np.result_type(dtype, np.asarray(vals).dtype) if vals else dtype)
 
 

@@ -54,8 +54,13 @@ class DirectSolver(Solver):
             self._prog, Xdev = kernel._lower(X)
         except NotImplementedError:
             self._prog, Xdev = None, X  # e.g. kernels.Conditioned: needs covariance=
-        dt = _device.common_dtype(np.asarray(X), noise_diag, covariance)
-        P = _device.points(Xdev, dt, limit=False)
+        if _device.is_tree(Xdev):  # pytree input: host-evaluated kernels only (kernel._lower raised above)
+            assert self._prog is None
+            dt = _device.common_dtype(*_device.tree_leaves(Xdev), noise_diag, covariance)
+            P = np.zeros((_device.num_points(Xdev), 1), dtype=dt)
+        else:
+            dt = _device.common_dtype(np.asarray(X), noise_diag, covariance)
+            P = _device.points(Xdev, dt, limit=False)
         if P.shape[1] > _device.MAX_DIM:
             # beyond the device evaluator (kernel._lower raised DeviceLimit above): every kernel matrix of this
             # solver comes from the host; the device never reads the coordinates -- it gets a 1-D placeholder
