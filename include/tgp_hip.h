@@ -120,7 +120,8 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
  *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming
  *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block
- *   "keep_grad_buffers" 1: tgp_solver_grad keeps its two N^2 work matrices between calls */
+ *   "keep_grad_buffers" 1: tgp_solver_grad keeps its (N + 128) x N work matrix between calls whatever its
+ *                       size (default: kept up to 4 GiB, released at once above) */
 int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* old);
 int tgp_ctx_get_option(tgp_ctx* ctx, const char* key, int64_t* value);
 /* name (<=255 chars), CU count, memory bytes, clock kHz of the ctx's device */

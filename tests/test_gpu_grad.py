@@ -101,3 +101,58 @@ def test_grad_larger_problem_and_gradient_step():
     lpd = GaussianProcess(build(kernels, theta), X, diag=0.01 + 1e-7).log_probability(y)
     lmd = GaussianProcess(build(kernels, theta), X, diag=0.01 - 1e-7).log_probability(y)
     np.testing.assert_allclose(np.sum(g["noise_diag"]), (lpd - lmd) / 2e-7, rtol=1e-4)
+
+
+@pytest.mark.parametrize("n,dtype", [(640, "float64"), (1400, "float64"), (3000, "float64"), (1400, "float32")],
+                         ids=lambda v: str(v))
+def test_grad_block_structures_of_the_inverse(n, dtype):
+    """K^-1 comes from L^-1 by halves over aligned blocks of 1, 2, 4, ... tiles (spd_inverse_lower): 5, 11 and 24
+    tiles exercise a lone block, a short second block and several full pairs per level.  Kernel-parameter sums
+    weight EVERY entry of K^-1 (amplitude: with K itself; scale: with r^2 K), the noise gradient reads its diagonal.
+    Tolerances as above in fp64; fp32 at 2e-3 of the largest component (K^-1 in fp32 at cond ~ 1e3)."""
+    rng = np.random.default_rng(n)
+    X = np.sort(rng.uniform(0, n / 40.0, n)).astype(dtype)
+    y = (np.sin(X) + 0.1 * rng.normal(size=n)).astype(dtype)
+    diag = rng.uniform(0.05, 0.15, n).astype(dtype)
+    theta0 = np.array([1.7, 0.9])
+    build = lambda k, t: t[0] * k.ExpSquared(t[1])  # noqa: E731
+    gp = GaussianProcess(build(kernels, theta0), X, diag=diag)
+    ll, g = gp.log_probability_and_grad(y)
+    assert gp.solver.info == 0 and np.isfinite(ll)
+    want_ll, want_g, want_noise, want_alpha = grad_np.log_probability_and_grad(
+        lambda t: build(o, t), theta0, X.astype(np.float64), diag.astype(np.float64), y.astype(np.float64))
+    tol = 2e-6 if dtype == "float64" else 2e-3
+    np.testing.assert_allclose(ll, want_ll, rtol=1e-8 if dtype == "float64" else 5e-4)
+    np.testing.assert_allclose(g["kernel"], want_g, rtol=tol, atol=tol * np.abs(want_g).max())
+    np.testing.assert_allclose(g["noise_diag"], want_noise, rtol=tol, atol=tol * np.abs(want_noise).max())
+
+
+def test_grad_at_n65536_matches_a_central_difference():
+    """The gradient at N = 65 536 (one (N + 128) x N work matrix beside the factor: 2 x 34 GB): the directional
+    derivative along the kernel-parameter gradient against a central difference of `log_probability` with the
+    step h = 1e-3 (log-probabilities of ~1e5 carry ~1e-8 relative rounding: h = 1e-5 would leave three digits), at
+    rtol 2e-3; and the sum of the noise gradient against the derivative with respect to a scalar `diag` (h = 1e-5)."""
+    from tinygp_amd import synthetic
+
+    n = 65536
+    X, y = synthetic.make_inputs(n, 1)
+    theta = np.array([2.0, 2.0])
+    build = lambda k, t: t[0] * k.ExpSquared(t[1])  # noqa: E731
+
+    def logp(t, diag=0.01):
+        gp = GaussianProcess(build(kernels, t), X, diag=diag)
+        v = gp.log_probability(y)
+        del gp
+        return v
+
+    gp = GaussianProcess(build(kernels, theta), X, diag=0.01)
+    ll, g = gp.log_probability_and_grad(y)
+    del gp
+    assert np.isfinite(ll)
+    gk = np.asarray(g["kernel"])
+    d = gk / np.linalg.norm(gk)
+    h = 1e-3
+    np.testing.assert_allclose((logp(theta + h * d) - logp(theta - h * d)) / (2 * h), np.linalg.norm(gk), rtol=2e-3)
+    hd = 1e-5
+    np.testing.assert_allclose(np.sum(g["noise_diag"]), (logp(theta, 0.01 + hd) - logp(theta, 0.01 - hd)) / (2 * hd),
+                               rtol=2e-3)

@@ -67,8 +67,7 @@ struct tgp_solver {
   void* vec2 = nullptr;
   void* resid = nullptr;  // resident residual (tgp_solver_set_resid)
   void* scratch = nullptr;  // per-solver workspace (multi-RHS / conditional products)
-  void* Minv = nullptr;     // L^-T (gradient path), npad x npad, allocated on first use
-  void* Kinv = nullptr;     // K^-1 lower tiles (gradient path)
+  void* Minv = nullptr;     // gradient path: (npad + 128) x npad, L^-1 in both orientations, then K^-1 (lower tiles at +128)
   void* winv = nullptr;     // inverses of the 128 x 128 diagonal blocks (streaming forward solve), lazy
   bool winv_valid = false;
   size_t scratch_bytes = 0;
@@ -533,7 +532,7 @@ int tgp_solver_destroy(tgp_solver* s) {
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
   }
-  void* bufs[] = {s->X, s->diag, s->A, s->dinv, s->vec, s->vec2, s->resid, s->scratch, s->Minv, s->Kinv, s->winv};
+  void* bufs[] = {s->X, s->diag, s->A, s->dinv, s->vec, s->vec2, s->resid, s->scratch, s->Minv, s->winv};
   for (void* b : bufs)
     if (b) hipFree(b);
   delete s;
@@ -860,33 +859,25 @@ int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, doub
   TGP_ARG_CHECK(logprob && grad_params, "null output pointer");
   tgp_ctx* ctx = s->ctx;
   const size_t es = esize(s->dtype);
-  const size_t mat = size_t(s->npad) * s->npad * es;
-  // Two more N_pad^2 matrices (L^-T and K^-1).  They are released again below unless the
-  // context option "keep_grad_buffers" is set (an optimiser loop at moderate N), and always
-  // on failure: an out-of-memory here must not pin 2/3 of the device for the solver's lifetime.
+  const int64_t ldk = s->npad + TILE;
+  const size_t mat = size_t(ldk) * s->npad * es;
+  // ONE more matrix of (N_pad + 128) x N_pad: L^-1 in both orientations, then K^-1 in the lower one's place
+  // (spd_inverse_lower).  Released again below unless the context option "keep_grad_buffers" is set (an optimiser
+  // loop at moderate N), and always on failure: an out-of-memory here must not pin the device for the solver's
+  // lifetime.
   auto release = [&]() {
     if (s->Minv) (void)hipFree(s->Minv);
-    if (s->Kinv) (void)hipFree(s->Kinv);
-    s->Minv = s->Kinv = nullptr;
+    s->Minv = nullptr;
   };
-  auto alloc = [&](void** p) -> int {
-    if (*p) return TGP_OK;
-    hipError_t e = hipMalloc(p, mat);
+  if (!s->Minv) {
+    hipError_t e = hipMalloc(&s->Minv, mat);
     if (e != hipSuccess) {
-      *p = nullptr;
+      s->Minv = nullptr;
       (void)hipGetLastError();
-      set_error("gradient needs two more %lld x %lld work matrices (%.1f GB each) and the device "
-                "is out of memory: %s", (long long)s->npad, (long long)s->npad, double(mat) / 1e9,
-                hipGetErrorString(e));
+      set_error("the gradient needs one %lld x %lld work matrix (%.1f GB) and the device is out of memory: %s",
+                (long long)ldk, (long long)s->npad, double(mat) / 1e9, hipGetErrorString(e));
       return e == hipErrorOutOfMemory ? TGP_E_NOMEM : TGP_E_HIP;
     }
-    return TGP_OK;
-  };
-  int ast = alloc(&s->Minv);
-  if (ast == TGP_OK) ast = alloc(&s->Kinv);
-  if (ast != TGP_OK) {
-    release();
-    return ast;
   }
   int gst = logprob_device(s, resid_host, logprob);  // s->vec = L^-1 r
   if (gst < 0) {
@@ -900,13 +891,12 @@ int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, doub
     T* alpha = (T*)s->vec;
     TGP_TRY(trsv<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, 1, alpha,
                     (ctx->stream_trsv != 0 && s->info == 0 && s->winv_valid) ? (const T*)s->winv : (const T*)nullptr));  // alpha = K^-1 r
-    TGP_TRY(tri_inverse_t<T>(ctx, s->npad, L, s->npad, (const T*)s->dinv, (T*)s->Minv, s->npad));
-    // K^-1 = L^-T L^-1 = M M^T, lower tiles, k-loop from the row tile (M upper triangular)
-    TGP_TRY(launch_gemm_nt<T>(ctx, ctx->stream, s->npad, s->npad, s->npad, (const T*)s->Minv, s->npad,
-                              (const T*)s->Minv, s->npad, (T*)s->Kinv, s->npad, 1, 5, 1));
+    TGP_TRY(ensure_winv<T>(s));
+    TGP_TRY(spd_inverse_lower<T>(ctx, s->npad, L, s->npad, (const T*)s->winv, (T*)s->Minv, ldk));
+    const T* Kinv = (const T*)s->Minv + TILE;  // lower tiles, leading dimension ldk
     int fleaf = -1, fkonst = -1;
     const int fast = launch_kgrad_fast<T>(ctx, s->kp, s->n, s->d, (const T*)s->X, (const T*)alpha,
-                                          (const T*)s->Kinv, s->npad, ctx->d_scal + 2, &fleaf, &fkonst);
+                                          Kinv, ldk, ctx->d_scal + 2, &fleaf, &fkonst);
     if (fast < 0) return fast;
     if (fast == 1) {  // d_scal[2] = d/d constant, d_scal[3] = d/d scale
       if (fkonst >= 0)
@@ -921,13 +911,13 @@ int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, doub
       const int nparam = (op == TGP_K_ESS || op == TGP_K_RQ) ? 2 : 1;
       for (int q = 0; q < nparam; ++q) {
         TGP_TRY(launch_kgrad<T>(ctx, s->kp, i, q, s->n, s->d, (const T*)s->X, (const T*)alpha,
-                                (const T*)s->Kinv, s->npad, ctx->d_scal + 2));
+                                Kinv, ldk, ctx->d_scal + 2));
         TGP_HIP_TRY(hipMemcpyAsync(&g[size_t(2 * i + q)], ctx->d_scal + 2, sizeof(double),
                                    hipMemcpyDeviceToHost, ctx->stream));
       }
     }
     if (grad_noise_host) {
-      TGP_TRY(launch_noise_grad<T>(ctx, s->n, (const T*)alpha, (const T*)s->Kinv, s->npad, (T*)s->vec2));
+      TGP_TRY(launch_noise_grad<T>(ctx, s->n, (const T*)alpha, Kinv, ldk, (T*)s->vec2));
       TGP_HIP_TRY(hipMemcpyAsync(grad_noise_host, s->vec2, size_t(s->n) * es, hipMemcpyDeviceToHost,
                                  ctx->stream));
     }
@@ -939,7 +929,10 @@ int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, doub
     set_error("hipStreamSynchronize failed in tgp_solver_grad");
     gst = TGP_E_HIP;
   }
-  if (gst < 0 || ctx->keep_grad_buffers == 0) {
+  // kept for the next call when it is small (an optimiser loop: allocating and freeing 2 GB cost more than the 52 ms
+  // of the gradient itself on every other call) or when the option says so; a large one goes back at once
+  const bool keep = ctx->keep_grad_buffers != 0 || mat <= (size_t(4) << 30);
+  if (gst < 0 || !keep) {
     (void)hipStreamSynchronize(ctx->stream);
     release();
   }

@@ -1473,49 +1473,99 @@ int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, c
   return TGP_OK;
 }
 
-// M (n x n, column-major, zero-initialised by the caller) <- L^-T (upper triangular).
-// Same right-sided sweep as trsm_right_lt applied to B = I, with the row range clipped:
-// column block j of L^-T is non-zero only in rows < (j+1)*128, so every solve / update
-// touches just the rows that can be non-zero -> n^3/3 flops instead of n^3.
+// ---------------------------------------------------------------------------------------
+// K^-1 from the factor (gradient path):  L^-1 by halves, then K^-1 = L^-T L^-1.
+//
+// Round 1-2 swept the right-sided solve over the identity (128 dependent hops of a 128-column solve + a K = 128
+// update + a K = 1024 update per panel, one stream: 28.7 ms at N = 16 384) and formed M M^T in a second N^2 buffer
+// (33.1 ms: tiles of different k-ranges shared nothing through the L2).  Round 3:
+//
+//   L = [A 0; B C]  ->  L^-1 = [A^-1 0; -C^-1 B A^-1  C^-1],
+//
+// bottom-up over aligned blocks of h = 1, 2, 4, ... tiles: the diagonal 128 x 128 inverses are the W_b of the
+// streaming solve (winv_kernel), and every level is TWO batched products over all its block pairs at once -- no
+// dependent chain at all, 2 log2(N/128) GEMM launches in total, all of them on the 128 x 128-tile MFMA kernel:
+//   R = M_A B^T          (M_A = A^-T upper triangular: k from the row tile on, walked from the end),
+//   Z = X_C R^T          (X_C = C^-1 lower triangular: k up to the row tile),        X_21 = -Z,  M_12 = -Z^T.
+// Both orientations of L^-1 are kept -- the NT kernel wants its triangular operand as "rows x k" -- in ONE buffer S
+// of (n + 128) x n:  M = L^-T (upper tiles, diagonal tiles included) at S[a, b],  X = L^-1 (lower tiles) at
+// S[a + 128, b]: the two triangles do not overlap, R lives where M_12 will go, and the mirror pass (memory-bound,
+// 0.1 ms per level) writes -Z back and -Z^T across.  K^-1 = M M^T then goes to X's place (lower tiles; X is dead),
+// so the caller's K^-1 is (S + 128, ld = n + 128) and the gradient needs ONE extra matrix, not two.
+// ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void set_identity_kernel(int64_t n, T* __restrict__ M, int64_t ld) {
-  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  if (i < n) M[i * ld + i] = T(1);
+__global__ __launch_bounds__(256) void tri_seed_kernel(const T* __restrict__ winv, const T* __restrict__ winvT,
+                                                      T* __restrict__ S, int64_t ld) {
+  const int b = blockIdx.x;
+  T* Mb = S + int64_t(b) * 128 * ld + int64_t(b) * 128;  // M_bb = W_b^T; X_bb = W_b sits 128 rows lower
+  const T* w = winv + int64_t(b) * 16384;
+  const T* wt = winvT + int64_t(b) * 16384;
+  for (int e = threadIdx.x; e < 16384; e += 256) {
+    const int r = e & 127, c = e >> 7;
+    Mb[int64_t(c) * ld + r] = wt[e];
+    Mb[int64_t(c) * ld + 128 + r] = w[e];
+  }
+}
+
+// Z (rows x cols, at Zb) <- -Z and Mt (cols x rows, at Mb) <- -Z^T, 64 x 64 per workgroup, blockIdx.y = batch
+template <typename T>
+__global__ __launch_bounds__(256) void tri_mirror_kernel(T* __restrict__ Zb, T* __restrict__ Mb, int64_t ld,
+                                                        int rt, int64_t stride) {
+  __shared__ T t[64][65];
+  T* Z = Zb + int64_t(blockIdx.y) * stride;
+  T* M = Mb + int64_t(blockIdx.y) * stride;
+  const int bi = blockIdx.x % rt, bj = blockIdx.x / rt;
+  const int r = threadIdx.x & 63, c4 = threadIdx.x >> 6;
+  T* z = Z + int64_t(bj) * 64 * ld + int64_t(bi) * 64;
+#pragma unroll 4
+  for (int c = c4; c < 64; c += 4) {
+    const T v = -z[int64_t(c) * ld + r];
+    z[int64_t(c) * ld + r] = v;
+    t[c][r] = v;
+  }
+  __syncthreads();
+  T* m = M + int64_t(bi) * 64 * ld + int64_t(bj) * 64;  // M(col, row) = Z(row, col)
+#pragma unroll 4
+  for (int c = c4; c < 64; c += 4) m[int64_t(c) * ld + r] = t[r][c];
 }
 
 template <typename T>
-int tri_inverse_t(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* dinv, T* M,
-                  int64_t ldm) {
-  TGP_ARG_CHECK(n % TILE == 0, "tri_inverse_t: n must be a multiple of %d", TILE);
+int spd_inverse_lower(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* winv, T* S, int64_t lds) {
+  TGP_ARG_CHECK(n % TILE == 0 && lds >= n + TILE, "spd_inverse_lower: n a multiple of %d and lds >= n + %d", TILE,
+                TILE);
+  if (n == 0) return TGP_OK;
   hipStream_t st = ctx->stream;
-  TGP_HIP_TRY(hipMemsetAsync(M, 0, size_t(ldm) * size_t(n) * sizeof(T), st));
-  hipLaunchKernelGGL((set_identity_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                     n, M, ldm);
-  int64_t NB = ctx->nb_outer;
-  if (NB < TILE) NB = TILE;
-  NB = NB / TILE * TILE;
-  for (int64_t k0 = 0; k0 < n; k0 += NB) {
-    const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
-    for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
-      const int64_t mr = j0 + TILE;  // rows that can be non-zero in column block j0
-      TGP_TRY(launch_trsm<T>(ctx, st, mr, L + j0 * ldl + j0, ldl, dinv + (j0 / TILE) * 2048,
-                             M + j0 * ldm, ldm));
-      const int64_t nc = (k0 + kb) - (j0 + TILE);
-      if (nc > 0)
-        TGP_TRY(launch_gemm_nt<T>(ctx, st, mr, nc, TILE, M + j0 * ldm, ldm,
-                                  L + j0 * ldl + j0 + TILE, ldl, M + (j0 + TILE) * ldm, ldm, 0, 0, 1));
+  const int64_t nt = n / TILE;
+  hipLaunchKernelGGL((tri_seed_kernel<T>), dim3((unsigned)nt), dim3(256), 0, st, winv, winv + nt * 16384, S, lds);
+  T* X = S + TILE;  // L^-1, lower tiles
+  for (int64_t h = 1; h < nt; h *= 2) {
+    const int64_t hw = h * TILE, pair = 2 * hw;
+    const int64_t nfull = nt / (2 * h), rem = nt - nfull * 2 * h;
+    // the full pairs in one batch, a last pair with a shorter second block on its own
+    for (int part = 0; part < 2; ++part) {
+      const int64_t batch = part == 0 ? nfull : 1;
+      const int64_t h2w = part == 0 ? hw : (rem - h) * TILE;
+      if (batch == 0 || h2w <= 0) continue;
+      const int64_t r0 = part == 0 ? 0 : nfull * pair;
+      const int64_t sS = pair * (lds + 1), sL = pair * (ldl + 1);
+      T* R = S + r0 + (r0 + hw) * lds;          // hw x h2w, where M_12 goes
+      T* Z = X + (r0 + hw) + r0 * lds;          // h2w x hw, where X_21 goes
+      TGP_TRY(launch_gemm_tri<T>(ctx, st, hw, h2w, hw, S + r0 * (lds + 1), lds, L + (r0 + hw) + r0 * ldl, ldl, R, lds,
+                                 0, 1 | 4 | 16, int(batch), sS, sL, sS));
+      TGP_TRY(launch_gemm_tri<T>(ctx, st, h2w, hw, h2w, X + (r0 + hw) * (lds + 1), lds, R, lds, Z, lds, 0, 1 | 8,
+                                 int(batch), sS, sS, sS));
+      hipLaunchKernelGGL((tri_mirror_kernel<T>), dim3((unsigned)((h2w / 64) * (hw / 64)), (unsigned)batch), dim3(256),
+                         0, st, Z, R, lds, int(h2w / 64), sS);
     }
-    const int64_t next = k0 + kb, nr = n - next;
-    if (nr > 0)
-      TGP_TRY(launch_gemm_nt<T>(ctx, st, next, nr, kb, M + k0 * ldm, ldm, L + k0 * ldl + next, ldl,
-                                M + next * ldm, ldm, 0, 0, 1));
   }
+  // K^-1 = M M^T, lower tiles, into X's place
+  TGP_TRY(launch_gemm_tri<T>(ctx, st, n, n, n, S, lds, S, lds, X, lds, 1, 1 | 4 | 16, 1, 0, 0, 0));
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
 
 #define TGP_INST(T)                                                                              \
-  template int tri_inverse_t<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, T*, int64_t);    \
+  template int spd_inverse_lower<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, T*, int64_t); \
   template int launch_potf2<T>(tgp_ctx*, hipStream_t, T*, int64_t, T*, int32_t*, int32_t,       \
                                const T*, int64_t);       \
   template int launch_trsm<T>(tgp_ctx*, hipStream_t, int64_t, const T*, int64_t, const T*, T*,   \

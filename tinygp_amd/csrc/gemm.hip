@@ -76,6 +76,12 @@ struct GemmArgs {
   int split_first, split_s, ngrid;
   T* ws;
   int* cnt;
+  // ROLE 3 (products with a triangular operand: L^-T by halves, K^-1 = M M^T): `batch` independent problems, operand
+  // q at base + q * s{A,B,C}; mode bit3: A lower triangular, k ends with the ROW tile; mode bit4: the k-range is
+  // walked from its END (tiles whose ranges end together -- bit2 -- then stream the same operand slices at the same
+  // time); workgroup ids enumerate 8 x 8 PATCHES of tiles, one patch per XCD at a time (see the kernel).
+  int batch;
+  int64_t sA, sB, sC;
 };
 
 // Linear workgroup id -> (ti, tj).  Tiles are enumerated column by column (tj major) so
@@ -152,6 +158,43 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   int ti, tj, gt;
+  const T* gA = g.A;
+  const T* gB = g.B;
+  T* gC = g.C;
+  if constexpr (ROLE == 3) {
+    // Products with a triangular operand have k-ranges that differ from tile row to tile row: in the column-major
+    // tile order the 64 tiles an XCD runs at a time are 64 different row tiles -- 65 operand slices per k-step for
+    // 64 tiles, nothing shared through the L2 -- and K^-1 = M M^T ran at 44 TFLOP/s on the fabric (33 ms at
+    // N = 16 384).  Here the workgroup id (dispatched in order, id % 8 = XCD) names slot s of the idx-th 8 x 8 PATCH
+    // of that XCD: its 64 resident tiles share 8 + 8 operand slices per k-step, and with bit4 their k-ranges END
+    // together.  Patches in order of decreasing k-range (longest first); slots outside the matrix leave at once.
+    const int xcd = tile & 7, idx = tile >> 3, slot = idx & 63;
+    const int pk = (idx >> 6) * 8 + xcd;
+    const int ptm = (g.tm + 7) >> 3, ptn = (g.tn + 7) >> 3;
+    const int pps = g.lower ? (ptm * (ptm + 1)) / 2 : ptm * ptn;
+    // the batch index runs fastest: the XCDs are dealt patches in order of decreasing k-range whatever the batch
+    // (problem by problem, two problems of 4 x 4 patches put both long rows on XCDs 0-3: 45 instead of 60 TFLOP/s)
+    const int pl = pk / g.batch, q = pk - pl * g.batch;
+    if (pl >= pps) return;
+    int Pi, Pj;
+    if (g.lower) {  // patch rows top down, row Pi holds patches 0..Pi
+      Pi = int((sqrtf(8.0f * float(pl) + 1.0f) - 1.0f) * 0.5f);
+      while (Pi > 0 && (Pi * (Pi + 1)) / 2 > pl) --Pi;
+      while (((Pi + 1) * (Pi + 2)) / 2 <= pl) ++Pi;
+      Pj = pl - (Pi * (Pi + 1)) / 2;
+    } else {
+      Pi = pl / ptn;
+      Pj = pl - Pi * ptn;
+      if (g.mode & 8) Pi = ptm - 1 - Pi;
+    }
+    ti = Pi * 8 + (slot & 7);
+    tj = Pj * 8 + (slot >> 3);
+    if (ti >= g.tm || tj >= g.tn || (g.lower && ti < tj)) return;
+    gt = tj;
+    gA += int64_t(q) * g.sA;
+    gB += int64_t(q) * g.sB;
+    gC += int64_t(q) * g.sC;
+  } else
   if (g.dG > 0) {
     decode_tile_dist<T>(bid, g, ti, tj, gt);
   } else {
@@ -164,12 +207,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
   const int64_t i0 = int64_t(ti) * BM, j0 = int64_t(tj) * BN;
 
   // mode 3 (TRMM): B = L is lower triangular, so column tile tj only needs k < (tj+1)*BN
-  const int nkt = (g.mode & 2) ? ((g.k < (tj + 1) * BN ? g.k : (tj + 1) * BN) / BK) : g.k / BK;
+  int nkt = (g.mode & 2) ? ((g.k < (tj + 1) * BN ? g.k : (tj + 1) * BN) / BK) : g.k / BK;
+  // ROLE 3, mode bit 3: A lower triangular -- row tile ti only needs k < (ti+1)*BM
+  if (ROLE == 3 && (g.mode & 8)) nkt = (g.k < (ti + 1) * BM ? g.k : (ti + 1) * BM) / BK;
   // mode bit 2: rows of an upper-triangular operand are zero left of the diagonal, so a
   // lower tile (ti >= tj) of M M^T only needs k >= ti*BM
   const int kt0 = (g.mode & 4) ? (ti * BM) / BK : 0;
+  const bool krev = ROLE == 3 && (g.mode & 16);
   const int lrow = lane & 15, lk = lane >> 4;
-  T* Cb = g.C + (j0 + wc * 64) * g.ldc + i0 + wr * 64;
+  T* Cb = gC + (j0 + wc * 64) * g.ldc + i0 + wr * 64;
 
   if constexpr (sizeof(T) == 8) {
     // fp64: v_mfma_f64_4x4x4_4b_f64 (16 cycles, measured 73-76 TFLOP/s) instead of
@@ -207,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     // C addresses as a wave-uniform base (SGPRs) + four loop-invariant 32-bit lane offsets: no
     // per-chunk address registers
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    const char* Cu = reinterpret_cast<const char*>(g.C + (j0 + (wu & 1) * 64) * g.ldc + i0 + (wu >> 1) * 64);
+    const char* Cu = reinterpret_cast<const char*>(gC + (j0 + (wu & 1) * 64) * g.ldc + i0 + (wu >> 1) * 64);
     uint32_t voff[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) voff[t] = uint32_t((int64_t(4 * lq + lk) * g.ldc + rot[t]) * 8);
@@ -219,11 +265,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     // the explicit one in front of the barrier that ends the k-tile.
     const uint32_t lds_a = uint32_t(size_t((__attribute__((address_space(3))) T*)(&sA[0][0]))) + uint32_t(wu * LDS_LD * 8);
     const uint32_t lds_b = uint32_t(size_t((__attribute__((address_space(3))) T*)(&sB[0][0]))) + uint32_t(wu * LDS_LD * 8);
-    const T* Au = g.A + i0;                 // wave-uniform row bases; the lane adds 16 l bytes
-    const T* Bu = g.B + int64_t(gt) * BN;
+    const T* Au = gA + i0;                 // wave-uniform row bases; the lane adds 16 l bytes
+    const T* Bu = gB + int64_t(gt) * BN;
     const uint32_t lane16 = uint32_t(lane) * 16u;
     auto issue_tile = [&](int kt_, int buf_) {
-      const int64_t kg = int64_t(kt_) * BK + wu;
+      const int64_t kg = int64_t(krev ? kbeg + kend - 1 - kt_ : kt_) * BK + wu;
 #pragma unroll
       for (int r = 0; r < BK / 4; ++r) {
         const T* ap = Au + (kg + 4 * r) * g.lda;
@@ -417,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     const int l32 = lane & 31, lh = lane >> 5;
     f16v acc[2][2];  // [a: 32 columns][b: 32 rows] of the wave's 64 x 64
     // this lane's C entries: row i0 + wr*64 + b*32 + l32, column j0 + wc*64 + a*32 + 8 (r >> 2) + 4 lh + (r & 3)
-    T* cbase = g.C + (j0 + (wu & 1) * 64 + 4 * lh) * g.ldc + i0 + (wu >> 1) * 64 + l32;
+    T* cbase = gC + (j0 + (wu & 1) * 64 + 4 * lh) * g.ldc + i0 + (wu >> 1) * 64 + l32;
     auto centry = [&](int a, int b, int r) -> T* {
       return cbase + int64_t(a * 32 + 8 * (r >> 2) + (r & 3)) * g.ldc + b * 32;
     };
@@ -443,10 +489,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     const uint32_t vob = uint32_t(lh) * uint32_t(g.ldb) * 4u + uint32_t(l32) * 16u;
     const uint32_t lds_a = uint32_t(size_t((__attribute__((address_space(3))) T*)(&sAm[0]))) + uint32_t(wu * 2 * BM * 4);
     const uint32_t lds_b = uint32_t(size_t((__attribute__((address_space(3))) T*)(&sBm[0]))) + uint32_t(wu * 2 * BM * 4);
-    const T* Au = g.A + i0;
-    const T* Bu = g.B + int64_t(gt) * BN;
+    const T* Au = gA + i0;
+    const T* Bu = gB + int64_t(gt) * BN;
     auto issue_tile = [&](int kt_, int stage) {
-      const int64_t kg = int64_t(kt_) * BK + 2 * wu;
+      const int64_t kg = int64_t(krev ? kt0 + nkt - 1 - kt_ : kt_) * BK + 2 * wu;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const T* ap = Au + (kg + 8 * r) * g.lda;
@@ -821,6 +867,7 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   g.skip00 = 0;
   g.dG = g.dr = g.dl0 = g.dnbt = 0;
   g.split_first = 0; g.split_s = 1; g.ngrid = 0; g.ws = nullptr; g.cnt = nullptr;
+  g.batch = 1; g.sA = g.sB = g.sC = 0;
   TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");
   // short-K updates, and (role 4) a latency-bound update with too few big tiles to fill the chip
   if ((((role == 1 || role == 3) && k <= 256) || role == 4) && (mode == 0 || mode == 1)) {
@@ -884,11 +931,46 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   // (Measured and removed, profiles/r02_r: the last, partly filled round of tiles on the 64x64-tile
   // kernel -- four workgroups per tile behind the full rounds.  Its k-loop of 64 short k-tiles takes
   // as long as the 245-us round it replaces: 4.43 vs 4.40 ms on a 16384^2 lower update.)
+  // (Measured and removed, profiles/r03_j: the 8 x 8 patch order of ROLE 3 on the trailing update -- FETCH_SIZE per
+  // launch -32 %, the factorisation 4 % SLOWER at N = 16 384 and 1 % at 65 536: half-empty diagonal patches unbalance
+  // the XCDs; and the run-time flag alone cost the fp32 kernel 1.3 %.)
   const unsigned grid = persistent_grid(ctx, g.nblk, reserve);
   if (role == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3(grid), dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3(grid), dim3(256), 0, st, g);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+// `batch` independent products C_q = A_q B_q^T (operand q at base + q * s{A,B,C}) with a triangular A, on the
+// 128 x 128-tile kernel in its patch order (ROLE 3):
+//   mode bit2: A upper triangular (k from the row tile on), bit3: A lower triangular (k up to the row tile),
+//   bit4: k walked from the end; always C = A B^T (bit0).  lower: only tiles ti >= tj (m == n).
+template <typename T>
+int launch_gemm_tri(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k, const T* A, int64_t lda,
+                    const T* B, int64_t ldb, T* C, int64_t ldc, int lower, int mode, int batch, int64_t sA,
+                    int64_t sB, int64_t sC) {
+  TGP_ARG_CHECK(m % BM == 0 && n % BN == 0 && k % BK == 0 && k > 0 && batch >= 1 && (mode & 1) && !(mode & 2) &&
+                    (!lower || m == n),
+                "gemm_tri: bad shape or mode (m, n, k = %lld, %lld, %lld)", (long long)m, (long long)n, (long long)k);
+  TGP_ARG_CHECK(!ctx->trace, "gemm_tri is not part of the traced schedule");
+  if (m == 0 || n == 0) return TGP_OK;
+  GemmArgs<T> g;
+  g.skip00 = 0;
+  g.dG = g.dr = g.dl0 = g.dnbt = 0;
+  g.split_first = 0; g.split_s = 1; g.ngrid = 0; g.ws = nullptr; g.cnt = nullptr;
+  g.A = A; g.B = B; g.C = C;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.tm = int(m / BM); g.tn = int(n / BN);
+  g.k = int(k); g.lower = lower; g.mode = mode;
+  g.batch = batch; g.sA = sA; g.sB = sB; g.sC = sC;
+  const int64_t ptm = (g.tm + 7) / 8, ptn = (g.tn + 7) / 8;
+  const int64_t patches = int64_t(batch) * (lower ? ptm * (ptm + 1) / 2 : ptm * ptn);
+  const int64_t grid = (patches + 7) / 8 * 8 * 64;
+  TGP_ARG_CHECK(grid < (int64_t(1) << 31), "gemm_tri: too many tiles");
+  g.nblk = int(grid);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, 3>), dim3(unsigned(grid)), dim3(256), 0, st, g);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -913,6 +995,7 @@ int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb
   g.k = int(k); g.lower = 1; g.mode = 0;
   g.dG = G; g.dr = rank; g.dl0 = int(l0); g.dnbt = int(nb / BN);
   g.split_first = 0; g.split_s = 1; g.ngrid = 0; g.ws = nullptr; g.cnt = nullptr;
+  g.batch = 1; g.sA = g.sB = g.sC = 0;
   int64_t total = 0;
   for (int64_t q = 0; q < nloc; ++q) {
     const int64_t g0 = ((l0 + q) * G + rank) * g.dnbt;
@@ -977,7 +1060,9 @@ int ubench_mfma(tgp_ctx* ctx, int dtype, double* tflops) {
   template int launch_gemm_nt_dist<T>(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const T*, \
                                       int64_t, T*, int64_t, int, int, int64_t, int64_t, int64_t); \
   template int launch_gemm_nt<T>(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const T*,     \
-                                 int64_t, const T*, int64_t, T*, int64_t, int, int, int);
+                                 int64_t, const T*, int64_t, T*, int64_t, int, int, int);         \
+  template int launch_gemm_tri<T>(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const T*, int64_t, const T*, \
+                                  int64_t, T*, int64_t, int, int, int, int64_t, int64_t, int64_t);
 TGP_INST(float)
 TGP_INST(double)
 #undef TGP_INST

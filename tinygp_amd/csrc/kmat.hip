@@ -197,41 +197,59 @@ __device__ __forceinline__ T leaf_fast(T r1, T r2, T p0, T p0sq) {
 }
 
 // Full interior tiles only (every row and column inside n1 x n2): no bounds checks in the loop.
+// One 128 x 128 tile per workgroup: wave w its columns 32w .. 32w + 31, lane l its rows 2l and 2l + 1 -- one 16-byte
+// store per lane and column, a wave store is the tile's whole 1-KiB column.  (Rounds 1-2: lane = one row, 64 columns,
+// 8-byte stores: 4.48 / 4.20 / 4.49 TB/s at N = 16 384 / 32 768 / 65 536; this shape 4.54 / 4.48 / 4.78.  A 512 x 32
+// shape -- 4 KiB of one matrix column per workgroup and column -- measured 3.18 / 3.97 / 4.49: profiles/r03_j.)
 template <typename T, int D, int OP, int L2>
 __global__ __launch_bounds__(256) void kmat_fast_kernel(T p0, T amp, int64_t n1, int64_t n2,
                                                         const T* __restrict__ X1,
                                                         const T* __restrict__ X2,
                                                         const T* __restrict__ diag, T* __restrict__ out,
                                                         int64_t ld, int flags, int tc0) {
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  constexpr int NCOL = 32;
+  const int cq = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int tr = blockIdx.x, tc = blockIdx.y + tc0;
   if ((flags & KMAT_LOWER) && tr < tc) return;
-  __shared__ T s2[KT * D];
-  const int64_t r0 = int64_t(tr) * KT, c0 = int64_t(tc) * KT;
-  for (int t = threadIdx.x; t < KT * D; t += 256) s2[t] = X2[c0 * D + t];
-  const int il = threadIdx.x & (KT - 1);
-  const int g = threadIdx.x >> 7;  // column half
-  const int64_t gi = r0 + il;
-  T xr[D];
-#pragma unroll
-  for (int t = 0; t < D; ++t) xr[t] = X1[gi * D + t];
-  const bool on_diag = diag != nullptr && tr == tc;
-  const T dg = on_diag ? diag[gi] : T(0);
-  const T p0sq = p0 * p0;
+  __shared__ T s2all[KT * D];
+  for (int t = threadIdx.x; t < KT * D; t += 256) s2all[t] = X2[int64_t(tc) * KT * D + t];
   __syncthreads();
-  T* o = out + (c0 + g * (KT / 2)) * ld + gi;
-  const T* sc = s2 + g * (KT / 2) * D;
-#pragma unroll 4
-  for (int c = 0; c < KT / 2; ++c) {
-    T r1 = 0, r2 = 0;
+  const T* s2 = s2all + cq * NCOL * D;
+  const int64_t c0 = int64_t(tc) * KT + cq * NCOL;
+  const int64_t gi = int64_t(tr) * KT + 2 * l;
+  T xr[2][D];
 #pragma unroll
-    for (int t = 0; t < D; ++t) {
-      const T dx = xr[t] - sc[c * D + t];
-      r1 += fabs(dx);
-      r2 += dx * dx;
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < D; ++t) xr[h][t] = X1[(gi + h) * D + t];
+  const bool on_diag = diag != nullptr && tr == tc;
+  const T dg0 = on_diag ? diag[gi] : T(0), dg1 = on_diag ? diag[gi + 1] : T(0);
+  const T p0sq = p0 * p0;
+  const int ldiag = 2 * l - cq * NCOL;  // column index (within the wave's 32) of this lane's first diagonal entry
+  T* o = out + c0 * ld + gi;
+#pragma unroll 4
+  for (int c = 0; c < NCOL; ++c) {
+    T v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      T r1 = 0, r2 = 0;
+#pragma unroll
+      for (int t = 0; t < D; ++t) {
+        const T dx = xr[h][t] - s2[c * D + t];
+        r1 += fabs(dx);
+        r2 += dx * dx;
+      }
+      v[h] = amp * leaf_fast<T, OP, L2>(r1, r2, p0, p0sq);
     }
-    T v = amp * leaf_fast<T, OP, L2>(r1, r2, p0, p0sq);
-    if (on_diag && il == g * (KT / 2) + c) v += dg;  // noise.py:77-78 fused
-    o[int64_t(c) * ld] = v;
+    if (on_diag) {  // noise.py:77-78 fused
+      if (c == ldiag) v[0] += dg0;
+      if (c == ldiag + 1) v[1] += dg1;
+    }
+    T2 pair;
+    pair.x = v[0];
+    pair.y = v[1];
+    *reinterpret_cast<T2*>(o + int64_t(c) * ld) = pair;
   }
 }
 
@@ -641,7 +659,8 @@ int launch_kmat_cols(tgp_ctx* ctx, hipStream_t st, const KProg& kp, int64_t n1, 
   // full tiles of "leaf" / "amp * leaf" programs: the straight-line kernel
   int ftr = 0, ftc = 0;
   const FastProg fp = fast_prog(kp);
-  if (fp.op >= 0 && d <= 3) {
+  // (its 16-byte stores need an even leading dimension and a 16-byte aligned matrix)
+  if (fp.op >= 0 && d <= 3 && ld % 2 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) {
     ftr = int(n1 / KT);
     ftc = int(n2 / KT);
     const int64_t fc = std::min<int64_t>(tc0 + ntc, ftc) - tc0;  // column tiles of this call that are full

@@ -99,7 +99,7 @@ struct tgp_ctx {
   int64_t profile = 0;
   int64_t first_split = 5;  // blocks of a panel after which its share of the next block-column update is issued early (0: off)
   int64_t stream_trsv = 1;  // forward solves on a resident factor: one streaming launch (0: one launch pair per block)
-  int64_t keep_grad_buffers = 0;  // tgp_solver_grad keeps its two N^2 work matrices between calls
+  int64_t keep_grad_buffers = 0;  // tgp_solver_grad keeps its (N + 128) x N work matrix between calls
   int64_t first_small_tiles = 1100;  // look-ahead block-column updates up to this many tiles use 64x64 tiles
   // panel chain as ONE launch per 128-column block (panel_step_kernel: potf2 + the rows' own pending update
   // + trsm behind a device-side flag) instead of potf2 | trsm | update of the next column block (0: the latter)
@@ -227,6 +227,12 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
                    int64_t lda, const T* B, int64_t ldb, T* C, int64_t ldc, int lower, int mode,
                    int role);
 
+// batched C_q = A_q B_q^T with a triangular A on the 128 x 128-tile kernel in patch order (gemm.hip, ROLE 3)
+template <typename T>
+int launch_gemm_tri(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k, const T* A, int64_t lda,
+                    const T* B, int64_t ldb, T* C, int64_t ldc, int lower, int mode, int batch, int64_t sA,
+                    int64_t sB, int64_t sC);
+
 template <typename T>
 int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb, int64_t k,
                         const T* P, int64_t ldp, T* Cloc, int64_t ldc, int G, int rank, int64_t l0,
@@ -269,8 +275,10 @@ int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, c
                   T* B, int64_t ldb);
 template <typename T>
 int gemv_sub(tgp_ctx* ctx, int64_t m, int64_t k, const T* P, int64_t ld, const T* x, T* y);
+// K^-1 (lower tiles) from the factor L and its 128 x 128 diagonal inverses (compute_winv), through L^-1 by halves:
+// S is ONE (n + 128) x n work matrix (lds >= n + 128); on return K^-1 is at S + 128 with leading dimension lds.
 template <typename T>
-int tri_inverse_t(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* dinv, T* M, int64_t ldm);
+int spd_inverse_lower(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* winv, T* S, int64_t lds);
 template <typename T>
 int compute_dinv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* dinv);
 
