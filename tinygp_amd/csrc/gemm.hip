@@ -303,10 +303,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
       for (int ks = 0; ks < BK / 4; ++ks) {
         double aop[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          aop[a] = pa[ks * 4 * LDS_LD + a * 16];
-          if constexpr (decltype(negated)::value) aop[a] = -aop[a];  // accumulate -A B^T
-        }
+        for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * LDS_LD + a * 16];
+        // accumulate -A B^T: the f64 MFMA's BLGP field is its NEG field (bit 0 negates A) -- no v_xor per operand
+        constexpr int NEG = decltype(negated)::value ? 1 : 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           double bop[4];
@@ -316,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
           for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              acc[a][b][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aop[a], bop[t], acc[a][b][t], 0, 0, 0);
+              acc[a][b][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aop[a], bop[t], acc[a][b][t], 0, 0, NEG);
         }
       }
       tile_landed();
@@ -509,11 +508,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
       if (kt0 + q < nkt) issue_tile(kt0 + q, q);
     // the C values are consumed HERE as far as the compiler can tell (else its waits for these loads land inside
     // the k-loop, where every iteration would drain the transfers in flight)
+    // mode 0 accumulates A B^T onto -C and stores the negative: the f32 MFMA has no NEG field, and negating the operand
+    // on its way from LDS was 16 VALU instructions per k-tile (1 024 per tile) against 128 here
     if (g.mode == 0) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(acc[a][b]));
+        for (int b = 0; b < 2; ++b) {
+          asm volatile("" : "+v"(acc[a][b]));
+          acc[a][b] = -acc[a][b];
+        }
     }
     auto kloop = [&](auto negated) {
       int stage = 0;
@@ -531,7 +535,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             aop[t] = pa[ks * 2 * BM + t * 32];
-            if constexpr (decltype(negated)::value) aop[t] = -aop[t];  // accumulate -A B^T
             bop[t] = pb[ks * 2 * BM + t * 32];
           }
 #pragma unroll
@@ -543,8 +546,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
         stage = stage == NST - 1 ? 0 : stage + 1;
       }
     };
-    if (g.mode == 0) kloop(std::true_type{});
-    else kloop(std::false_type{});
+    kloop(std::false_type{});
+    if (g.mode == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = -acc[a][b];
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -698,10 +706,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
       for (int ks = 0; ks < BK / 4; ++ks) {
         double aop[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          aop[a] = pa[ks * 4 * SM + oa[a]];
-          if constexpr (decltype(negated)::value) aop[a] = -aop[a];  // accumulate -A B^T
-        }
+        for (int a = 0; a < 2; ++a) aop[a] = pa[ks * 4 * SM + oa[a]];
+        constexpr int NEG = decltype(negated)::value ? 1 : 0;  // accumulate -A B^T through the MFMA's NEG field
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           double bop[4];
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
           for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              acc[a][b][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aop[a], bop[t], acc[a][b][t], 0, 0, 0);
+              acc[a][b][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aop[a], bop[t], acc[a][b][t], 0, 0, NEG);
         }
       }
       stage = stage == NST - 1 ? 0 : stage + 1;
