@@ -1015,8 +1015,10 @@ int tgp_solver_condition_cov(tgp_solver* s, const tgp_kop* prog, int nops, int64
       // Kss + noise - A^T A (direct.py:92,95): SYRK-shaped MFMA GEMM, K = n
       TGP_TRY(launch_kmat<T>(ctx, kp, m, m, s->d, (const T*)Xt, (const T*)Xt, (const T*)nzp,
                              (T*)Kss, mpad, mpad, mpad, 0));
+      // (lower tiles only -- the product is symmetric -- and the upper triangle mirrored from them: half the flops)
       TGP_TRY(launch_gemm_nt<T>(ctx, ctx->stream, mpad, mpad, s->npad, (const T*)Bp, mpad,
-                                (const T*)Bp, mpad, (T*)Kss, mpad, 0, 0, 1));
+                                (const T*)Bp, mpad, (T*)Kss, mpad, 1, 0, 1));
+      TGP_TRY(symmetrize_lower<T>(ctx, mpad, (T*)Kss, mpad));
       TGP_HIP_TRY(hipMemcpy2DAsync(out_host, size_t(m) * es, Kss, size_t(mpad) * es, size_t(m) * es,
                                    size_t(m), hipMemcpyDeviceToHost, ctx->stream));
     }

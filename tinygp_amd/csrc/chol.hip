@@ -1445,31 +1445,64 @@ int gemv_sub(tgp_ctx* ctx, int64_t m, int64_t k, const T* P, int64_t ld, const T
   return TGP_OK;
 }
 
+// B (m x n) <- B L^-T: the rows of K(X_test, X) L^-T behind condition() / predict(return_var=True)
+// (direct.py:94).  Two-level right-looking sweep: per panel of NB columns a chain of [128-column solve + in-panel
+// update], then the MFMA update of everything to the right.  Round 3: on TWO streams.  The chain is 8 dependent hops
+// of kernels with m / 64 workgroups each -- on one stream the chip idled through 280 us per panel (4.5 of 22 ms at
+// m = 4 096, n = 16 384).  Now, with (i)_k the update of the NEXT panel's columns by panel k and (ii)_k the update of
+// everything right of that:
+//   priority stream:  chain_0, (i)_0, chain_1, (i)_1, ...     main stream:  (ii)_0, (ii)_1, ...
+//   (i)_k after chain_k [stream order] and (ii)_{k-1} [event];  (ii)_k after chain_k [event] and (ii)_{k-1} [order].
+// The long (ii) launches keep the chip full; the next panel's share and chain run beside them on the priority stream.
 template <typename T>
 int trsm_right_lt(tgp_ctx* ctx, int64_t m, int64_t n, const T* L, int64_t ldl, const T* dinv, T* B,
                   int64_t ldb) {
   TGP_ARG_CHECK(m % TILE == 0 && n % TILE == 0, "trsm_right_lt: m, n must be multiples of %d", TILE);
+  if (m == 0 || n == 0) return TGP_OK;
   hipStream_t st = ctx->stream;
-  // two-level right-looking sweep: 128-column solve + in-block update, then one wide
-  // MFMA update of everything to the right per outer block of NB columns
   int64_t NB = ctx->nb_outer;
   if (NB < TILE) NB = TILE;
   NB = NB / TILE * TILE;
-  for (int64_t k0 = 0; k0 < n; k0 += NB) {
-    const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
+  const bool two = ctx->lookahead != 0 && ctx->panel_stream != nullptr && n > 2 * NB;
+  hipStream_t cs = two ? ctx->panel_stream : st;  // the chains' stream
+  auto chain = [&](int64_t k0, int64_t kb) -> int {
     for (int64_t j0 = k0; j0 < k0 + kb; j0 += TILE) {
-      TGP_TRY(launch_trsm<T>(ctx, st, m, L + j0 * ldl + j0, ldl, dinv + (j0 / TILE) * 2048,
-                             B + j0 * ldb, ldb));
+      TGP_TRY(launch_trsm<T>(ctx, cs, m, L + j0 * ldl + j0, ldl, dinv + (j0 / TILE) * 2048, B + j0 * ldb, ldb));
       const int64_t nc = (k0 + kb) - (j0 + TILE);
       if (nc > 0)  // B[:, j0+128 .. k0+kb) -= X_j0 * L[j0+128 .. k0+kb, j0 block]^T
-        TGP_TRY(launch_gemm_nt<T>(ctx, st, m, nc, TILE, B + j0 * ldb, ldb,
-                                  L + j0 * ldl + j0 + TILE, ldl, B + (j0 + TILE) * ldb, ldb, 0, 0, 1));
+        TGP_TRY(launch_gemm_nt<T>(ctx, cs, m, nc, TILE, B + j0 * ldb, ldb, L + j0 * ldl + j0 + TILE, ldl,
+                                  B + (j0 + TILE) * ldb, ldb, 0, 0, 1));
     }
-    const int64_t next = k0 + kb, nr = n - next;
-    if (nr > 0)
-      TGP_TRY(launch_gemm_nt<T>(ctx, st, m, nr, kb, B + k0 * ldb, ldb, L + k0 * ldl + next, ldl,
-                                B + next * ldb, ldb, 0, 0, 1));
+    return TGP_OK;
+  };
+  if (two) {  // the chain stream starts behind whatever produced B on the main stream
+    TGP_TRY(ev_record(ctx, ctx->ev_a, st));
+    TGP_TRY(st_wait(ctx, cs, ctx->ev_a));
   }
+  for (int64_t k0 = 0; k0 < n; k0 += NB) {
+    const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
+    TGP_TRY(chain(k0, kb));
+    const int64_t next = k0 + kb, nr = n - next;
+    if (two) TGP_TRY(ev_record(ctx, ctx->ev_b, cs));  // chain_k done
+    if (nr <= 0) break;
+    const int64_t kn = (nr < NB) ? nr : NB;  // width of the next panel
+    if (!two) {
+      TGP_TRY(launch_gemm_nt<T>(ctx, st, m, nr, kb, B + k0 * ldb, ldb, L + k0 * ldl + next, ldl, B + next * ldb,
+                                ldb, 0, 0, 1));
+      continue;
+    }
+    // (i)_k on the chain stream, behind (ii)_{k-1} (ev_a, recorded below one iteration earlier / above at entry)
+    TGP_TRY(st_wait(ctx, cs, ctx->ev_a));
+    TGP_TRY(launch_gemm_nt<T>(ctx, cs, m, kn, kb, B + k0 * ldb, ldb, L + k0 * ldl + next, ldl, B + next * ldb, ldb,
+                              0, 0, 1));
+    // (ii)_k on the main stream, behind chain_k
+    TGP_TRY(st_wait(ctx, st, ctx->ev_b));
+    if (nr > kn)
+      TGP_TRY(launch_gemm_nt<T>(ctx, st, m, nr - kn, kb, B + k0 * ldb, ldb, L + k0 * ldl + next + kn, ldl,
+                                B + (next + kn) * ldb, ldb, 0, 0, 1));
+    TGP_TRY(ev_record(ctx, ctx->ev_a, st));
+  }
+  if (two) TGP_TRY(st_wait(ctx, st, ctx->ev_b));  // the last chain rejoins the main stream
   return TGP_OK;
 }
 
@@ -1529,6 +1562,38 @@ __global__ __launch_bounds__(256) void tri_mirror_kernel(T* __restrict__ Zb, T* 
   for (int c = c4; c < 64; c += 4) m[int64_t(c) * ld + r] = t[r][c];
 }
 
+// upper triangle <- transpose of the lower one (n a multiple of 64), 64 x 64 per workgroup, strictly-lower blocks only
+template <typename T>
+__global__ __launch_bounds__(256) void symmetrize_kernel(T* __restrict__ A, int64_t ld, int nt) {
+  __shared__ T t[64][65];
+  // block (bi, bj), bi > bj, from the linear index over the strict lower triangle
+  const int b = blockIdx.x;
+  int bi = int((1.0f + sqrtf(1.0f + 8.0f * float(b))) * 0.5f);
+  while ((bi * (bi - 1)) / 2 > b) --bi;
+  while (((bi + 1) * bi) / 2 <= b) ++bi;
+  const int bj = b - (bi * (bi - 1)) / 2;
+  const int r = threadIdx.x & 63, c4 = threadIdx.x >> 6;
+  const T* z = A + int64_t(bj) * 64 * ld + int64_t(bi) * 64;
+#pragma unroll 4
+  for (int c = c4; c < 64; c += 4) t[c][r] = z[int64_t(c) * ld + r];
+  __syncthreads();
+  T* m = A + int64_t(bi) * 64 * ld + int64_t(bj) * 64;
+#pragma unroll 4
+  for (int c = c4; c < 64; c += 4) m[int64_t(c) * ld + r] = t[r][c];
+  // (diagonal 64 x 64 blocks: the caller's producers write them in full)
+}
+
+template <typename T>
+int symmetrize_lower(tgp_ctx* ctx, int64_t n, T* A, int64_t ld) {
+  TGP_ARG_CHECK(n % 64 == 0, "symmetrize_lower: n must be a multiple of 64");
+  const int64_t nt = n / 64, blocks = nt * (nt - 1) / 2;
+  if (blocks == 0) return TGP_OK;
+  TGP_ARG_CHECK(blocks < (int64_t(1) << 31), "symmetrize_lower: too many blocks");
+  hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A, ld, (int)nt);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
 template <typename T>
 int spd_inverse_lower(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* winv, T* S, int64_t lds) {
   TGP_ARG_CHECK(n % TILE == 0 && lds >= n + TILE, "spd_inverse_lower: n a multiple of %d and lds >= n + %d", TILE,
@@ -1566,6 +1631,7 @@ int spd_inverse_lower(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T*
 
 #define TGP_INST(T)                                                                              \
   template int spd_inverse_lower<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, T*, int64_t); \
+  template int symmetrize_lower<T>(tgp_ctx*, int64_t, T*, int64_t);                               \
   template int launch_potf2<T>(tgp_ctx*, hipStream_t, T*, int64_t, T*, int32_t*, int32_t,       \
                                const T*, int64_t);       \
   template int launch_trsm<T>(tgp_ctx*, hipStream_t, int64_t, const T*, int64_t, const T*, T*,   \

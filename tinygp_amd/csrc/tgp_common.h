@@ -279,6 +279,9 @@ int gemv_sub(tgp_ctx* ctx, int64_t m, int64_t k, const T* P, int64_t ld, const T
 // S is ONE (n + 128) x n work matrix (lds >= n + 128); on return K^-1 is at S + 128 with leading dimension lds.
 template <typename T>
 int spd_inverse_lower(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T* winv, T* S, int64_t lds);
+// upper triangle of A (n x n, n a multiple of 64) <- transpose of its lower triangle (the diagonal 64 x 64 blocks are left alone)
+template <typename T>
+int symmetrize_lower(tgp_ctx* ctx, int64_t n, T* A, int64_t ld);
 template <typename T>
 int compute_dinv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* dinv);
 
