@@ -1,22 +1,13 @@
 #!/bin/bash
-# round 3, batch 23: streaming solves with graded polling (only the critical workgroup polls at full rate)
+# round 3, batch 24: BASELINE config 5's matrix at full size (N = 262 144, fp32, 256 GiB) through bench.py
 R=$GRAFT_REPO_ROOT
 cd $R
-O=$R/gpurun_out/b23
+O=$R/gpurun_out/b24
 mkdir -p $O
 export TMPDIR=/tmp
-B="--no-cpu-baseline"
-sec() { python -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print(d['config']['workload'][:12], round(d['value'],4), round(d['ms_per_step'],3))
-for r in d.get('roofline_secondary', []): print('   ', r['kernel'][:40], round(r['achieved'],1), r['unit'], 'frac', round(r['frac'],3), 'ms', round(r.get('ms'),4))"; }
 {
 date
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_gp.py -m gpu -x -q -k "trsv or solve or logp or log_prob or condition or predict" 2>&1 | tail -3
-for wl in n4096 c2 n32768 n65536; do
-timeout 300 python bench.py --workload $wl --steps 2 --warmup 1 $B 2>/dev/null | tail -1 | sec
-done
-timeout 300 python scripts/time_paths.py 16384 4096 | head -5
+timeout 900 python bench.py --workload n262144f32 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary 2>&1 | tail -1 | tee $O/line.json | cut -c1-1200
 date
 } > $O/log.txt 2>&1
-cat $O/log.txt | cut -c1-200
+cat $O/log.txt | cut -c1-1300
