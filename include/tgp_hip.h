@@ -268,7 +268,8 @@ int tgp_solver_device_factor(tgp_solver* s, void** L_dev, int64_t* n_pad);
 /* last-call timings measured with HIP events on the ctx stream when option "profile"=1:
  * ms[0]=assembly of the first panel's columns (the rest is assembled beside the factorisation),
  * ms[1]=potrf total, ms[2]=sum of the 128x128-tile trailing-update launches (event spans),
- * ms[3]=number of those launches, ms[4]=separate trsv pass (0 when fused), ms[5]=unused,
+ * ms[3]=number of those launches, ms[4]=separate trsv pass (0 when fused), ms[5]=HOST time from the entry of the last
+ * factorisation to its last enqueue (how far ahead of the device the submitting thread runs),
  * ms[6]=algorithmic flops of those launches */
 int tgp_solver_timings(tgp_solver* s, double* ms, int n);
 

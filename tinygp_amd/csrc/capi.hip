@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" boundary of libtgp_hip.so (include/tgp_hip.h).
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 
@@ -593,6 +594,7 @@ static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void*
   }
   TGP_ARG_CHECK(s->has_prog || cov_host != nullptr, "factor needs a kernel program or a covariance");
   s->winv_valid = false;
+  const auto host0 = std::chrono::steady_clock::now();  // -> ms[5]: how long the HOST takes to submit the evaluation
   const size_t es = esize(s->dtype);
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   const bool prof = ctx->profile != 0;
@@ -636,6 +638,7 @@ static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void*
   double two[2] = {0, 0};
   TGP_HIP_TRY(hipMemcpyAsync(two, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  s->ms[5] = std::chrono::duration<double, std::milli>(ctx->submitted - host0).count();  // (potrf's last enqueue)
   s->logdet_half = two[1];
   if (fused && logprob)
     *logprob = -0.5 * two[0] - (s->logdet_half + 0.5 * double(s->n) * std::log(2.0 * M_PI));

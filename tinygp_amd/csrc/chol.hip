@@ -1359,6 +1359,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     TGP_TRY(st_wait(ctx, S0, ctx->ev_c));
   }
   int32_t info = 0;
+  ctx->submitted = std::chrono::steady_clock::now();
   if (!ctx->trace) {
     TGP_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, S0));
     TGP_HIP_TRY(hipStreamSynchronize(S0));

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
 #include <functional>
 #include <mutex>
 #include <vector>
@@ -93,6 +94,7 @@ struct tgp_ctx {
   // the fused forward-substitution steps ride on the update stream, behind the in-panel update of the same
   // block: three busy queues instead of four (c2 30.3 -> 29.8 ms, N = 4096 2.66 -> 2.45 ms; 0: own stream)
   int64_t solve_on_update = 1;
+  std::chrono::steady_clock::time_point submitted;  // host time at which potrf had enqueued its last launch
   // panels that start with at least this many rows left are 2 nb_outer wide (0: never): half as many passes
   // over the trailing matrix; +1.3 % at N = 65 536, a loss below ~30 000 rows (profiles/r02_i_wide_panels.txt)
   int64_t nb_wide_rows = 30000;

@@ -403,7 +403,7 @@ class DirectSolver(Solver):
     def timings(self) -> dict:
         ms = (C.c_double * 8)()
         _ffi.check(_ffi.lib().tgp_solver_timings(self._handle, ms, 8), "tgp_solver_timings")
-        keys = ["assembly_ms", "potrf_ms", "syrk_ms", "syrk_launches", "trsv_ms", "panel_ms"]
+        keys = ["assembly_ms", "potrf_ms", "syrk_ms", "syrk_launches", "trsv_ms", "host_submit_ms"]
         return {k: ms[i] for i, k in enumerate(keys)}
 
     # -- lifetime ----------------------------------------------------------------------
