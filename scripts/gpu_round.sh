@@ -1,12 +1,17 @@
 #!/bin/bash
-# round 3, batch 26: is the submitting thread ahead of the device?  wall-clock of an evaluation next to the host time of its enqueues
+# round 3, batch 27: the round-end sequence on the final tree -- pytest -m gpu, smoke, the default bench line (with the re-stamped PMC traffic)
 R=$GRAFT_REPO_ROOT
 cd $R
-O=$R/gpurun_out/b26
+O=$R/gpurun_out/b27
 mkdir -p $O
+export TMPDIR=/tmp
 {
-date
-timeout 300 python scripts/host_submit.py 1024 2048 4096 8192 16384 32768
+echo "== pytest -m gpu"; date
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+echo "== smoke"; date
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+echo "== bench default"; date
+timeout 600 python bench.py 2>/dev/null | tail -1 | tee $O/bench_default.json | cut -c1-2600
 date
 } > $O/log.txt 2>&1
-cat $O/log.txt
+cat $O/log.txt | cut -c1-2700
