@@ -621,12 +621,13 @@ __device__ __forceinline__ T bits_to(typename Sent<T>::bits_t b) {
 // tmp <- y, y <- sentinel, ticket <- 0
 template <typename T>
 __global__ __launch_bounds__(256) void trsv_prep_kernel(int64_t n, T* __restrict__ y, T* __restrict__ tmp,
-                                                        int32_t* __restrict__ ticket) {
+                                                        int32_t* __restrict__ ticket, T* __restrict__ part) {
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (i == 0) *ticket = 0;
   if (i < n) {
     tmp[i] = y[i];
     y[i] = bits_to<T>(Sent<T>::value);
+    if (part != nullptr) part[i] = bits_to<T>(Sent<T>::value);  // the helpers' partial sums (forward kernel)
   }
 }
 
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
                                                               const T* __restrict__ winv,
                                                               const T* __restrict__ tfwd,
                                                               const T* __restrict__ yin, T* __restrict__ x,
-                                                              int32_t* __restrict__ ticket) {
+                                                              int32_t* __restrict__ ticket, T* __restrict__ part) {
   typedef T T2 __attribute__((ext_vector_type(2)));
   using bits_t = typename Sent<T>::bits_t;
   // 256 threads = one wave per SIMD (up to 512 VGPRs each): lane = 2 rows, wave = 32 columns;
@@ -712,9 +713,17 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
   const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar address math
   if (tid == 0) sb = atomicAdd(ticket, 1);
   __syncthreads();
-  const int b = __builtin_amdgcn_readfirstlane(sb);
+  // Round 3 (batch 31's stamps): the dependent part of a hop -- x_{b-1} seen -> x_b published -- is 0.63 us, but a
+  // workgroup was ready for it only every OTHER hop: it must pull one 128-KiB tile through ONE CU's memory path per
+  // hop (2.3-2.8 us at the ~50 GB/s a CU reaches), and that, not the hand-off, set the 3.4 us per block.  Two
+  // workgroups per block row now share the tiles -- tickets 2b (helper: tiles b-3, b-5, ..., its partial sums handed
+  // over as a tagged granule one hop before they are needed) and 2b+1 (primary: tiles b-2, b-4, ..., then W_b, tf_b
+  // and the hop) -- so each streams a tile every second hop.
+  const int tk = __builtin_amdgcn_readfirstlane(sb);
+  const int b = tk >> 1;
+  const bool helper = (tk & 1) == 0;  // (the helper's ticket first: a workgroup only ever waits for EARLIER tickets)
   if (b >= nblk) return;
-  if (b >= 1) {  // column j of tf_b: 64 lanes x 16 bytes = one wave transfer
+  if (b >= 1 && !helper) {  // column j of tf_b: 64 lanes x 16 bytes = one wave transfer
     const T* tb = tfwd + int64_t(b) * 16384 + int64_t(NC * cg) * 128 + 2 * rq;
     T2 stage[NC];
 #pragma unroll
@@ -771,14 +780,15 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
     __hip_atomic_store(reinterpret_cast<bits_t*>(x + int64_t(b) * 128 + tid), out, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   };
-  // next: 0 nothing, 1 tile c+1, 2 W_b -- always issued BEFORE waiting for x_c
+  // next: 0 nothing, 1 tile c+2 (this workgroup's next), 2 W_b -- always issued BEFORE waiting for x_c
   auto step = [&](int c, T2 (&cur)[NC], T2 (&nxt)[NC], int next) {
-    if (next == 1) load_tile(nxt, c + 1);
+    if (next == 1) load_tile(nxt, c + 2);
     if (next == 2) load_blk(nxt, winv);
-    wait_x(c, c & 1);
-    if (tid < 128) xb = (next == 1) ? load_x_bits<T>(x + int64_t(c + 1) * 128 + tid) : Sent<T>::value;
+    const int slot = (c >> 1) & 1;
+    wait_x(c, slot);
+    if (tid < 128) xb = (next == 1) ? load_x_bits<T>(x + int64_t(c + 2) * 128 + tid) : Sent<T>::value;
     T a0, a1;
-    matvec(cur, &sx[c & 1][NC * cg], a0, a1);
+    matvec(cur, &sx[slot][NC * cg], a0, a1);
     acc0 += a0;
     acc1 += a1;
   };
@@ -789,7 +799,18 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
     red[cg][2 * rq] = acc0;
     red[cg][2 * rq + 1] = acc1;
     __syncthreads();
-    if (tid < 128) sr[tid] = yin[int64_t(b) * 128 + tid] - sum4(tid);
+    if (tid < 128) {
+      T pv = T(0);
+      if (b >= 3) {  // the helper's tiles b-3, b-5, ...: handed over one hop ago as a rule
+        bits_t pb = Sent<T>::value;
+        for (long spin = 0; pb == Sent<T>::value && spin < (1L << 26); ++spin) {
+          if (spin) __builtin_amdgcn_s_sleep(1);
+          pb = load_x_bits<T>(part + int64_t(b) * 128 + tid);
+        }
+        pv = bits_to<T>(pb);
+      }
+      sr[tid] = (yin[int64_t(b) * 128 + tid] - sum4(tid)) - pv;
+    }
     __syncthreads();
     T p0, p1;
     matvec(wf, &sr[NC * cg], p0, p1);
@@ -818,26 +839,50 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
     __syncthreads();
     if (tid < 128) publish(sp[tid] - sum4(tid));
   };
-  const int nt = b - 1;  // tiles (b, 0 .. b-2) are streamed; tile (b, b-1) is inside tf_b
-  if (nt <= 0) {
+  // tiles (b, 0 .. b-2) are streamed (tile (b, b-1) is inside tf_b): the primary takes c = b-2, b-4, ..., the helper
+  // c = b-3, b-5, ... -- each in INCREASING c: first = its parity's smallest index, last = b-2 resp. b-3
+  const int last = helper ? b - 3 : b - 2;
+  if (helper) {
+    if (last < 0) return;  // (blocks 0..2 have no helper tiles; the primary does not wait for them)
+  } else if (last < 0) {
     load_blk(bufA, winv);
     finish(bufA);
     return;
   }
-  load_tile(bufA, 0);
-  int c = 0;
-  for (; c + 2 < nt; c += 2) {
+  const int first = last & 1;
+  const int cnt = (last - first) / 2 + 1;  // this workgroup's tiles
+  load_tile(bufA, first);
+  int c = first, left = cnt;
+  for (; left > 2; left -= 2, c += 4) {
     step(c, bufA, bufB, 1);
-    step(c + 1, bufB, bufA, 1);
+    step(c + 2, bufB, bufA, 1);
   }
-  if (nt - c == 2) {
+  const int tail_next = helper ? 0 : 2;  // the primary's last step fetches W_b into the free buffer
+  bool w_in_a;
+  if (left == 2) {
     step(c, bufA, bufB, 1);
-    step(c + 1, bufB, bufA, 2);
-    finish(bufA);
+    step(c + 2, bufB, bufA, tail_next);
+    w_in_a = true;
   } else {
-    step(c, bufA, bufB, 2);
-    finish(bufB);
+    step(c, bufA, bufB, tail_next);
+    w_in_a = false;
   }
+  if (helper) {  // partial sums of this workgroup's tiles -> part[b] (tagged like x)
+    red[cg][2 * rq] = acc0;
+    red[cg][2 * rq + 1] = acc1;
+    __syncthreads();
+    if (tid < 128) {
+      const T pv = sum4(tid);
+      bits_t out;
+      __builtin_memcpy(&out, &pv, sizeof(T));
+      if (out == Sent<T>::value) out ^= 1;
+      __hip_atomic_store(reinterpret_cast<bits_t*>(part + int64_t(b) * 128 + tid), out, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  if (w_in_a) finish(bufA);
+  else finish(bufB);
 }
 
 // Backward substitution L^T x = z in one launch: workgroup (ticket) t owns block b = nblk-1-t, i.e.
@@ -1401,13 +1446,15 @@ int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int tra
   hipStream_t st = ctx->stream;
   const int64_t nb = n / TILE;
   if (winv != nullptr && n > 0) {  // one streaming launch (trsv_fwd_stream_kernel / trsv_bwd_stream_kernel)
-    TGP_TRY(ensure_work(ctx, size_t(n) * sizeof(T) + 256));
+    TGP_TRY(ensure_work(ctx, 2 * size_t(n) * sizeof(T) + 1024));
     T* tmp = static_cast<T*>(ctx->d_work);
     int32_t* ticket = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->d_work) + size_t(n) * sizeof(T) + 64);
-    hipLaunchKernelGGL((trsv_prep_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, y, tmp, ticket);
+    T* part = static_cast<T*>(ctx->d_work) + n + 64;  // (forward kernel: the helpers' partial sums, n entries)
+    hipLaunchKernelGGL((trsv_prep_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, y, tmp, ticket,
+                       transpose ? static_cast<T*>(nullptr) : part);
     if (!transpose)
-      hipLaunchKernelGGL((trsv_fwd_stream_kernel<T>), dim3((unsigned)nb), dim3(256), 0, st, (int)nb, L, ld, winv,
-                         winv + 2 * nb * 16384, (const T*)tmp, y, ticket);
+      hipLaunchKernelGGL((trsv_fwd_stream_kernel<T>), dim3((unsigned)(2 * nb)), dim3(256), 0, st, (int)nb, L, ld, winv,
+                         winv + 2 * nb * 16384, (const T*)tmp, y, ticket, part);
     else
       hipLaunchKernelGGL((trsv_bwd_stream_kernel<T>), dim3((unsigned)nb), dim3(512), 0, st, (int)nb, L, ld,
                          winv + nb * 16384, (const T*)tmp, y, ticket);
