@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void trsv_prep_kernel(int64_t n, T* __restrict
   if (i < n) {
     tmp[i] = y[i];
     y[i] = bits_to<T>(Sent<T>::value);
-    if (part != nullptr) part[i] = bits_to<T>(Sent<T>::value);  // the helpers' partial sums (forward kernel)
+    part[i] = bits_to<T>(Sent<T>::value);  // the helpers' partial sums
   }
 }
 
@@ -896,7 +896,7 @@ template <typename T>
 __global__ __launch_bounds__(512) void trsv_bwd_stream_kernel(int nblk, const T* __restrict__ L, int64_t ld,
                                                               const T* __restrict__ winvT,
                                                               const T* __restrict__ zin, T* __restrict__ x,
-                                                              int32_t* __restrict__ ticket) {
+                                                              int32_t* __restrict__ ticket, T* __restrict__ part) {
   typedef T T2 __attribute__((ext_vector_type(2)));
   using bits_t = typename Sent<T>::bits_t;
   constexpr int NC = 16, NG = 8, PAD = 65;  // 8 waves (two per SIMD, <= 256 VGPRs each) x 16 columns
@@ -909,7 +909,11 @@ __global__ __launch_bounds__(512) void trsv_bwd_stream_kernel(int nblk, const T*
   const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) sb = atomicAdd(ticket, 1);
   __syncthreads();
-  const int t = __builtin_amdgcn_readfirstlane(sb);
+  // two workgroups per block column, as in the forward kernel: ticket 2t the helper (tiles b+2, b+4, ..., partial sums
+  // handed over as a tagged granule), ticket 2t+1 the primary (tiles b+1, b+3, ..., W_b^T and the hop)
+  const int tk = __builtin_amdgcn_readfirstlane(sb);
+  const int t = tk >> 1;
+  const bool helper = (tk & 1) == 0;
   if (t >= nblk) return;
   const int b = nblk - 1 - t;
   const T* Lcol = L + (int64_t(b) * 128 + NC * cg) * ld;  // + j * ld + c * 128 + 2 rq
@@ -928,20 +932,21 @@ __global__ __launch_bounds__(512) void trsv_bwd_stream_kernel(int nblk, const T*
     for (int j = 0; j < NC; ++j) buf[j] = *reinterpret_cast<const T2*>(wb + j * 128 + 2 * rq);
   };
   bits_t xb = Sent<T>::value;
-  // tiles are visited in DEcreasing c; next: 0 nothing, 1 tile c-1, 2 W_b^T
+  // tiles are visited in DEcreasing c, every second one; next: 0 nothing, 1 tile c-2, 2 W_b^T
   auto step = [&](int c, T2 (&cur)[NC], T2 (&nxt)[NC], int next) {
-    if (next == 1) load_tile(nxt, c - 1);
+    if (next == 1) load_tile(nxt, c - 2);
     if (next == 2) load_w(nxt);
+    const int slot = (c >> 1) & 1;
     if (tid < 128) {
       for (long spin = 0; xb == Sent<T>::value && spin < (1L << 26); ++spin) {
         if (spin) __builtin_amdgcn_s_sleep(1);
         xb = load_x_bits<T>(x + int64_t(c) * 128 + tid);
       }
-      sx[c & 1][tid] = bits_to<T>(xb);
+      sx[slot][tid] = bits_to<T>(xb);
     }
     __syncthreads();
-    if (tid < 128) xb = (next == 1) ? load_x_bits<T>(x + int64_t(c - 1) * 128 + tid) : Sent<T>::value;
-    const T x0 = sx[c & 1][2 * rq], x1 = sx[c & 1][2 * rq + 1];
+    if (tid < 128) xb = (next == 1) ? load_x_bits<T>(x + int64_t(c - 2) * 128 + tid) : Sent<T>::value;
+    const T x0 = sx[slot][2 * rq], x1 = sx[slot][2 * rq + 1];
 #pragma unroll
     for (int j = 0; j < NC; ++j) acc[j] += cur[j].x * x0 + cur[j].y * x1;
   };
@@ -961,7 +966,29 @@ __global__ __launch_bounds__(512) void trsv_bwd_stream_kernel(int nblk, const T*
       red[h][jj] = s0 + s1;
     }
     __syncthreads();
-    if (tid < 128) sr[tid] = zin[int64_t(b) * 128 + tid] - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    if (helper) {  // this workgroup's share of the column sums -> part[b] (tagged like x); nothing else to do
+      if (tid < 128) {
+        const T pv = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        bits_t out;
+        __builtin_memcpy(&out, &pv, sizeof(T));
+        if (out == Sent<T>::value) out ^= 1;
+        __hip_atomic_store(reinterpret_cast<bits_t*>(part + int64_t(b) * 128 + tid), out, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    if (tid < 128) {
+      T pv = T(0);
+      if (b + 2 <= nblk - 1) {  // the helper's tiles b+2, b+4, ...
+        bits_t pb = Sent<T>::value;
+        for (long spin = 0; pb == Sent<T>::value && spin < (1L << 26); ++spin) {
+          if (spin) __builtin_amdgcn_s_sleep(1);
+          pb = load_x_bits<T>(part + int64_t(b) * 128 + tid);
+        }
+        pv = bits_to<T>(pb);
+      }
+      sr[tid] = (zin[int64_t(b) * 128 + tid] - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]))) - pv;
+    }
     __syncthreads();
     T p0 = 0, p1 = 0;
 #pragma unroll
@@ -988,24 +1015,28 @@ __global__ __launch_bounds__(512) void trsv_bwd_stream_kernel(int nblk, const T*
                          __HIP_MEMORY_SCOPE_AGENT);
     }
   };
-  const int ntiles = nblk - 1 - b;  // tiles c = nblk-1 .. b+1
-  if (ntiles == 0) {
+  // tiles c = nblk-1 .. b+1: the primary takes b+1, b+3, ..., the helper b+2, b+4, ... (each from its largest c down)
+  const int last = helper ? b + 2 : b + 1;
+  if (last > nblk - 1) {
+    if (helper) return;  // (no tiles: the primary does not wait for this helper)
     load_w(bufA);
     finish(bufA);
     return;
   }
-  load_tile(bufA, nblk - 1);
-  int c = nblk - 1;
-  for (; c - 2 > b; c -= 2) {
+  const int cnt = (nblk - 1 - last) / 2 + 1;
+  int c = last + 2 * (cnt - 1), left = cnt;
+  load_tile(bufA, c);
+  for (; left > 2; left -= 2, c -= 4) {
     step(c, bufA, bufB, 1);
-    step(c - 1, bufB, bufA, 1);
+    step(c - 2, bufB, bufA, 1);
   }
-  if (c - b == 2) {
+  const int tail_next = helper ? 0 : 2;  // the primary's last step fetches W_b^T into the free buffer
+  if (left == 2) {
     step(c, bufA, bufB, 1);
-    step(c - 1, bufB, bufA, 2);
+    step(c - 2, bufB, bufA, tail_next);
     finish(bufA);
   } else {
-    step(c, bufA, bufB, 2);
+    step(c, bufA, bufB, tail_next);
     finish(bufB);
   }
 }
@@ -1449,15 +1480,15 @@ int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int tra
     TGP_TRY(ensure_work(ctx, 2 * size_t(n) * sizeof(T) + 1024));
     T* tmp = static_cast<T*>(ctx->d_work);
     int32_t* ticket = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->d_work) + size_t(n) * sizeof(T) + 64);
-    T* part = static_cast<T*>(ctx->d_work) + n + 64;  // (forward kernel: the helpers' partial sums, n entries)
+    T* part = static_cast<T*>(ctx->d_work) + n + 64;  // the helpers' partial sums, n entries
     hipLaunchKernelGGL((trsv_prep_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, y, tmp, ticket,
-                       transpose ? static_cast<T*>(nullptr) : part);
+                       part);
     if (!transpose)
       hipLaunchKernelGGL((trsv_fwd_stream_kernel<T>), dim3((unsigned)(2 * nb)), dim3(256), 0, st, (int)nb, L, ld, winv,
                          winv + 2 * nb * 16384, (const T*)tmp, y, ticket, part);
     else
-      hipLaunchKernelGGL((trsv_bwd_stream_kernel<T>), dim3((unsigned)nb), dim3(512), 0, st, (int)nb, L, ld,
-                         winv + nb * 16384, (const T*)tmp, y, ticket);
+      hipLaunchKernelGGL((trsv_bwd_stream_kernel<T>), dim3((unsigned)(2 * nb)), dim3(512), 0, st, (int)nb, L, ld,
+                         winv + nb * 16384, (const T*)tmp, y, ticket, part);
     TGP_HIP_TRY(hipGetLastError());
     return TGP_OK;
   }
