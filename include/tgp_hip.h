@@ -246,7 +246,8 @@ int tgp_solver_alpha(tgp_solver* s, const void* resid_host, void* alpha_host, do
  * grad_params: 2*nops doubles, [2*i + q] = d ll / d (p0 if q==0 else p1) of program op i (0 for
  * ADD/MUL and unused p1); grad_noise_host (n,) = d ll / d noise_i = 1/2 (alpha_i^2 - K^-1_ii), or
  * NULL; alpha_host (n,) = K^-1 resid = d ll / d mean_i, or NULL.  Needs tgp_solver_factor first;
- * allocates two more n_pad^2 buffers (L^-T and K^-1) on first use. */
+ * allocates ONE (n_pad + 128) x n_pad work matrix on first use (L^-1 in both orientations, then K^-1 in the lower one's
+ * place; kept between calls up to 4 GiB, see option "keep_grad_buffers"). */
 int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, double* grad_params,
                     void* grad_noise_host, void* alpha_host);
 /* mean = K(Xt, X) alpha (gp.py:353-357; K9 fused). Xt host (m,d) row-major */

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     // over the k-loop instead: k-tile r fetches chunk r of C (two of a lane's 64 entries) right
     // behind the operand prefetch and subtracts it one k-tile later, when the in-order return of
     // the operand loads has already proved it complete -- no additional wait.  The MFMA operand
-    // read from LDS is negated on the way, so the accumulators end as C - A B^T and the epilogue
+    // is negated by the instruction itself (its NEG field), so the accumulators end as C - A B^T and the epilogue
     // is 64 stores, nothing loaded.
     constexpr int NCH = 8;  // chunks of eight entries: (a, b-pair)
     const int kq = (nkt - kt0) / nsl;               // k-tiles of this workgroup (all of them unless a tail slice)
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     // fp32, round 3 (BASELINE config 5's arithmetic): v_mfma_f32_32x32x2_f32 (the fp32 instruction that reaches
     // the 157 TFLOP/s peak; 16x16x4 tops out at 139), operands staged global -> LDS directly, three k-tiles deep
     // with counted vmcnt waits and a raw s_barrier, C fetched first and used as the accumulators' initial value
-    // (the MFMA A operand is negated on the way: the epilogue is 64 stores).  Round 1-2's loop -- register
+    // (negated: the accumulators collect A B^T on top of -C and change sign once before the 64 stores).  Round 1-2's loop -- register
     // staging one k-tile ahead, read-modify-write epilogue -- ran at 117 of 157 TFLOP/s.
     // LDS stage: [16 k][128 rows] floats, unpadded: a k-row is 512 bytes = half a wave transfer, and a 32-lane
     // ds_read_b32 group reads 128 contiguous bytes of ONE k-row -- no conflicts, no swizzle.
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
           acc[a][b] = -acc[a][b];
         }
     }
-    auto kloop = [&](auto negated) {
+    auto kloop = [&]() {
       int stage = 0;
       for (int kt = kt0; kt < nkt; ++kt) {
         const int ahead = nkt - 1 - kt;  // tiles issued behind this one
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
         stage = stage == NST - 1 ? 0 : stage + 1;
       }
     };
-    kloop(std::false_type{});
+    kloop();
     if (g.mode == 0) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     // fp64, round 3: operands staged global -> LDS directly (global_load_lds_dwordx4: no staging VGPRs, no
     // ds_write pass), NST k-tiles deep with counted vmcnt waits and a raw s_barrier (a __syncthreads() would
     // drain the transfers in flight), C fetched before the first transfer and used as the accumulators' initial
-    // value (the MFMA A operand is negated on the way: acc ends as C - A B^T, the epilogue is 16 stores).
+    // value (the MFMA negates its A operand -- NEG field: acc ends as C - A B^T, the epilogue is 16 stores).
     // Before: one k-tile of register prefetch -- a 0.4-us k-tile cannot cover a 1-2-us L2 / HBM round trip, the
     // MFMA pipes were 50 % busy (profiles/r02_s) and this kernel's 27 % of the flops cost 36 % of an evaluation.
     // LDS image per stage: [16 k][64 rows] doubles, UNPADDED (one wave transfer = two 512-byte k-rows, lane l at
