@@ -243,3 +243,31 @@ def test_pytree_inputs_reach_host_evaluated_kernels():
         _device.num_points((t, band[:5]))
     with pytest.raises(NotImplementedError):  # a stationary kernel has no meaning on a pytree
         kernels.Matern32(1.0)(X, X)
+
+
+def test_host_diag_validates_like_the_pairs_route_and_constant_takes_pytrees():
+    """Round-3 advisor finding: the host route's diagonal (D > 16, long trees, custom metrics) must raise for a
+    non-scalar scale like evaluate_diag -> evaluate does in the reference (stationary.py:77-81 via base.py:59-66),
+    must CALL a user-defined metric at (x, x) instead of assuming 0, and Constant's host methods must accept the
+    pytree inputs the same route admits."""
+    rng = np.random.default_rng(3)
+    a20 = rng.normal(size=(5, 20))
+    with pytest.raises(ValueError, match="scalar scales"):
+        kernels.Matern32(np.ones(20))._host_diag(a20)
+    with pytest.raises(ValueError, match="scalar scales"):
+        kernels.Matern32(np.ones(20))(a20)  # through __call__ (D > 16 -> host route)
+
+    class Offset(kernels.Distance):  # distance(x, x) = 0.25, not 0
+        def distance(self, X1, X2):
+            return np.abs(X1 - X2).sum() + 0.25
+
+    k = kernels.Exp(0.5, distance=Offset())
+    np.testing.assert_allclose(k(a20), np.full(5, np.exp(-0.25 / 0.5)), rtol=1e-15)
+    np.testing.assert_allclose(k(a20), np.diag(k(a20, a20)), rtol=1e-15)
+    k2 = kernels.ExpSquared(0.5, distance=Offset())  # squared_distance: the base-class square (distance.py:30-38)
+    np.testing.assert_allclose(k2(a20), np.full(5, np.exp(-0.5 * 0.25**2 / 0.25)), rtol=1e-15)
+    t = np.linspace(0.0, 1.0, 7)
+    X = {"t": t, "band": np.arange(7) % 2}
+    c = kernels.Constant(2.5)
+    assert c._host_matrix(X, (t[:3], t[:3])).shape == (7, 3) and np.all(c._host_matrix(X, X) == 2.5)
+    assert c._host_diag(X).shape == (7,)

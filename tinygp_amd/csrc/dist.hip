@@ -149,8 +149,10 @@ int chain_chunk_and_pack(tgp_dist* h, int64_t k, int64_t c, int64_t nch) {
     TGP_TRY(wait_slot_free(h, k));
   }
   const std::function<int(hipEvent_t)> no_mid = [](hipEvent_t) { return TGP_OK; };
-  TGP_TRY(panel_chain<T>(ctx, S1, rows, Ap, ld, dk, k * h->nb, 0, h->nb, false, (T*)nullptr, 0, no_mid, c * bpc,
-                         (c + 1) * bpc));
+  // an unchunked panel takes panel_chain's defaults (blk_begin = 0, blk_end = -1): only those reach the
+  // one-launch-per-panel / one-launch-per-block forms of the chain (round-3 advisor finding)
+  TGP_TRY(panel_chain<T>(ctx, S1, rows, Ap, ld, dk, k * h->nb, 0, h->nb, false, (T*)nullptr, 0, no_mid,
+                         nch == 1 ? 0 : c * bpc, nch == 1 ? -1 : (c + 1) * bpc));
   T* slot = (T*)h->ring[k % tgp_dist::NSLOT];
   unsigned gx = (unsigned)((rows / (16 / sizeof(T)) + 255) / 256);
   if (gx > 64) gx = 64;

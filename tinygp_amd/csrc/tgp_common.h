@@ -136,7 +136,7 @@ struct tgp_ctx {
   // profiling (option "profile"): event pairs around trailing-update launches
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
-  double prof_syrk_ms = 0, prof_syrk_flops = 0, prof_panel_ms = 0;
+  double prof_syrk_ms = 0, prof_syrk_flops = 0;
   int64_t prof_syrk_launches = 0;
   int cus = 0;
   // dry run: launches and event operations are recorded here instead of being issued

@@ -275,13 +275,15 @@ class Constant(Kernel):
     def _host_matrix(self, X1, X2):  # only reached as an operand of a tree beyond the device limits
         if np.ndim(self.value) != 0:
             raise ValueError("The value of a constant kernel must be a scalar")
-        dt = _device.common_dtype(np.asarray(X1), np.asarray(X2))
-        return np.full((np.shape(X1)[0], np.shape(X2)[0]), self.value, dtype=dt)
+        leaves = lambda X: _device.tree_leaves(X) if _device.is_tree(X) else [np.asarray(X)]  # noqa: E731
+        dt = _device.common_dtype(*leaves(X1), *leaves(X2))
+        return np.full((_device.num_points(X1), _device.num_points(X2)), self.value, dtype=dt)
 
     def _host_diag(self, X):
         if np.ndim(self.value) != 0:
             raise ValueError("The value of a constant kernel must be a scalar")
-        return np.full((np.shape(X)[0],), self.value, dtype=_device.common_dtype(np.asarray(X)))
+        leaves = _device.tree_leaves(X) if _device.is_tree(X) else [np.asarray(X)]
+        return np.full((_device.num_points(X),), self.value, dtype=_device.common_dtype(*leaves))
 
     def __repr__(self):
         return f"Constant({self.value!r})"

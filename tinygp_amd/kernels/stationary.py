@@ -103,10 +103,23 @@ class Stationary(base.Kernel):
         return self._host_pairs(_as_points(X1, dt), _as_points(X2, dt))
 
     def _host_diag(self, X):
+        """k(x, x) per point, like the reference's evaluate_diag -> evaluate(x, x) (base.py:59-66): the same
+        scale validation as ``_host_pairs`` and, for a user-defined metric, the metric's OWN value at (x, x)."""
+        if np.ndim(self.scale) != 0:
+            raise ValueError(
+                "Only scalar scales are permitted for stationary kernels; pre-scale the "
+                "inputs for anisotropic length scales")
         P = _as_points(X, _device_common(X))
-        zero = np.zeros((1, 1), dtype=P.dtype)
-        v = self._of_r(None, zero)[0, 0] if self._uses_squared else self._of_r(zero, None)[0, 0]
-        return np.full((P.shape[0],), v, dtype=P.dtype)  # k(x, x): distance 0 for every metric
+        if type(self.distance) in (L1Distance, L2Distance):  # distance 0 at (x, x) for both built-in metrics
+            zero = np.zeros((1, 1), dtype=P.dtype)
+            v = self._of_r(None, zero)[0, 0] if self._uses_squared else self._of_r(zero, None)[0, 0]
+            return np.full((P.shape[0],), v, dtype=P.dtype)
+        scale = P.dtype.type(self.scale)
+        if self._uses_squared:
+            r2 = np.array([self.distance.squared_distance(x, x) for x in P], dtype=P.dtype)[:, None]
+            return self._of_r(None, r2 / np.square(scale))[:, 0]
+        r = np.array([self.distance.distance(x, x) for x in P], dtype=P.dtype)[:, None]
+        return self._of_r(r / scale, None)[:, 0]
 
 
 def _device_common(*arrays):
