@@ -274,43 +274,59 @@ def cpu_baseline(spec, budget_s=75.0):
     order = sorted(sweep, key=sweep.get, reverse=True)
     del K0, work
 
-    def evaluate(nn, threads):
-        """one full evaluation at size nn: blocked assembly (oracle formulas), raw dpotrf in place on the
-        Fortran-ordered matrix, dtrtrs, reductions; returns (stage seconds, loglik)"""
+    def evaluate(nn, thread_list, per_run_est=0.0):
+        """one full evaluation at size nn: blocked assembly (oracle formulas) ONCE, then raw dpotrf in place on a
+        Fortran-ordered copy for every thread count of `thread_list` while the budget lasts, dtrtrs + reductions with
+        the fastest; returns (stage seconds with the fastest potrf, loglik, {threads: potrf seconds})"""
         s = dict(spec, n=nn)
         X, y = make_inputs(s)
         X, y = X.astype(np.float64), y.astype(np.float64)
-        with limit(threads):
-            t0 = time.perf_counter()
-            K = np.empty((nn, nn), order="F")
-            bs = 2048  # blocked assembly: bounded temporaries; K is symmetric, so a row block fills a column block
-            for i0 in range(0, nn, bs):
-                K[:, i0:i0 + bs] = kern(X[i0:i0 + bs], X).T
-            K[np.diag_indices(nn)] += spec["diag"]
-            t1 = time.perf_counter()
-            L, info = lapack.dpotrf(K, lower=1, overwrite_a=1)
+        t0 = time.perf_counter()
+        K = np.empty((nn, nn), order="F")
+        bs = 2048  # blocked assembly: bounded temporaries; K is symmetric, so a row block fills a column block
+        for i0 in range(0, nn, bs):
+            K[:, i0:i0 + bs] = kern(X[i0:i0 + bs], X).T
+        K[np.diag_indices(nn)] += spec["diag"]
+        t1 = time.perf_counter()
+        potrf_s, L = {}, None
+        if len(thread_list) > 1:
+            work = np.empty_like(K, order="F")
+        for q, th in enumerate(thread_list):
+            if potrf_s and time.perf_counter() - t_start + per_run_est > 1.2 * budget_s:
+                notes.append(f"full-size dpotrf runs stopped before {th} threads (time budget)")
+                break
+            last = q == len(thread_list) - 1
+            if last and L is None:  # the only (or last) run factors K itself: no copy at all
+                with limit(th):
+                    lapack.dpotrf(np.asfortranarray(K[:256, :256].copy()), lower=1, overwrite_a=1)  # pool awake
+                    tq = time.perf_counter()
+                    L, info = lapack.dpotrf(K, lower=1, overwrite_a=1)
+                    potrf_s[th] = time.perf_counter() - tq
+            else:
+                potrf_s[th], _ = time_potrf(K, work, th)
+        best = min(potrf_s, key=potrf_s.get)
+        if L is None:  # `work` holds the factor of the last timed run (identical for every thread count up to rounding)
+            L = work
+        with limit(best):
             t2 = time.perf_counter()
             alpha, info2 = lapack.dtrtrs(L, y, lower=1)
             ll = -0.5 * float(alpha @ alpha) - float(np.sum(np.log(np.diag(L)))) - 0.5 * nn * np.log(2 * np.pi)
             t3 = time.perf_counter()
-        return (t1 - t0, t2 - t1, t3 - t2), ll
+        return (t1 - t0, potrf_s[best], t3 - t2), ll, potrf_s
 
-    # 2. the workload's own N with the sweep's best thread counts (the second one only while the budget lasts),
-    #    else the largest N that fits (extrapolated N^2 / N^3 per stage)
+    # 2. the workload's own N: EVERY multi-thread count of the sweep re-timed on the workload's own matrix, best first
+    #    (dpotrf's dgemm share grows with N, so the ranking at N_s need not hold), while the budget lasts; if the
+    #    size itself does not fit: the largest N that does (extrapolated N^2 / N^3 per stage)
     best_gf = sweep[order[0]] if order else 30.0
-    est = (n**3 / 3) / (best_gf * 1e9) + 8e-9 * n * n
+    est = (n**3 / 3) / (best_gf * 1e9)
     n_eval, extrap = n, False
-    while est > 0.6 * budget_s and n_eval > 4096:
+    while est + 8e-9 * n_eval * n_eval > 0.5 * budget_s and n_eval > 4096:
         n_eval //= 2
         est /= 8
         extrap = True
-    runs = {}
-    for th in (order[:2] if order else [cores]):
-        if runs and time.perf_counter() - t_start + est > 1.3 * budget_s:
-            break
-        runs[th] = evaluate(n_eval, th)
-    threads = min(runs, key=lambda th: sum(runs[th][0]))
-    stages, ll = runs[threads]
+    cand = [th for th in order if th > 1] or order or [cores]
+    stages, ll, potrf_s = evaluate(n_eval, cand, est)
+    threads = min(potrf_s, key=potrf_s.get)
     if extrap:
         f2, f3 = (n / n_eval) ** 2, (n / n_eval) ** 3
         t_full = stages[0] * f2 + stages[1] * f3 + stages[2] * f2
@@ -322,23 +338,22 @@ def cpu_baseline(spec, budget_s=75.0):
     one = {}
     for nn in (2048, 4096):
         if nn <= n and time.perf_counter() - t_start < 1.6 * budget_s:
-            st, _ = evaluate(nn, 1)
+            st, _, _ = evaluate(nn, [1])
             one[str(nn)] = {"seconds": sum(st), "potrf_gflops": (nn**3 / 3) / st[1] / 1e9}
     return {
         "value": 1.0 / t_full, "unit": "evals/s", "cores": threads, "threads": threads, "host_cores": cores,
         "kind": "port",
         "sample": (f"oracle/tinygp_np.py formulas + raw LAPACK dpotrf (in place, Fortran order) / dtrtrs from SciPy's "
                    f"OpenBLAS: one full evaluation {'MEASURED' if not extrap else 'measured'} at N={n_eval} with "
-                   f"{threads} threads = the faster of the full-size runs at the sweep's best thread counts "
-                   f"{sorted(runs)} (sweep over {sorted(sweep)} threads on a {ns}^2 dpotrf, warm pool; `cores` = threads "
+                   f"{threads} threads = the fastest of the full-size dpotrf runs at {sorted(potrf_s)} threads "
+                   f"(first: sweep over {sorted(sweep)} threads on a {ns}^2 dpotrf, warm pool; `cores` = threads "
                    f"used, the box has {cores}): assembly {stages[0]:.2f}s potrf {stages[1]:.2f}s solve+reduce "
                    f"{stages[2]:.3f}s" + ("; " + "; ".join(notes) if notes else "")),
         "potrf_gflops": (n_eval**3 / 3) / stages[1] / 1e9,
         "thread_sweep_potrf_gflops": {str(k): v for k, v in sweep.items()},
         "thread_sweep_n": ns,
         "blas_threads_seen_by_threadpoolctl": {str(k): v for k, v in seen.items()},
-        "full_size_runs": {str(th): {"seconds": sum(r[0]), "potrf_gflops": (n_eval**3 / 3) / r[0][1] / 1e9}
-                           for th, r in runs.items()},
+        "full_size_potrf_gflops": {str(th): (n_eval**3 / 3) / t / 1e9 for th, t in potrf_s.items()},
         "one_thread": one,
         "loglik_sample": ll,
     }
