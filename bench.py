@@ -265,7 +265,9 @@ def cpu_baseline(spec, budget_s=75.0):
     work = np.empty_like(K0, order="F")
     time_potrf(K0, work, cores)  # first touch of `work`'s pages, library start-up: outside every measurement
     sweep, seen = {}, {}
-    for th in sorted({t for t in (1, 8, 16, 32, 64, 128, cores) if t <= cores}):
+    ladder = [int(t) for t in os.environ.get("TGP_CPU_THREADS", "1,8,16,32,64,128").split(",")] + [cores]
+    cap = min(cores, blas_threads() or cores)  # OpenBLAS's own pool size (64 on a 256-core host): never ask beyond it
+    for th in sorted({min(t, cap) for t in ladder}):
         if time.perf_counter() - t_start > 0.45 * budget_s:
             notes.append(f"sweep stopped before {th} threads (time budget)")
             break
