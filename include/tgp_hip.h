@@ -108,6 +108,10 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       panel_step_kernel); 0 (default): potf2 | trsm | in-panel update as separate
  *                       launches.  "gate_split" (with fused_step = 1): the block-column update
  *                       between two chains in three column pieces, the chain starts behind the first
+ *   "chain_kernel"      1: the panel chain is ONE persistent launch per panel (two when an early share of the next
+ *                       gate branches off): tile tasks behind a ticket counter factor the diagonal blocks, solve
+ *                       the rows below and apply the in-panel updates left-looking, hand-offs by per-tile flag
+ *                       words (chol.hip, chain_kernel); no update stream, no per-block launches or events
  *   "chain_reserve"     workgroup slots (of two per CU) that a trailing update running beside a panel
  *                       chain leaves to the chain's kernels (default 128; 0: the update fills the chip)
  *   "reserve_max_tiles" ... when the update has at most this many 128x128 tiles (default 1200)
@@ -360,6 +364,9 @@ int tgp_dist_get_column(tgp_dist* h, int64_t l, void* out_host);
  *        8 residual copy into the work vector     9 final reductions
  *       10 fused panel step   v = {tile offset, pending-update operand offset or -1, rows below, ld,
  *                                  has_potf2}  (potf2 + per row tile: pending update, trsm)
+ *       11 persistent chain   v = {panel origin offset, ld, row tiles, first block column, end block column}
+ *                                  (potf2 of blocks [max(first, 1), end), the solves of the rows below and the
+ *                                  in-panel updates of those block columns: ONE launch)
  * `fused`: 1 = forward substitution fused into the factorisation.  `options`: "key=value,..." over the
  * names of tgp_ctx_set_option (the format of the TGP_HIP_OPTIONS environment variable), NULL or "" for
  * the library defaults -- the dry run takes every tuning the real run takes.
@@ -369,6 +376,13 @@ int tgp_dist_get_column(tgp_dist* h, int64_t l, void* out_host);
  * accesses is ordered by stream order or an event. */
 int tgp_trace_factor(int64_t n_pad, const char* options, int32_t fused, int64_t* out, int64_t cap_records,
                      int64_t* n_records);
+
+/* Measurement hook of the persistent panel chain (ctx option "chain_stamps" = 1 before a factorisation): per
+ * tile task of the chain launches since the last tgp_potrf / tgp_solver_factor* call, 16 int64 =
+ * {kind (0 bulk tile, 1 diagonal chain), row tile, block column, launch index, 12 time stamps} of the device's
+ * 100 MHz real-time counter (0 = phase not run), copied to `out` (at most cap_tasks tasks; *n_tasks = recorded).
+ * Phases: scripts/chain_timeline.py. */
+int tgp_chain_stamps(tgp_ctx* ctx, int64_t* out, int64_t cap_tasks, int64_t* n_tasks);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ from tinygp_amd import _ffi
 NSTREAMS = 5
 EV_G1, EV_G2 = 7, 8  # split gate: column block 1 / column blocks 2.. of the next panel
 KIND = {1: "potf2", 2: "trsm", 3: "gemm", 4: "trsv_step", 5: "record", 6: "wait", 7: "assembly",
-        8: "residual_copy", 9: "reductions", 10: "panel_step"}
+        8: "residual_copy", 9: "reductions", 10: "panel_step", 11: "chain"}
 
 
 def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1, wide_rows=0, **more):
@@ -99,6 +99,22 @@ def accesses(rec, T):
             R.add(("A", tr + i, tc)); W.add(("A", tr + i, tc))
             if v[1] >= 0:
                 R.add(("A", tr + i, tc - 1))
+    elif kind == 11:  # persistent chain: block columns [cb, ce) of the panel at (t0, t0): `rows` row tiles, nblk columns
+        ld, rows, cb, ce, nblk = v[1], v[2], v[3], v[4], v[5]
+        t0, t0c = tile(v[0], ld)
+        assert t0 == t0c and 0 <= cb < ce <= nblk <= rows
+        for c in range(cb, ce):  # factor / solve
+            R.add(("A", t0 + c, t0 + c)); R.add(("D", t0 + c))
+            if c > 0:  # (the panel's first block is factored by the potf2 launch in front)
+                W.add(("A", t0 + c, t0 + c)); W.add(("D", t0 + c))
+            for i in range(c + 1, rows):
+                R.add(("A", t0 + i, t0 + c)); W.add(("A", t0 + i, t0 + c))
+        if cb > 0:  # diag(cb) folds tile (cb, cb-1), solved by the launch before
+            R.add(("A", t0 + cb, t0 + cb - 1))
+        # right-looking: every later block column of the PANEL is updated by the columns factored here
+        for c in range(cb + 1, nblk):
+            for i in range(c, rows):
+                R.add(("A", t0 + i, t0 + c)); W.add(("A", t0 + i, t0 + c))
     elif kind == 4:
         ld = v[2]
         lr, lc = tile(v[0], ld)
@@ -193,6 +209,19 @@ CONFIGS = [
     (5120, 1024, 1, 5, 1100, 3, 0, dict(nb_first=256)),
     (5248, 1024, 1, 5, 1100, 3, 0, dict(nb_first=512, sub_panel=512)),
     (16384, 1024, 1, 5, 1100, 3, 0, dict(sub_panel=512, nb_first=768)),
+    # the persistent chain: one launch per panel (two with an early share), no in-panel update launches
+    (128, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1)),
+    (1152, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1)),
+    (2560, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1)),
+    (2560, 1024, 1, 5, 1100, 2, 0, dict(chain_kernel=1)),
+    (5120, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1)),
+    (5120, 1024, 0, 5, 1100, 3, 0, dict(chain_kernel=1)),
+    (5120, 1024, 1, 0, 1100, 3, 0, dict(chain_kernel=1)),
+    (5120, 512, 1, 3, 1100, 3, 0, dict(chain_kernel=1)),
+    (3456, 1024, 1, 7, 0, 3, 0, dict(chain_kernel=1)),
+    (8192, 1024, 1, 5, 1100, 3, 3000, dict(chain_kernel=1)),
+    (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1)),
+    (5248, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, nb_first=512)),
 ]
 
 
@@ -207,13 +236,22 @@ def test_schedule_has_no_data_race(cfg):
     recs = trace(*cfg[:7], **(cfg[7] if len(cfg) > 7 else {}))
     T = n_pad // 128
     # every block column is factored exactly once, in order
-    potf2 = [(r[2] % r[4]) // 128 for r in recs if r[0] == 1] + \
-            [(r[2] % r[5]) // 128 for r in recs if r[0] == 10 and r[6] == 1]
-    assert sorted(potf2) == list(range(T))
-    order = [(r[2] % (r[4] if r[0] == 1 else r[5])) // 128 for r in recs
-             if r[0] == 1 or (r[0] == 10 and r[6] == 1)]
+    def factored(r):  # block columns a record factors
+        if r[0] == 1:
+            return [(r[2] % r[4]) // 128]
+        if r[0] == 10 and r[6] == 1:
+            return [(r[2] % r[5]) // 128]
+        if r[0] == 11:  # chain over [cb, ce) of a panel: every diagonal block but the panel's first
+            t0 = (r[2] % r[3]) // 128
+            return [t0 + c for c in range(max(r[5], 1), r[6])]
+        return []
+
+    order = [j for r in recs for j in factored(r)]
     assert order == list(range(T))
-    if cfg[5] & 2:
+    if len(cfg) > 7 and cfg[7].get("chain_kernel"):
+        assert not any(r[0] in (2, 10) for r in recs)            # no trsm / panel-step launches ...
+        assert not any(r[0] == 3 and r[1] == 3 for r in recs)    # ... and nothing on the update stream's GEMM queue
+    elif cfg[5] & 2:
         assert not any(r[0] == 10 for r in recs)
     else:
         assert not any(r[0] == 2 for r in recs)  # every trsm of the chain rides in a panel step

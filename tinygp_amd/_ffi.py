@@ -99,6 +99,7 @@ SIGNATURES = {
     "tgp_solver_device_factor": [_vp, _pvp, _pi64],
     "tgp_solver_timings": [_vp, _pdbl, _int],
     "tgp_trace_factor": [_i64, C.c_char_p, _i32, _pi64, _i64, _pi64],
+    "tgp_chain_stamps": [_vp, _pi64, _i64, _pi64],
     "tgp_dist_slot_elems": [_i64, _i64],
     "tgp_dist_create": [_vp, _int, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _pvp],
     "tgp_dist_destroy": [_vp],
@@ -199,7 +200,7 @@ class Ctx:
         return old.value
 
     # the options that shape the factorisation's schedule (tgp_trace_factor takes the same names)
-    SCHEDULE_OPTIONS = ("nb_outer", "lookahead", "first_split", "first_small_tiles", "nb_wide_rows", "fused_step",
+    SCHEDULE_OPTIONS = ("nb_outer", "lookahead", "first_split", "first_small_tiles", "nb_wide_rows", "fused_step", "chain_kernel",
                         "gate_split", "chain_reserve", "reserve_max_tiles", "sub_panel", "sub_panel_min_rows",
                         "nb_first", "split_tail", "solve_on_update")
 

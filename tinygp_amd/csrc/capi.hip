@@ -174,6 +174,10 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipMalloc(&ctx->d_info, sizeof(int32_t)));
   TGP_HIP_TRY(hipMalloc(&ctx->d_step_flag, 64));
   TGP_HIP_TRY(hipMemset(ctx->d_step_flag, 0, 64));
+  TGP_HIP_TRY(hipMalloc(&ctx->d_chain_flags, size_t(tgp::CHAIN_MAX_ROW_TILES) * 16 * sizeof(uint32_t)));
+  TGP_HIP_TRY(hipMemset(ctx->d_chain_flags, 0, size_t(tgp::CHAIN_MAX_ROW_TILES) * 16 * sizeof(uint32_t)));
+  TGP_HIP_TRY(hipMalloc(&ctx->d_chain_ticket, 64));
+  TGP_HIP_TRY(hipMemset(ctx->d_chain_ticket, 0, 64));
   hipDeviceProp_t prop;
   TGP_HIP_TRY(hipGetDeviceProperties(&prop, device));
   ctx->cus = prop.multiProcessorCount;
@@ -211,6 +215,9 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
   if (ctx->d_scal) hipFree(ctx->d_scal);
   if (ctx->d_info) hipFree(ctx->d_info);
   if (ctx->d_step_flag) hipFree(ctx->d_step_flag);
+  if (ctx->d_chain_flags) hipFree(ctx->d_chain_flags);
+  if (ctx->d_chain_ticket) hipFree(ctx->d_chain_ticket);
+  if (ctx->d_chain_stamps) hipFree(ctx->d_chain_stamps);
   if (ctx->d_dinv) hipFree(ctx->d_dinv);
   if (ctx->d_work) hipFree(ctx->d_work);
   if (ctx->d_gemm_ws) hipFree(ctx->d_gemm_ws);
@@ -239,6 +246,8 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "dist_solve_aux")) return &ctx->dist_solve_aux;
   if (!strcmp(key, "solve_on_update")) return &ctx->solve_on_update;
   if (!strcmp(key, "fused_step")) return &ctx->fused_step;
+  if (!strcmp(key, "chain_kernel")) return &ctx->chain_kernel;
+  if (!strcmp(key, "chain_stamps")) return &ctx->chain_stamps;
   if (!strcmp(key, "chain_reserve")) return &ctx->chain_reserve;
   if (!strcmp(key, "gate_split")) return &ctx->gate_split;
   if (!strcmp(key, "reserve_max_tiles")) return &ctx->reserve_max_tiles;
@@ -1092,6 +1101,19 @@ int tgp_solver_timings(tgp_solver* s, double* ms, int n) {
   SOLVER_GUARD(s);
   TGP_ARG_CHECK(ms != nullptr && n >= 0, "bad argument");
   for (int i = 0; i < n && i < 8; ++i) ms[i] = s->ms[i];
+  return TGP_OK;
+}
+
+int tgp_chain_stamps(tgp_ctx* ctx, int64_t* out, int64_t cap_tasks, int64_t* n_tasks) {
+  CTX_GUARD(ctx);
+  TGP_ARG_CHECK(out != nullptr && n_tasks != nullptr && cap_tasks >= 0, "chain_stamps: bad argument");
+  const int64_t n = std::min<int64_t>(ctx->d_chain_stamps ? ctx->chain_stamp_base : 0, cap_tasks);
+  *n_tasks = n;
+  if (n > 0) {
+    for (hipStream_t q : {ctx->stream, ctx->panel_stream, ctx->update_stream})
+      if (q) TGP_HIP_TRY(hipStreamSynchronize(q));
+    TGP_HIP_TRY(hipMemcpy(out, ctx->d_chain_stamps, size_t(n) * 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
+  }
   return TGP_OK;
 }
 

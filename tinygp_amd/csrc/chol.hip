@@ -352,6 +352,472 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   trsm_fold_body<T, FOLD>(S, b - has_p, A, ld, dinv, Xp, flag, epoch, has_p, info);
 }
 
+// ---------------------------------------------------------------------------------------
+// Persistent panel chain (round 4): ONE launch factors block columns [cb, ce) of a panel -- every potf2, every
+// solve of the rows below AND every in-panel update -- instead of [potf2 | trsm | rank-128 update] x blocks on
+// two streams with an event pair per block.  No dependent-launch gaps (7 us each, two per block), no update
+// stream, nothing for the host to submit per block.
+//
+// Work = tile tasks, one per workgroup, handed out by a ticket counter in an order in which every task depends on
+// EARLIER tickets only, so a workgroup never waits for one that has not started (no co-residency requirement):
+//
+//   diag(c)        the diagonal chain's own workgroup: solves tile (c, c-1) the moment L_{c-1,c-1} is published,
+//                  publishes it, folds it -- X_{c,c-1} never leaves the registers -- into tile (c, c) and factors
+//                  that (potf2).  Between two potf2 there is ONE hand-off.
+//   solve(i, c)    X_ic = A_ic L_cc^-T for the other rows (transposed recurrence, as trsm_fold_body)
+//   update(i,c,k)  A_ic -= X_ik X_ck^T, one 128 x 128 x 128 product per task (lower blocks only on the diagonal):
+//                  right-looking, so that the updates behind column k spread over the whole chip the moment its
+//                  tiles are solved.  (A first version accumulated them left-looking inside the task that solves
+//                  the tile: one compute unit then owes a tile up to seven products of 22-32 us each, and the
+//                  chain waited for exactly those -- profiles/r04_b.)  The update (c, c, c-1) is diag(c)'s fold.
+//   order          per column k: diag(k+1), solve(.., k), update(.., c, k) for c = k+1 .. (column k+1 first)
+//
+// State of tile (i, c) = ONE word, epoch * 32 + s: s = k + 1 once the updates from block columns <= k are applied
+// (those from columns < cb were applied by the launches before), s = 31 once the tile is final.  The epoch is the
+// launch's (nothing to reset).  Hand-offs follow MI355X_MICROARCH.md / cdna_hip_programming.md Guideline 16, form
+// R1: everything another workgroup reads is stored WRITE-THROUGH (agent-scope relaxed atomic stores = `sc1`), every
+// storing wave drains (`s_waitcnt vmcnt(0)`), barrier, ONE lane stores the word; a consumer polls with ONE wave
+// (relaxed, s_sleep), ONE agent-scope acquire, barrier, then plain loads.  Every poll is bounded and a timeout
+// poisons `info` for all (STEP_TIMEOUT): a lost producer ends in an error code, never in a hung GPU.
+// ---------------------------------------------------------------------------------------
+template <typename T> struct AgentBits;
+template <> struct AgentBits<double> { using t = unsigned long long; };
+template <> struct AgentBits<float> { using t = unsigned int; };
+template <typename T>
+__device__ __forceinline__ void st_agent(T* p, T v) {
+  typename AgentBits<T>::t b;
+  __builtin_memcpy(&b, &v, sizeof(T));
+  __hip_atomic_store(reinterpret_cast<typename AgentBits<T>::t*>(p), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// time stamp k of this workgroup's task (100 MHz real-time counter; the hook is off unless chain_stamps = 1)
+__device__ __forceinline__ void chain_stamp(long long* st, int k) {
+  if (st != nullptr && threadIdx.x == 0) st[4 + k] = (long long)__builtin_amdgcn_s_memrealtime();
+}
+
+constexpr int CHAIN_FLAG_LD = 16;  // state word of tile (i, c) of the panel: flags[i * 16 + c] (panels are <= 2048 wide)
+constexpr uint32_t CHAIN_FINAL = 31;
+
+template <typename T>
+struct ChainArgs {
+  T* A0;        // the panel's origin: tile (i, c) at A0 + c * 128 * ld + i * 128
+  int64_t ld;
+  T* dinv;      // 16 x 16 inverses of the panel's diagonal blocks, 2048 entries per block column
+  int32_t* info;
+  uint32_t* flags;
+  int32_t* ticket;
+  uint32_t epoch32;    // epoch * 32
+  int32_t pivot_base;  // global index of the panel's first pivot
+  int32_t R;           // row tiles of the panel (rows of A0 down to the end of the matrix)
+  int32_t nblk;        // block columns of the panel
+  int32_t cb, ce;      // block columns [cb, ce) of the panel are factored by this launch; [0, cb) are final, and so
+                       // is L_00 when cb == 0 (a panel's first block is factored by potf2_kernel in front)
+  long long* stamps;   // measurement hook (ctx option chain_stamps): 16 words per task from this base, or NULL
+  int32_t launch;
+};
+
+// all threads; wave 0 polls up to three state words (lane l: word f[l] == v[l]; NULL: nothing to wait for),
+// one acquire, barrier.  NAP: s_sleep between polls (the diagonal chain polls eagerly, the others politely).
+template <int NAP>
+__device__ __forceinline__ void chain_wait(const uint32_t* f0, uint32_t v0, const uint32_t* f1, uint32_t v1,
+                                           const uint32_t* f2, uint32_t v2, int32_t* info) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const uint32_t* f = lane == 0 ? f0 : (lane == 1 ? f1 : (lane == 2 ? f2 : nullptr));
+    const uint32_t want = lane == 0 ? v0 : (lane == 1 ? v1 : v2);
+    bool ok = f == nullptr || __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+    int spin = 0;
+    while (!__all(ok)) {
+      __builtin_amdgcn_s_sleep(NAP);
+      if (!ok) ok = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+      ++spin;
+      bool dead = false;
+      if ((spin & 255) == 0 && lane == 0)  // somebody timed out, or this wait has lasted a few tenths of a second
+        dead = spin >= (1 << 18) || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == STEP_TIMEOUT;
+      if (__any(dead)) {
+        if (lane == 0) atomicExch(info, STEP_TIMEOUT);
+        break;
+      }
+    }
+    if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+// every storing wave has drained -> barrier -> one lane publishes the tile's new state
+__device__ __forceinline__ void chain_publish(uint32_t* word, uint32_t value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// update(i, c, k), i > c:  A_ic -= X_ik X_ck^T.  128 x 128 x 128 on the MFMAs, operands double-buffered through S
+// as in trsm_fold_body; the tile is read and written once, write-through.
+template <typename T>
+__device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, int i, int c, int k) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lk = lane >> 4;
+  const int64_t ld = q.ld;
+  constexpr int FK = 16, F_LD = 144;  // as gemm_nt: [k][128 rows], 144 mod 32 == 16
+  static_assert(4 * FK * F_LD == 36 * 256, "the operand buffers are exactly potf2's tile image");
+  T* sA = S;                  // [2][FK * F_LD]
+  T* sB = S + 2 * FK * F_LD;  // [2][FK * F_LD]
+  const int wr = w >> 1, wc = w & 1;  // wave tile: 32 rows x 64 columns
+  acc_t acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+  const T* Xi = q.A0 + int64_t(k) * TILE * ld + int64_t(i) * TILE;
+  const T* Xj = q.A0 + int64_t(k) * TILE * ld + int64_t(c) * TILE;
+  T2 ra[2], rb[2];
+  auto load_global = [&](int kt) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int64_t kk = int64_t(kt) * FK + w + 8 * r;
+      ra[r] = *reinterpret_cast<const T2*>(Xi + kk * ld + lane * 2);
+      rb[r] = *reinterpret_cast<const T2*>(Xj + kk * ld + lane * 2);
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int kk = w + 8 * r;
+      *reinterpret_cast<T2*>(&sA[buf * FK * F_LD + kk * F_LD + lane * 2]) = ra[r];
+      *reinterpret_cast<T2*>(&sB[buf * FK * F_LD + kk * F_LD + lane * 2]) = rb[r];
+    }
+  };
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  constexpr int nkt = TILE / FK;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_global(kt + 1);
+    const T* pa = &sB[buf * FK * F_LD + lk * F_LD + wc * 64 + lrow];  // MFMA A operand <- Xj rows (C column)
+    const T* pb = &sA[buf * FK * F_LD + lk * F_LD + wr * 32 + lrow];  // MFMA B operand <- Xi rows (C row)
+#pragma unroll
+    for (int ks = 0; ks < FK / 4; ++ks) {
+      T aop[4], bop[2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bop[b] = pb[ks * 4 * F_LD + b * 16];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = M::mma(aop[a], bop[b], acc[a][b]);
+    }
+    if (kt + 1 < nkt) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+  // C[wr*32 + b*16 + lrow, wc*64 + a*16 + drow(lane, r)] -= acc[a][b][r]
+  T* Cu = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + int64_t(wc * 64) * ld + wr * 32;
+  const uint32_t coff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    T cc[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cc[b][r] = (Cu + int64_t(a * 16 + M::drow(0, r)) * ld + b * 16)[coff];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        st_agent(Cu + int64_t(a * 16 + M::drow(0, r)) * ld + b * 16 + coff, T(cc[b][r] - acc[a][b][r]));
+    __builtin_amdgcn_sched_barrier(0);  // one pass of eight loads at a time (register budget: 128)
+  }
+}
+
+// update(c, c, k): the diagonal tile (c, c) -= X_ck X_ck^T, lower 16 x 16 blocks only (potf2's fold: block pairs
+// spread 5 / 4 over the waves, the slabs exchanged through S), write-through.
+template <typename T>
+__device__ __forceinline__ void chain_update_diag(const ChainArgs<T>& q, T* S, int c, int k) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lk = lane >> 4;
+  const int64_t ld = q.ld;
+  constexpr int XC_LD = 144;
+  T* Xc = S;
+  const int pr = w & 3, i1 = pr, i2 = 7 - pr;
+  const int t0 = (w < 4) ? 0 : 5, nt = (w < 4) ? 5 : 4;
+  acc_t Cf[5];
+#pragma unroll
+  for (int tt = 0; tt < 5; ++tt) Cf[tt] = acc_t{0, 0, 0, 0};
+  const T* Xk = q.A0 + int64_t(k) * TILE * ld + int64_t(c) * TILE;
+  acc_t V[8];
+  const int xoff = M::drow(lane, 0) * int(ld) + lrow;
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) V[jb][r] = (Xk + int64_t(jb * 16 + M::drow(0, r)) * ld + w * 16)[xoff];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Xc[((jq * 4 + r) * 4 + lk) * XC_LD + w * 16 + lrow] = V[h * 4 + jq][r];
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const T* row = &Xc[(ks * 4 + lk) * XC_LD + lrow];
+      const T b1 = row[i1 * 16], b2 = row[i2 * 16];
+#pragma unroll
+      for (int tt = 0; tt < 5; ++tt) {
+        if (tt < nt) {
+          const int t = t0 + tt;
+          const bool first = t <= pr;
+          const int jj = first ? t : t - pr - 1;
+          Cf[tt] = M::mma(row[jj * 16], first ? b1 : b2, Cf[tt]);
+        }
+      }
+    }
+  }
+  T* Acc = q.A0 + int64_t(c) * TILE * ld + int64_t(c) * TILE;
+#pragma unroll
+  for (int tt = 0; tt < 5; ++tt) {
+    if (tt < nt) {
+      const int t = t0 + tt;
+      const bool first = t <= pr;
+      const int ii = first ? i1 : i2, jj = first ? t : t - pr - 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T* pe = Acc + int64_t(jj * 16 + M::drow(lane, r)) * ld + ii * 16 + lrow;
+        st_agent(pe, T(*pe - Cf[tt][r]));
+      }
+    }
+  }
+}
+
+// solve(i, c): X_ic = A_ic L_cc^-T by the transposed recurrence (L_cc with the 16 x 16 inverses in its diagonal
+// slots staged in S).  The caller has waited for the tile's updates and for L_cc.  The solved tile is stored
+// write-through; V returns -Y (the operand layout of potf2's fold).
+template <typename T>
+__device__ __forceinline__ void chain_solve(const ChainArgs<T>& q, T* S, int i, int c,
+                                            typename Mfma<T>::acc_t (&V)[8], long long* st, int s0) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15, lk = lane >> 4;
+  const int64_t ld = q.ld;
+  T* Bt = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE;
+  const T* Ljj = q.A0 + int64_t(c) * TILE * ld + int64_t(c) * TILE;
+  const T* dinv = q.dinv + int64_t(c) * 2048;
+  // this wave's 16 rows of the tile, D layout
+  T* bu = Bt + w * 16;  // wave-uniform; lane offset below
+  const uint32_t boff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) V[jb][r] = (bu + int64_t(jb * 16 + M::drow(0, r)) * ld)[boff];
+  // L_cc -> LDS in potf2's block image: the 28 blocks below the diagonal as they are, the diagonal
+  // slots take the 16 x 16 inverses (all a solve needs of a diagonal block).  In two rounds of blocks (3 + 2 per
+  // wave): the tile's 64 registers are live beside the staging registers, and five blocks at once spill.
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    constexpr int NTR = 3;
+    T tr[NTR][4];
+    const int t_lo = round * NTR, t_n = round == 0 ? NTR : 5 - NTR;
+#pragma unroll
+    for (int tq = 0; tq < NTR; ++tq) {
+      const int b = w + 8 * (t_lo + tq);
+      if (tq < t_n && b < 36) {
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+        const int bj = b - bi * (bi + 1) / 2;
+        if (bi == bj) {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) tr[tq][qq] = dinv[bi * 256 + qq * 64 + lane];
+        } else {
+          const int voff = lk * int(ld) + lrow;
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) tr[tq][qq] = (Ljj + int64_t(bj * 16 + qq * 4) * ld + bi * 16)[voff];
+        }
+      }
+    }
+#pragma unroll
+    for (int tq = 0; tq < NTR; ++tq) {
+      const int b = w + 8 * (t_lo + tq);
+      if (tq < t_n && b < 36) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) S[b * 256 + qq * 64 + lane] = tr[tq][qq];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  chain_stamp(st, s0);  // tile in registers, L_cc staged in LDS
+  T* bs = bu;  // the stores recompute their addresses
+  asm volatile("" : "+s"(bs));
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    acc_t acc = V[jb], acc2 = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb < jb; ++kb) {
+      const T* Lb = &S[blk(jb, kb)];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const T l = Lb[M::drow(lane, s) * 16 + lrow];
+        if (s & 1) acc2 = M::mma(l, V[kb][s], acc2);
+        else acc = M::mma(l, V[kb][s], acc);
+      }
+    }
+    acc += acc2;
+    const T* Db = &S[blk(jb, jb)];
+    acc_t y = acc_t{0, 0, 0, 0}, y2 = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const T d = Db[M::drow(lane, s) * 16 + lrow];
+      if (s & 1) y2 = M::mma(d, acc[s], y2);
+      else y = M::mma(d, acc[s], y);
+    }
+    y += y2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st_agent(bs + int64_t(jb * 16 + M::drow(0, r)) * ld + boff, T(y[r]));
+    V[jb] = -y;
+  }
+  chain_stamp(st, s0 + 1);  // solved, stores issued
+}
+
+// One task per workgroup (grid = number of tasks): a task loop inside the kernel lets the compiler hoist the
+// lane-derived values of every phase across the whole loop body -- 100+ spilled VGPRs under the 128-register cap
+// that keeps two chain workgroups on a CU beside the trailing update.  Tickets are taken at workgroup start, so
+// every earlier ticket belongs to a workgroup that is running or done, whatever order the hardware starts them in.
+template <typename T>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void chain_kernel(const ChainArgs<T> q) {
+  __shared__ __attribute__((aligned(16))) T S[36 * 256];
+  __shared__ T Rs[2 * 16];
+  __shared__ T Dg[256];
+  __shared__ int s_task[5];
+  using acc_t = typename Mfma<T>::acc_t;
+  if (threadIdx.x == 0) {
+    // ticket -> task.  diag(cb) first in a continuation launch (a panel's very first block is factored in front of
+    // the launch); then per column k: diag(k+1) [if in range], solve(r0.., k) with r0 = k + 2 while diag(k+1) owns
+    // tile (k+1, k), update(i, c, k) for c = k+1 .. nblk-1 and i = c .. R-1 without (k+1, k+1, k) = diag(k+1)'s fold
+    int t = atomicAdd(q.ticket, 1);
+    s_task[4] = t;
+    int kind = -1, ti = 0, tc = 0, tk = 0;  // kind: 0 solve, 1 diag, 2 update, 3 update of a diagonal tile
+    if (q.cb > 0) {
+      if (t == 0) { kind = 1; tc = q.cb; }
+      --t;
+    }
+    for (int k = q.cb; k < q.ce && kind < 0; ++k) {
+      const bool next_diag = k + 1 < q.ce;
+      if (next_diag) {
+        if (t == 0) { kind = 1; tc = k + 1; break; }
+        --t;
+      }
+      const int r0 = next_diag ? k + 2 : k + 1;
+      const int ns = q.R - r0 > 0 ? q.R - r0 : 0;
+      if (t >= 0 && t < ns) { kind = 0; ti = r0 + t; tc = k; break; }
+      t -= ns;
+      for (int c = k + 1; c < q.nblk; ++c) {
+        const int i0 = c == k + 1 ? c + 1 : c;
+        const int nu = q.R - i0 > 0 ? q.R - i0 : 0;
+        if (t >= 0 && t < nu) { ti = i0 + t; tc = c; tk = k; kind = ti == c ? 3 : 2; break; }
+        t -= nu;
+      }
+    }
+    s_task[0] = kind; s_task[1] = ti; s_task[2] = tc; s_task[3] = tk;
+  }
+  __syncthreads();
+  const int kind = __builtin_amdgcn_readfirstlane(s_task[0]);
+  const int ti = __builtin_amdgcn_readfirstlane(s_task[1]);
+  const int tc = __builtin_amdgcn_readfirstlane(s_task[2]);
+  const int tk = __builtin_amdgcn_readfirstlane(s_task[3]);
+  if (kind < 0) return;
+  long long* st = nullptr;
+  if (q.stamps != nullptr) {  // {kind, row tile, block column, launch | update column << 8, stamps ...}
+    st = q.stamps + int64_t(__builtin_amdgcn_readfirstlane(s_task[4])) * 16;
+    if (threadIdx.x == 0) {
+      st[0] = kind; st[1] = kind == 1 ? tc : ti; st[2] = tc; st[3] = q.launch | (tk << 8);
+      for (int k = 1; k < 12; ++k) st[4 + k] = 0;
+    }
+    chain_stamp(st, 0);  // task started
+  }
+  const uint32_t E = q.epoch32;
+  const bool head_final = q.cb == 0;  // L_00 was factored in front of the launch
+  if (kind >= 2) {  // ---- update(i, c, k) ----
+    const int i = ti, c = tc, k = tk;
+    uint32_t* wt = q.flags + i * CHAIN_FLAG_LD + c;
+    chain_wait<8>(q.flags + i * CHAIN_FLAG_LD + k, E + CHAIN_FINAL, q.flags + c * CHAIN_FLAG_LD + k, E + CHAIN_FINAL,
+                  k > q.cb ? wt : nullptr, E + uint32_t(k), q.info);
+    chain_stamp(st, 1);  // operands final, the tile carries every earlier update
+    if (kind == 2) chain_update_full<T>(q, S, i, c, k);
+    else chain_update_diag<T>(q, S, c, k);
+    chain_stamp(st, 2);
+    chain_publish(wt, E + uint32_t(k + 1));
+    chain_stamp(st, 3);
+    return;
+  }
+  __builtin_amdgcn_s_setprio(2);
+  if (kind == 0) {  // ---- solve(i, c) ----
+    const int i = ti, c = tc;
+    uint32_t* wt = q.flags + i * CHAIN_FLAG_LD + c;
+    const uint32_t* wl = q.flags + c * CHAIN_FLAG_LD + c;
+    chain_wait<4>(c > q.cb ? wt : nullptr, E + uint32_t(c), (c == 0 && head_final) ? nullptr : wl, E + CHAIN_FINAL,
+                  nullptr, 0, q.info);
+    chain_stamp(st, 1);
+    acc_t V[8];
+    chain_solve<T>(q, S, i, c, V, st, 2);
+    chain_publish(wt, E + CHAIN_FINAL);
+    chain_stamp(st, 4);
+    return;
+  }
+  // ---- diag(c) ----
+  const int c = tc;
+  T* A = q.A0 + int64_t(c) * TILE * q.ld + int64_t(c) * TILE;
+  const int64_t ld = q.ld;
+  T* dinv = q.dinv + int64_t(c) * 2048;
+  int32_t* info = q.info;
+  const int32_t pivot_base = q.pivot_base + c * TILE;
+  uint32_t* frow = q.flags + c * CHAIN_FLAG_LD;
+  acc_t Vx[8];  // (+-) X_{c,c-1}: row w * 16 + lrow, column jb * 16 + drow(lane, r)
+  if (c > q.cb) {
+    // tile (c, c-1): its updates (from columns cb .. c-2 of this launch) and L_{c-1,c-1}
+    const uint32_t* wl = q.flags + (c - 1) * CHAIN_FLAG_LD + (c - 1);
+    chain_wait<1>(c - 1 > q.cb ? frow + (c - 1) : nullptr, E + uint32_t(c - 1),
+                  (c - 1 == 0 && head_final) ? nullptr : wl, E + CHAIN_FINAL, nullptr, 0, q.info);
+    chain_stamp(st, 1);
+    chain_solve<T>(q, S, c, c - 1, Vx, st, 2);
+    chain_publish(frow + (c - 1), E + CHAIN_FINAL);  // the updates behind column c-1 and the next solves need it NOW
+    chain_stamp(st, 4);
+    // tile (c, c) with the updates from columns cb .. c-2 (the one from c-1 is the fold below)
+    if (c - 1 > q.cb) chain_wait<1>(frow + c, E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
+    else __syncthreads();  // (every wave is done with L_{c-1,c-1}'s image in S)
+    chain_stamp(st, 5);
+  } else {
+    using M = Mfma<T>;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const T* Xp = A - int64_t(TILE) * ld;  // tile (c, c-1), final since the previous launch
+    const int xoff = M::drow(lane, 0) * int(ld) + (lane & 15);
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Vx[jb][r] = (Xp + int64_t(jb * 16 + M::drow(0, r)) * ld + w * 16)[xoff];
+  }
+  {
+    constexpr bool FOLD = true;
+#define POTF2_ST(p, v) st_agent((p), T(v))
+#define POTF2_V_IN_REGS Vx
+#include "potf2_body.inc"
+#undef POTF2_V_IN_REGS
+#undef POTF2_ST
+  }
+  chain_stamp(st, 6);  // factored, stores issued
+  chain_publish(frow + c, E + CHAIN_FINAL);
+  chain_stamp(st, 7);  // L_cc published
+}
+
 // dinv for an existing factor: one thread per (16-block, column)
 template <typename T>
 __global__ __launch_bounds__(256) void dinv_kernel(int64_t n, const T* __restrict__ L, int64_t ld,
@@ -1095,6 +1561,50 @@ int launch_panel_step(tgp_ctx* ctx, hipStream_t st, int64_t m, T* Ljj, int64_t l
   return TGP_OK;
 }
 
+// Persistent chain over block columns [cb, ce) of the panel whose origin is A0 (R row tiles down to the end of
+// the matrix; dinv0 = the inverses of the panel's first block).  head_done: L_cb,cb is already factored.
+template <typename T>
+int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int64_t pivot_base, int64_t R,
+                 int64_t nblk, int64_t cb, int64_t ce, bool head_done) {
+  TGP_ARG_CHECK(R >= 1 && R <= CHAIN_MAX_ROW_TILES && cb >= 0 && cb < ce && ce <= nblk && nblk <= CHAIN_FLAG_LD && nblk <= R,
+                "chain: bad panel shape (R=%lld, columns [%lld, %lld))", (long long)R, (long long)cb, (long long)ce);
+  // a panel's first block has no in-panel update pending: plain potf2 in front of the launch (in the look-ahead
+  // schedule it already ran on the main stream, in front of the big update: head_done)
+  if (cb == 0 && !head_done) TGP_TRY(launch_potf2<T>(ctx, st, A0, ld, dinv0, ctx->d_info, (int32_t)pivot_base));
+  if (ctx->trace) {  // v: panel origin offset, ld, row tiles, first / end block column
+    trace_push(ctx, 11, st, trace_off(ctx, A0), ld, R, cb, ce, nblk);
+    return TGP_OK;
+  }
+  int64_t tasks = cb > 0 ? 1 : 0;
+  for (int64_t k = cb; k < ce; ++k) {
+    const bool next_diag = k + 1 < ce;
+    tasks += next_diag ? 1 : 0;
+    tasks += std::max<int64_t>(0, R - (next_diag ? k + 2 : k + 1));
+    for (int64_t c = k + 1; c < nblk; ++c) tasks += std::max<int64_t>(0, R - (c == k + 1 ? c + 1 : c));
+  }
+  if (tasks == 0) return TGP_OK;
+  ctx->step_epoch = (ctx->step_epoch + 1) & 0x3FFFFFFu;  // the state words hold epoch * 32 + s
+  if (ctx->step_epoch == 0) ctx->step_epoch = 1;          // 0 is the words' initial value
+  const uint32_t epoch = ctx->step_epoch;
+  ChainArgs<T> q;
+  q.A0 = A0; q.ld = ld; q.dinv = dinv0; q.info = ctx->d_info; q.flags = ctx->d_chain_flags;
+  q.ticket = ctx->d_chain_ticket; q.epoch32 = epoch * 32u; q.pivot_base = (int32_t)pivot_base; q.R = (int32_t)R;
+  q.nblk = (int32_t)nblk;
+  q.cb = (int32_t)cb; q.ce = (int32_t)ce;
+  q.stamps = nullptr;
+  q.launch = (int32_t)ctx->chain_launches++;
+  if (ctx->chain_stamps != 0 && ctx->chain_stamp_base + tasks <= CHAIN_STAMP_TASKS) {
+    if (ctx->d_chain_stamps == nullptr)
+      TGP_HIP_TRY(hipMalloc((void**)&ctx->d_chain_stamps, size_t(CHAIN_STAMP_TASKS) * 16 * sizeof(long long)));
+    q.stamps = ctx->d_chain_stamps + ctx->chain_stamp_base * 16;
+    ctx->chain_stamp_base += tasks;
+  }
+  TGP_HIP_TRY(hipMemsetAsync(ctx->d_chain_ticket, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL((chain_kernel<T>), dim3((unsigned)tasks), dim3(512), 0, st, q);  // one task per workgroup
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
 template <typename T>
 int compute_dinv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* dinv) {
   if (n == 0) return TGP_OK;
@@ -1169,6 +1679,35 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
   const int64_t j_stop = blk_end < 0 ? k0 + kb : std::min<int64_t>(k0 + kb, k0 + blk_end * TILE);
   hipStream_t S3 = ctx->update_stream;
   hipStream_t S2 = ctx->solve_on_update != 0 ? S3 : ctx->solve_stream;  // behind the update of the same block
+  if (ctx->chain_kernel != 0 && kb / TILE <= CHAIN_FLAG_LD && (n - k0) / TILE <= CHAIN_MAX_ROW_TILES) {
+    // ONE persistent launch for the blocks to run now (two when the early share of the next gate branches off
+    // behind `after_blocks` blocks): potf2, the solves of the rows below and the in-panel updates are tile tasks
+    // of chain_kernel.  The forward-substitution steps of the blocks follow on the solve stream behind the launch.
+    const int64_t nblk = kb / TILE, R = (n - k0) / TILE;
+    const int64_t cb = blk_begin, ce = blk_end < 0 ? nblk : std::min<int64_t>(nblk, blk_end);
+    T* A0 = A + k0 * ld + k0;
+    T* d0 = dinv + (k0 / TILE) * 2048;
+    // (as in the per-block path: the early share exists when rows AND columns are left behind block after_blocks-1)
+    const bool want_mid = after_blocks > cb && after_blocks < ce && after_blocks < nblk && R > after_blocks;
+    int64_t seg[3] = {cb, want_mid ? after_blocks : ce, ce};
+    for (int part = 0; part < 2; ++part) {
+      const int64_t s0 = seg[part], s1 = seg[part + 1];
+      if (s0 >= s1) continue;
+      TGP_TRY(launch_chain<T>(ctx, st, A0, ld, d0, pivot_off + k0, R, nblk, s0, s1, head_done && s0 == 0));
+      const bool mid_here = want_mid && part == 0;
+      if (y != nullptr || mid_here) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
+      if (y != nullptr) {
+        TGP_TRY(st_wait(ctx, S2, ctx->ev_d));
+        for (int64_t c = s0; c < s1; ++c) {
+          const int64_t j0 = k0 + c * TILE;
+          TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, n - (j0 + TILE), A + j0 * ld + j0, ld, dinv + (j0 / TILE) * 2048,
+                                          y + j0));
+        }
+      }
+      if (mid_here) TGP_TRY(mid(ctx->ev_d));
+    }
+    return TGP_OK;
+  }
   if (ctx->fused_step != 0 && blk_begin == 0 && blk_end < 0) {
     // One launch per block (panel_step_kernel).  The rows' workgroups apply the update of THIS column
     // block from the previous one themselves, so the separate in-panel update of block j covers the
@@ -1276,6 +1815,8 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   if (NB < TILE) NB = TILE;
   NB = NB / TILE * TILE;
   if (!ctx->trace) TGP_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int32_t), S0));
+  ctx->chain_stamp_base = 0;
+  ctx->chain_launches = 0;
   const bool prof_on = ctx->profile != 0 && !ctx->trace;
   std::vector<ProfSpan> spans;
   ctx->ev_used = 0;

@@ -124,6 +124,16 @@ struct tgp_ctx {
   int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
   uint32_t* d_step_flag = nullptr;  // the flag potf2's workgroup publishes; value = step_epoch of the launch
   uint32_t step_epoch = 0;
+  // persistent panel chain (chol.hip, chain_kernel): ONE launch per panel (two with an early share) factors its
+  // block columns, solves the rows below and applies the in-panel updates -- tile tasks behind a ticket counter,
+  // hand-offs by per-tile flag words that carry the launch's epoch (0: potf2 | trsm | update launches per block)
+  int64_t chain_kernel = 0;
+  uint32_t* d_chain_flags = nullptr;  // CHAIN_MAX_ROW_TILES x 16 words, zero at allocation, never reset (epochs)
+  int32_t* d_chain_ticket = nullptr;  // zeroed in front of every launch
+  int64_t chain_stamps = 0;           // 1: every chain task records its phases' time stamps (tgp_chain_stamps)
+  long long* d_chain_stamps = nullptr;  // CHAIN_STAMP_TASKS x 16, allocated on first use
+  int64_t chain_stamp_base = 0;       // tasks recorded so far in this factorisation
+  int64_t chain_launches = 0;
   // small device scratch: scal[0..15] doubles, info int
   double* d_scal = nullptr;
   int32_t* d_info = nullptr;
@@ -252,6 +262,12 @@ template <typename T>
 int launch_panel_step(tgp_ctx* ctx, hipStream_t st, int64_t m, T* Ljj, int64_t ld, T* dj, int32_t* info,
                       int32_t pivot_base, const T* Xp, bool has_p);
 
+constexpr int64_t CHAIN_MAX_ROW_TILES = 4096;  // panels of up to 524 288 rows
+constexpr int64_t CHAIN_STAMP_TASKS = 32768;
+// persistent chain over block columns [cb, ce) of the panel at A0 (R row tiles, nblk block columns; chol.hip)
+template <typename T>
+int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int64_t pivot_base, int64_t R,
+                 int64_t nblk, int64_t cb, int64_t ce, bool head_done);
 template <typename T>
 int panel_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int64_t pivot_off,
                 int64_t j0, bool pend);
