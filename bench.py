@@ -79,7 +79,7 @@ def traced_update_bytes(options: dict, n_pad: int, itemsize: int):
                                            C.byref(n)), "tgp_trace_factor")
     total, launches, flops = 0, 0, 0.0
     for r in out[: n.value * 10].reshape(-1, 10):
-        if r[0] == 3 and (r[8] >> 8) == 0 and r[1] == 0:  # gemm, role 0 (128x128 tiles), main stream
+        if r[0] == 3 and (r[8] >> 8) == 0:  # gemm, role 0 (128x128 tiles: the profiled kernel), whatever the stream
             m, nn, k = int(r[5]), int(r[6]), int(r[7])
             entries = nn * m - nn * (nn - 1) // 2
             total += itemsize * (2 * entries + m * k)
@@ -633,7 +633,7 @@ def north_star_blocks(args, local_rank, torch):
     out = {}
     # (tests only: TGP_BENCH_SMALL=1 runs the same code path at sizes that take a second; the blocks say so)
     small = os.environ.get("TGP_BENCH_SMALL") == "1"
-    for key, name in (("n65536", "n4096" if small else "n65536"), ("c3", "n4096d3" if small else "c3")):
+    for key, name in (("n65536", "n8192" if small else "n65536"), ("c3", "n8192d3" if small else "c3")):
         try:
             spec = workload_spec(name)
             m = timed_passes(args, spec, 0, local_rank, 1, torch, None, steps=2, warmup=1, prof_steps=1)

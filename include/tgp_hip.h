@@ -33,8 +33,10 @@ extern "C" {
 #endif
 
 /* bumped whenever an exported signature or option changes; the Python binding refuses another version
- * (round 2 -> 3: tgp_trace_factor gained nb_wide_rows, ~15 entry points added, "potf2_sync" removed) */
-#define TGP_ABI_VERSION 3
+ * (round 2 -> 3: tgp_trace_factor gained nb_wide_rows, ~15 entry points added, "potf2_sync" removed;
+ *  round 3 -> 4: tgp_chain_stamps, the resident-factor solves of the block-column driver -- tgp_dist_fwd_block,
+ *  _bwd_block, _trmv_partial, _cross_cov, _colsumsq_owned, _gram_owned -- and tgp_dist_abort added) */
+#define TGP_ABI_VERSION 4
 
 /* element types: follows the dtype of the caller's arrays (gp.py:89) */
 #define TGP_F32 0
@@ -347,6 +349,33 @@ int tgp_dist_bwd_step(tgp_dist* h, int64_t k);
  * kernels/base.py:68-82), fused, into out_dev (m,); the host all-reduces it */
 int tgp_dist_cond_mean_partial(tgp_dist* h, const tgp_kop* prog, int nops, int64_t m,
                                const void* Xt_host, void* out_dev);
+/* ---- solves on the RESIDENT distributed factor (a new right-hand side costs O(N^2), not a factorisation) ------
+ * Buffers are caller-owned DEVICE memory (the host reduces / broadcasts slices of them with RCCL): nrhs == 1: vectors
+ * of n_pad entries; nrhs a multiple of 128: (n_pad, nrhs) ROW-major -- block k of all right-hand sides is ONE
+ * contiguous chunk of nb * nrhs entries, and read column-major it is X_k^T, the MFMA kernels' operand.
+ *
+ * forward (solve_triangular(y), solvers/direct.py:66-70; A = L^-1 Ks, :94), fan-in: per block k the host REDUCES
+ * block k of every rank's accumulator to the owner of k (north_star's reduce of the solve RHS over xGMI: nb * nrhs
+ * entries per block), then the owner:  x_k = L_kk^-1 (y_k + acc_k),  acc[rows below] -= L[rows below, k] x_k.
+ * No-op on the other ranks.  acc starts at zero; x is zero outside the owned blocks (one all-reduce replicates it). */
+int tgp_dist_fwd_block(tgp_dist* h, int64_t k, int64_t nrhs, const void* y_dev, void* acc_dev, void* x_dev);
+/* backward (solve_triangular(y, transpose=True), direct.py:68), block k on its owner, on ANY device vector of n_pad
+ * entries: x_k <- L_kk^-T (x_k - L[below, k]^T x[below]); the host then broadcasts x_k */
+int tgp_dist_bwd_block(tgp_dist* h, int64_t k, void* x_dev);
+/* this rank's share of dot_triangular (direct.py:72-73): out = sum over the owned block columns of L[:, k] y_k;
+ * device vectors of n_pad entries; the host all-reduces */
+int tgp_dist_trmv_partial(tgp_dist* h, const void* y_dev, void* out_dev);
+/* Ks = K(X, X*) (direct.py:87-91) as right-hand sides of the forward solve: out_dev (n_pad, m_pad) ROW-major, zero
+ * padded; m_pad a multiple of 128 */
+int tgp_dist_cross_cov(tgp_dist* h, const tgp_kop* prog, int nops, int64_t m, const void* Xt_host, int64_t m_pad,
+                       void* out_dev);
+/* this rank's share of colsum(A o A) (conditional variance without the M x M product, direct.py:94-95) and of A^T A
+ * (direct.py:95; column-major nrhs x nrhs) over the rows of its OWNED blocks; the host all-reduces */
+int tgp_dist_colsumsq_owned(tgp_dist* h, int64_t nrhs, const void* x_dev, void* out_dev);
+int tgp_dist_gram_owned(tgp_dist* h, int64_t nrhs, const void* x_dev, void* out_dev);
+/* after a rank-local failure: joins every stream and forgets the interrupted pass's markers (a retry starts from a
+ * quiet device) */
+int tgp_dist_abort(tgp_dist* h);
 /* inspection: local block column l (rows from its diagonal block down, ld = rows) to the host */
 int tgp_dist_get_column(tgp_dist* h, int64_t l, void* out_host);
 

@@ -15,6 +15,9 @@ from tinygp_amd import _ffi, kernels, noise, synthetic  # noqa: E402
 from tinygp_amd.solvers import DirectSolver  # noqa: E402
 
 
+QUICK = "--quick" in sys.argv
+
+
 def spd(n, dt, seed):
     rng = np.random.default_rng(seed)
     B = rng.normal(size=(n, 96))
@@ -24,11 +27,13 @@ def spd(n, dt, seed):
 
 bad = 0
 for dt, tol in ((np.float64, 1e-11), (np.float32, 2e-3)):
-    for n in (128, 256, 384, 1024, 1152, 2176, 2560, 4224, 5248):
+    for n in (128, 384, 1152, 2560, 5248, 8192) if QUICK else (128, 256, 384, 1024, 1152, 2176, 2560, 4224, 5248, 8192):
         A = spd(n, dt, n)
         Lref = sla.cholesky(A.astype(np.float64), lower=True)
-        for opts in (dict(lookahead=1), dict(lookahead=0), dict(lookahead=1, nb_outer=512, first_split=3),
-                     dict(lookahead=1, first_split=0)):
+        for opts in ((dict(lookahead=1), dict(lookahead=1, chain_full_rows=0), dict(lookahead=0, chain_full_rows=0)) if QUICK else
+                     (dict(lookahead=1), dict(lookahead=0), dict(lookahead=1, nb_outer=512, first_split=3),
+                      dict(lookahead=1, first_split=0), dict(lookahead=1, chain_full_rows=0),
+                      dict(lookahead=0, chain_full_rows=0), dict(lookahead=1, chain_full_rows=2048, nb_outer=512))):
             try:
                 L, info = ll.potrf(A.copy(), chain_kernel=1, **opts)
                 err = np.abs(L - Lref).max() / np.abs(Lref).max()

@@ -187,6 +187,82 @@ class NumpyBlockOps:
             out += ref_prog.eval_matrix(prog, Pt, self.P[j0:j0 + cnt]) @ self.xn[j0:j0 + cnt]
         return torch.from_numpy(out)
 
+    # -- solves on the resident factor: same buffer layout as csrc/dist.hip ((npad,) or (npad, nrhs) row-major) ----
+    def rhs_zeros(self, nrhs):
+        tdt = torch.float64 if self.dtype == np.float64 else torch.float32
+        return torch.zeros((self.npad,) if nrhs == 1 else (self.npad, nrhs), dtype=tdt)
+
+    def rhs_from_host(self, Y, nrhs):
+        buf = self.rhs_zeros(nrhs)
+        if nrhs == 1:
+            buf.numpy()[: self.n] = Y.reshape(self.n)
+        else:
+            buf.numpy()[: self.n, : Y.shape[1]] = Y
+        return buf
+
+    def rhs_to_host(self, buf):
+        return buf.numpy().copy()
+
+    def rhs_block(self, buf, k):
+        return buf[k * self.nb:(k + 1) * self.nb]
+
+    def fwd_block(self, k, nrhs, y, acc, x):
+        self.calls.append(("fwd_block", k))
+        if k % self.G != self.rank:
+            return
+        nb = self.nb
+        C = self._col(k // self.G)
+        sl = slice(k * nb, (k + 1) * nb)
+        with np.errstate(all="ignore"):
+            xk = sla.solve_triangular(C[sl], y.numpy()[sl] + acc.numpy()[sl], lower=True, check_finite=False)
+            x.numpy()[sl] = xk
+            acc.numpy()[(k + 1) * nb:] -= C[(k + 1) * nb:] @ xk
+
+    def bwd_block(self, k, x):
+        if k % self.G != self.rank:
+            return
+        nb = self.nb
+        C = self._col(k // self.G)
+        xn = x.numpy()
+        with np.errstate(all="ignore"):
+            xk = xn[k * nb:(k + 1) * nb] - C[(k + 1) * nb:].T @ xn[(k + 1) * nb:]
+            xn[k * nb:(k + 1) * nb] = sla.solve_triangular(C[k * nb:(k + 1) * nb], xk, lower=True, trans=1,
+                                                           check_finite=False)
+
+    def trmv_partial(self, y):
+        out = self.rhs_zeros(1)
+        for l in range(self.nloc):
+            k = l * self.G + self.rank
+            Lk = self._col(l)[k * self.nb:].copy()
+            Lk[: self.nb] = np.tril(Lk[: self.nb])
+            out.numpy()[k * self.nb:] += Lk @ y.numpy()[k * self.nb:(k + 1) * self.nb]
+        return out
+
+    def cross_cov(self, prog, Pt, m_pad):
+        out = self.rhs_zeros(m_pad)
+        out.numpy()[: self.n, : Pt.shape[0]] = ref_prog.eval_matrix(prog, self.P, Pt)
+        return out
+
+    def _owned_rows(self):
+        rows = np.zeros(self.npad, dtype=bool)
+        for l in range(self.nloc):
+            k = l * self.G + self.rank
+            rows[k * self.nb:(k + 1) * self.nb] = True
+        return rows
+
+    def colsumsq_owned(self, nrhs, x):
+        return torch.from_numpy(np.sum(np.square(x.numpy()[self._owned_rows()]), axis=0))
+
+    def gram_owned(self, nrhs, x):
+        a = x.numpy()[self._owned_rows()]
+        return torch.from_numpy(np.ascontiguousarray(a.T @ a))
+
+    def set_x(self, buf):
+        self.xn[:] = buf.numpy()
+
+    def abort(self):
+        self.calls.append(("abort",))
+
     def column(self, l, rows):
         j0 = (l * self.G + self.rank) * self.nb
         return self._col(l)[j0:].copy()

@@ -487,18 +487,21 @@ def test_multi_stream_schedule_is_deterministic(n, reps):
 
 
 @pytest.mark.parametrize("lookahead", [0, 1])
-@pytest.mark.parametrize("fused_step", [0, 1])
+@pytest.mark.parametrize("fused_step", [0, 1, 2])
 def test_potf2_stress_n3000(lookahead, fused_step):
     """The setting that exposed round 2's timing-ordered diagonal block (12 wrong factorisations in 25 000 for a
     sibling build, profiles/r02_u): N = 3 000, 2 000 fused evaluations per look-ahead mode, through the
-    stand-alone potf2 kernel and through the fused panel step's copy of the same body -- every result
+    stand-alone potf2 kernel, through the fused panel step's copy of the same body and through the persistent chain's
+    (hand-offs by flag words inside one launch) -- every result
     bit-identical to the first.  (The order itself is proved on the host: tests/test_potf2_lds.py; the
     10^5-evaluation runs are in profiles/r03_a.)"""
     from tinygp_amd import _ffi
 
-    n, reps = 3000, 2000 if fused_step == 0 else 600
+    # fused_step 2: the persistent chain (the default schedule: every hand-off inside ONE launch is a flag word)
+    n, reps = 3000, 2000 if fused_step != 1 else 600
     ctx = _ffi.default_ctx()
-    old = {"lookahead": ctx.set_option("lookahead", lookahead), "fused_step": ctx.set_option("fused_step", fused_step)}
+    old = {"lookahead": ctx.set_option("lookahead", lookahead), "fused_step": ctx.set_option("fused_step", fused_step & 1),
+           "chain_kernel": ctx.set_option("chain_kernel", 1 if fused_step == 2 else 0)}
     try:
         X, y = _cases.synthetic.make_inputs(n, 1)
         ks = [1.5**2 * kernels.ExpSquared(2.5), 1.4**2 * kernels.ExpSquared(2.2)]

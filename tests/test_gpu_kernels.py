@@ -179,17 +179,23 @@ def test_potrf_block_sizes_agree(nb_outer):
 
 
 @pytest.mark.parametrize("n", [1152, 2560, 5120])
-@pytest.mark.parametrize("opts", [dict(fused_step=1, gate_split=0), dict(fused_step=1, gate_split=1),
-                                  dict(fused_step=1, gate_split=1, lookahead=0),
-                                  dict(fused_step=0, chain_reserve=0), dict(fused_step=1, chain_reserve=256),
-                                  dict(sub_panel=512), dict(sub_panel=256, first_split=4), dict(nb_first=256),
-                                  dict(nb_first=512, sub_panel=512, lookahead=0), dict(split_tail=1),
-                                  dict(split_tail=1, sub_panel=512, nb_first=768)])
+@pytest.mark.parametrize("opts", [dict(chain_kernel=0, fused_step=1, gate_split=0), dict(chain_kernel=0, fused_step=1, gate_split=1),
+                                  dict(chain_kernel=0, fused_step=1, gate_split=1, lookahead=0),
+                                  dict(chain_kernel=0, fused_step=0, chain_reserve=0), dict(chain_kernel=0, fused_step=1, chain_reserve=256),
+                                  dict(chain_kernel=0, sub_panel=512), dict(chain_kernel=0, sub_panel=256, first_split=4),
+                                  dict(chain_kernel=0, nb_first=256), dict(chain_kernel=0, nb_first=512, sub_panel=512, lookahead=0),
+                                  dict(chain_kernel=0, split_tail=1), dict(chain_kernel=0, split_tail=1, sub_panel=512, nb_first=768),
+                                  dict(chain_kernel=0),
+                                  # the persistent chain (the default): panel by panel only, without look-ahead, two
+                                  # chain workgroups per compute unit, narrow panels + early share, a narrow first panel
+                                  dict(chain_full_rows=0), dict(lookahead=0), dict(lookahead=0, chain_full_rows=0),
+                                  dict(chain_lds_pad=0), dict(nb_outer=512, first_split=3, chain_full_rows=2048),
+                                  dict(nb_first=256, chain_full_rows=1024), dict(first_split=0, chain_reserve=0)])
 def test_panel_chain_variants_agree(n, opts):
-    """The optional schedules of the panel chain -- one fused launch per 128-column block
-    (panel_step_kernel: potf2 + the rows' own pending update + trsm behind a device-side flag), the
-    split gate, reserved workgroup slots -- give the default schedule's factor (same arithmetic per
-    entry except the fused step's left-looking update order: 1e-12) and LAPACK's."""
+    """The schedules of the panel chain -- the default persistent chain (chain_kernel: tile tasks behind a ticket
+    counter, the whole rest of the matrix in one launch once few rows are left), one fused launch per 128-column
+    block (panel_step_kernel), the separate launches per block with their options -- give the default schedule's
+    factor (the same arithmetic per entry up to the order of the in-panel updates: 1e-12) and LAPACK's."""
     K = _spd(n, np.float64, seed=3)
     Lref, info0 = ll.potrf(K)
     L, info = ll.potrf(K, **opts)
@@ -206,7 +212,8 @@ def test_split_tail_and_two_level_at_n6144_deterministic():
     K = _spd(6144, np.float64, seed=5)
     Lref, info0 = ll.potrf(K)
     assert info0 == 0
-    for opts in (dict(split_tail=1, chain_reserve=0), dict(split_tail=1, sub_panel=512)):
+    for opts in (dict(split_tail=1, chain_reserve=0), dict(chain_kernel=0, split_tail=1, sub_panel=512), dict(chain_full_rows=0),
+                 dict(chain_kernel=0)):
         L, info = ll.potrf(K, **opts)
         assert info == 0
         np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-12 * np.abs(Lref).max())
@@ -216,16 +223,18 @@ def test_split_tail_and_two_level_at_n6144_deterministic():
 
 def test_panel_step_fp32_and_bad_pivot():
     K = _spd(1536, np.float32, cond_diag=0.5)
-    L, info = ll.potrf(K, fused_step=1)
-    assert info == 0
     Lref = sla.cholesky(K.astype(np.float64), lower=True)
-    np.testing.assert_allclose(L, Lref, rtol=5e-4, atol=5e-4)
-    # first non-positive pivot is reported from inside the fused step like from potf2
+    for opts in (dict(chain_kernel=0, fused_step=1), dict(chain_kernel=1), dict(chain_kernel=1, chain_full_rows=0)):
+        L, info = ll.potrf(K, **opts)
+        assert info == 0
+        np.testing.assert_allclose(L, Lref, rtol=5e-4, atol=5e-4)
+    # first non-positive pivot is reported from inside the fused step / the persistent chain like from potf2
     Kb = _spd(1024, np.float64, seed=2)
     Kb[700, 700] = -1.0
-    _, info = ll.potrf(Kb, fused_step=1)
-    _, info_ref = ll.potrf(Kb)
-    assert info == info_ref == 701
+    _, info = ll.potrf(Kb, chain_kernel=0, fused_step=1)
+    _, info_chain = ll.potrf(Kb, chain_kernel=1)
+    _, info_ref = ll.potrf(Kb, chain_kernel=0)
+    assert info == info_chain == info_ref == 701
 
 
 def test_potrf_fp32():

@@ -18,7 +18,7 @@ from tinygp_amd import _ffi
 NSTREAMS = 5
 EV_G1, EV_G2 = 7, 8  # split gate: column block 1 / column blocks 2.. of the next panel
 KIND = {1: "potf2", 2: "trsm", 3: "gemm", 4: "trsv_step", 5: "record", 6: "wait", 7: "assembly",
-        8: "residual_copy", 9: "reductions", 10: "panel_step", 11: "chain"}
+        8: "residual_copy", 9: "reductions", 10: "panel_step", 11: "chain", 12: "chain_poll"}
 
 
 def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1, wide_rows=0, **more):
@@ -31,7 +31,9 @@ def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1,
     out = np.zeros(cap * 10, dtype=np.int64)
     n = C.c_int64()
     opts = dict(nb_outer=nb, lookahead=lookahead, first_split=first_split, first_small_tiles=first_small,
-                nb_wide_rows=wide_rows, fused_step=0 if fused & 2 else 1, gate_split=0 if fused & 4 else 1, **more)
+                nb_wide_rows=wide_rows, fused_step=0 if fused & 2 else 1, gate_split=0 if fused & 4 else 1)
+    opts["chain_kernel"] = 0  # (the library's default is the persistent chain: its configurations say so)
+    opts.update(more)
     text = ",".join(f"{k}={v}" for k, v in opts.items())
     st = lib.tgp_trace_factor(n_pad, text.encode(), fused & 1, out.ctypes.data_as(C.POINTER(C.c_int64)), cap,
                               C.byref(n))
@@ -99,22 +101,10 @@ def accesses(rec, T):
             R.add(("A", tr + i, tc)); W.add(("A", tr + i, tc))
             if v[1] >= 0:
                 R.add(("A", tr + i, tc - 1))
-    elif kind == 11:  # persistent chain: block columns [cb, ce) of the panel at (t0, t0): `rows` row tiles, nblk columns
-        ld, rows, cb, ce, nblk = v[1], v[2], v[3], v[4], v[5]
-        t0, t0c = tile(v[0], ld)
-        assert t0 == t0c and 0 <= cb < ce <= nblk <= rows
-        for c in range(cb, ce):  # factor / solve
-            R.add(("A", t0 + c, t0 + c)); R.add(("D", t0 + c))
-            if c > 0:  # (the panel's first block is factored by the potf2 launch in front)
-                W.add(("A", t0 + c, t0 + c)); W.add(("D", t0 + c))
-            for i in range(c + 1, rows):
-                R.add(("A", t0 + i, t0 + c)); W.add(("A", t0 + i, t0 + c))
-        if cb > 0:  # diag(cb) folds tile (cb, cb-1), solved by the launch before
-            R.add(("A", t0 + cb, t0 + cb - 1))
-        # right-looking: every later block column of the PANEL is updated by the columns factored here
-        for c in range(cb + 1, nblk):
-            for i in range(c, rows):
-                R.add(("A", t0 + i, t0 + c)); W.add(("A", t0 + i, t0 + c))
+    elif kind == 11:  # persistent chain: the whole launch (find_races steps through it column by column)
+        for c in range(v[3], v[4]):
+            r, w = chain_column_accesses(rec, c)
+            R |= r; W |= w
     elif kind == 4:
         ld = v[2]
         lr, lc = tile(v[0], ld)
@@ -123,6 +113,31 @@ def accesses(rec, T):
         R.add(("Y", lr)); W.add(("Y", lr))
         for i in range(1, v[1] // 128 + 1):
             R.add(("A", lr + i, lc)); R.add(("Y", lr + i)); W.add(("Y", lr + i))
+    return R, W
+
+
+def chain_column_accesses(rec, c):
+    """What the persistent chain launch `rec` (kind 11: block columns [cb, ce) of the panel at (t0, t0), `rows` row
+    tiles, nblk block columns) reads and writes while it makes block column c final: the column's own tiles (potf2 --
+    the panel's very first block is factored by the potf2 launch in front --, the solves of the rows below) and,
+    right-looking, every LATER block column of the panel (the update tasks behind column c)."""
+    _, _, *v = rec
+    ld, rows, cb, ce, nblk = v[1], v[2], v[3], v[4], v[5]
+    off = v[0]
+    assert off >= 0 and off % 128 == 0 and (off % ld) % 128 == 0
+    t0, t0c = (off % ld) // 128, (off // ld) // 128
+    assert t0 == t0c and 0 <= cb <= c < ce <= nblk <= rows
+    R, W = set(), set()
+    R.add(("A", t0 + c, t0 + c)); R.add(("D", t0 + c))
+    if c > 0:
+        W.add(("A", t0 + c, t0 + c)); W.add(("D", t0 + c))
+    for i in range(c + 1, rows):
+        R.add(("A", t0 + i, t0 + c)); W.add(("A", t0 + i, t0 + c))
+    if c == cb and cb > 0:  # diag(cb) folds tile (cb, cb-1), solved by the launch before
+        R.add(("A", t0 + cb, t0 + cb - 1))
+    for cc in range(c + 1, nblk):
+        for i in range(cc, rows):
+            R.add(("A", t0 + i, t0 + cc)); W.add(("A", t0 + i, t0 + cc))
     return R, W
 
 
@@ -137,23 +152,10 @@ def find_races(recs, T, limit=5):
         s, c, _ = prev
         return now_clock[s] >= c
 
-    for idx, rec in enumerate(recs):
-        kind, s = rec[0], rec[1]
-        assert 0 <= s < NSTREAMS, rec
-        if kind == 5:
-            snap[rec[2]] = list(clock[s])
-            continue
-        if kind == 6:
-            if rec[2] in snap:
-                clock[s] = [max(a, b) for a, b in zip(clock[s], snap[rec[2]])]
-            continue
-        clock[s][s] += 1
-        now = list(clock[s])
-        me = (s, now[s], idx)
-        R, W = accesses(rec, T)
+    def check_and_register(R, W, now, me, idx):
         for r in R | W:
             lw = last_w.get(r)
-            if lw is not None and not ordered(lw, now):
+            if lw is not None and lw[2] != idx and not ordered(lw, now):
                 races.append((r, lw[2], idx, "after write"))
         for r in W:
             for rd in readers.get(r, ()):
@@ -164,6 +166,40 @@ def find_races(recs, T, limit=5):
             readers[r] = []
         for r in R - W:
             readers.setdefault(r, []).append(me)
+
+    for idx, rec in enumerate(recs):
+        kind, s = rec[0], rec[1]
+        assert 0 <= s < NSTREAMS, rec
+        if kind == 5:
+            snap[rec[2]] = list(clock[s])
+            continue
+        if kind == 6:
+            if rec[2] in snap:
+                clock[s] = [max(a, b) for a, b in zip(clock[s], snap[rec[2]])]
+            continue
+        if kind == 12:  # one-wave poll: this stream continues once block column c of the chain launch at `off` is final
+            key = ("chain", rec[2], rec[4])
+            assert key in snap, ("poll without a chain launch in front of it (host order)", rec)
+            clock[s] = [max(a, b) for a, b in zip(clock[s], snap[key])]
+            continue
+        if kind == 11:
+            # the launch makes its block columns final one after the other; a poller waits for ONE of them: step
+            # through the columns, each with its own tick and its own snapshot for the pollers
+            for c in range(rec[5], rec[6]):
+                clock[s][s] += 1
+                now = list(clock[s])
+                me = (s, now[s], idx)
+                R, W = chain_column_accesses(rec, c)
+                check_and_register(R, W, now, me, idx)
+                snap[("chain", rec[2], c)] = list(clock[s])
+            if len(races) >= limit:
+                break
+            continue
+        clock[s][s] += 1
+        now = list(clock[s])
+        me = (s, now[s], idx)
+        R, W = accesses(rec, T)
+        check_and_register(R, W, now, me, idx)
         if len(races) >= limit:
             break
     return [(r, f"#{i} {KIND[recs[i][0]]} s{recs[i][1]}", f"#{j} {KIND[recs[j][0]]} s{recs[j][1]}", why)
@@ -222,6 +258,12 @@ CONFIGS = [
     (8192, 1024, 1, 5, 1100, 3, 3000, dict(chain_kernel=1)),
     (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1)),
     (5248, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, nb_first=512)),
+    # ... panel by panel only (chain_full_rows = 0), and the whole rest in one launch from 2048 / 8192 rows
+    (5120, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_full_rows=0)),
+    (5120, 1024, 0, 5, 1100, 3, 0, dict(chain_kernel=1, chain_full_rows=0)),
+    (5120, 512, 1, 3, 1100, 3, 0, dict(chain_kernel=1, chain_full_rows=2048)),
+    (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_full_rows=8192)),
+    (16384, 1024, 1, 5, 1100, 2, 0, dict(chain_kernel=1, chain_full_rows=0)),
 ]
 
 
@@ -284,6 +326,27 @@ def test_checker_sees_a_missing_dependency():
     assert find_races(no_chain_wait, T)
 
 
+def test_checker_sees_a_missing_poll_of_the_persistent_chain():
+    """Persistent chain: the forward-substitution step of block j and the early share of the next block-column
+    update start behind a one-wave poll of block column j's count of final tiles while the launch still runs.
+    Without the polls (or without the event that keeps a poller behind the zeroing of the counters, or the one that
+    keeps the next launch's zeroing behind the last poller) the checker must report the race / refuse the order."""
+    recs = trace(5120, 1024, 1, 5, 1100, 3, 0, chain_kernel=1, chain_full_rows=0)
+    T = 5120 // 128
+    assert find_races(recs, T) == []
+    polls = [r for r in recs if r[0] == 12]
+    assert len(polls) >= T - 1  # one per forward-substitution step (+ the early shares on panels without a solve)
+    assert find_races([r for r in recs if r[0] != 12], T)
+    # every poll sits behind a wait for ev_d (recorded between the launch's memset and the kernel) on ITS stream,
+    # and every chain launch but the first behind a wait for ev_f (the previous launch's last poller)
+    chain_idx = [i for i, r in enumerate(recs) if r[0] == 11]
+    for q, i in enumerate(chain_idx):
+        before = recs[:i]
+        assert any(r[0] == 5 and r[1] == recs[i][1] and r[2] == 3 for r in before[-3:]), "ev_d in front of the launch"
+        if q > 0:
+            assert any(r[0] == 6 and r[1] == recs[i][1] and r[2] == 6 for r in before[chain_idx[q - 1]:]), "wait for ev_f"
+
+
 def test_bench_accounting_comes_from_the_launch_records():
     """bench.py's algorithmic bytes / flops per launch (roofline.algorithmic_bytes_per_launch) are summed over the
     library's own launch records for the profiled kernel (128 x 128-tile GEMM, role 0, main stream): without
@@ -296,7 +359,7 @@ def test_bench_accounting_comes_from_the_launch_records():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     n_pad, nb = 8192, 1024
-    total, launches, flops = bench.traced_update_bytes(dict(nb_outer=nb, lookahead=0), n_pad, 8)
+    total, launches, flops = bench.traced_update_bytes(dict(nb_outer=nb, lookahead=0, chain_kernel=0), n_pad, 8)
     want_b, want_f = 0, 0.0
     for k0 in range(0, n_pad - nb, nb):
         m = n_pad - k0 - nb
@@ -304,6 +367,11 @@ def test_bench_accounting_comes_from_the_launch_records():
         want_b += 8 * (2 * entries + m * nb)
         want_f += 2.0 * entries * nb
     assert (total, launches, flops) == (want_b, n_pad // nb - 1, want_f)
-    _, launches, flops = bench.traced_update_bytes({}, 16384, 8)  # library defaults
+    _, launches, flops = bench.traced_update_bytes(dict(chain_kernel=0), 16384, 8)  # the per-block chain's schedule
     assert launches == 14
     assert 1.0e12 < flops < 16384**3 / 3  # the rest of the N^3 / 3 runs on the 64 x 64-tile kernel (gates, in-panel)
+    # library defaults (persistent chain, depth-2 schedule, the last 4 096 rows ONE chain launch): the ten `rest`
+    # updates of panels 0..9; gates and pre-updates have at most 1 100 tiles and run on the 64 x 64-tile kernel
+    _, launches, flops = bench.traced_update_bytes({}, 16384, 8)
+    assert launches == 10
+    assert 0.8e12 < flops < 16384**3 / 3  # (less than the per-block schedule: the last 4 096 rows are chain tasks)

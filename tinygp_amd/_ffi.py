@@ -118,10 +118,17 @@ SIGNATURES = {
     "tgp_dist_bwd_step": [_vp, _i64],
     "tgp_dist_cond_mean_partial": [_vp, _pkop, _int, _i64, _vp, _vp],
     "tgp_dist_get_column": [_vp, _i64, _vp],
+    "tgp_dist_fwd_block": [_vp, _i64, _i64, _vp, _vp, _vp],
+    "tgp_dist_bwd_block": [_vp, _i64, _vp],
+    "tgp_dist_trmv_partial": [_vp, _vp, _vp],
+    "tgp_dist_cross_cov": [_vp, _pkop, _int, _i64, _vp, _i64, _vp],
+    "tgp_dist_colsumsq_owned": [_vp, _i64, _vp, _vp],
+    "tgp_dist_gram_owned": [_vp, _i64, _vp, _vp],
+    "tgp_dist_abort": [_vp],
 }
 
 
-ABI_VERSION = 3  # TGP_ABI_VERSION of include/tgp_hip.h
+ABI_VERSION = 4  # TGP_ABI_VERSION of include/tgp_hip.h
 
 
 def load_library(path: Path | None = None) -> C.CDLL:
@@ -200,7 +207,7 @@ class Ctx:
         return old.value
 
     # the options that shape the factorisation's schedule (tgp_trace_factor takes the same names)
-    SCHEDULE_OPTIONS = ("nb_outer", "lookahead", "first_split", "first_small_tiles", "nb_wide_rows", "fused_step", "chain_kernel",
+    SCHEDULE_OPTIONS = ("nb_outer", "lookahead", "first_split", "first_small_tiles", "nb_wide_rows", "fused_step", "chain_kernel", "chain_full_rows", "chain_lds_pad", "chain_depth2",
                         "gate_split", "chain_reserve", "reserve_max_tiles", "sub_panel", "sub_panel_min_rows",
                         "nb_first", "split_tail", "solve_on_update")
 

@@ -102,6 +102,8 @@ static int assemble_lower(tgp_ctx* ctx, const tgp::KProg& kp, int64_t n, int d, 
   if (ctx->lookahead != 0 && ctx->asm_stream != nullptr) {
     int64_t nb = ctx->nb_outer / 128;
     if (nb < 1) nb = 1;
+    // (the first panel can be wider than nb_outer: nb_first, or the whole matrix as ONE persistent chain launch)
+    nb = std::max<int64_t>(nb, first_panel_cols(ctx, npad) / 128);
     if (nb < tc) t1 = nb;
   }
   const int flags = KMAT_LOWER | KMAT_PAD_IDENTITY;
@@ -174,10 +176,10 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipMalloc(&ctx->d_info, sizeof(int32_t)));
   TGP_HIP_TRY(hipMalloc(&ctx->d_step_flag, 64));
   TGP_HIP_TRY(hipMemset(ctx->d_step_flag, 0, 64));
-  TGP_HIP_TRY(hipMalloc(&ctx->d_chain_flags, size_t(tgp::CHAIN_MAX_ROW_TILES) * 16 * sizeof(uint32_t)));
-  TGP_HIP_TRY(hipMemset(ctx->d_chain_flags, 0, size_t(tgp::CHAIN_MAX_ROW_TILES) * 16 * sizeof(uint32_t)));
-  TGP_HIP_TRY(hipMalloc(&ctx->d_chain_ticket, 64));
-  TGP_HIP_TRY(hipMemset(ctx->d_chain_ticket, 0, 64));
+  TGP_HIP_TRY(hipMalloc(&ctx->d_chain_flags, size_t(tgp::CHAIN_MAX_ROW_TILES) * 64 * sizeof(uint32_t)));
+  TGP_HIP_TRY(hipMemset(ctx->d_chain_flags, 0, size_t(tgp::CHAIN_MAX_ROW_TILES) * 64 * sizeof(uint32_t)));
+  TGP_HIP_TRY(hipMalloc(&ctx->d_chain_ticket, 512));
+  TGP_HIP_TRY(hipMemset(ctx->d_chain_ticket, 0, 512));
   hipDeviceProp_t prop;
   TGP_HIP_TRY(hipGetDeviceProperties(&prop, device));
   ctx->cus = prop.multiProcessorCount;
@@ -248,6 +250,9 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "fused_step")) return &ctx->fused_step;
   if (!strcmp(key, "chain_kernel")) return &ctx->chain_kernel;
   if (!strcmp(key, "chain_stamps")) return &ctx->chain_stamps;
+  if (!strcmp(key, "chain_full_rows")) return &ctx->chain_full_rows;
+  if (!strcmp(key, "chain_lds_pad")) return &ctx->chain_lds_pad;
+  if (!strcmp(key, "chain_depth2")) return &ctx->chain_depth2;
   if (!strcmp(key, "chain_reserve")) return &ctx->chain_reserve;
   if (!strcmp(key, "gate_split")) return &ctx->gate_split;
   if (!strcmp(key, "reserve_max_tiles")) return &ctx->reserve_max_tiles;

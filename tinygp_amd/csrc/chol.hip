@@ -372,8 +372,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 //                  chain waited for exactly those -- profiles/r04_b.)  The update (c, c, c-1) is diag(c)'s fold.
 //   order          per column k: diag(k+1), solve(.., k), update(.., c, k) for c = k+1 .. (column k+1 first)
 //
-// State of tile (i, c) = ONE word, epoch * 32 + s: s = k + 1 once the updates from block columns <= k are applied
-// (those from columns < cb were applied by the launches before), s = 31 once the tile is final.  The epoch is the
+// State of tile (i, c) = ONE word, epoch * 128 + s: s = k + 1 once the updates from block columns <= k are applied
+// (those from columns < cb were applied by the launches before), s = 127 once the tile is final.  The epoch is the
 // launch's (nothing to reset).  Hand-offs follow MI355X_MICROARCH.md / cdna_hip_programming.md Guideline 16, form
 // R1: everything another workgroup reads is stored WRITE-THROUGH (agent-scope relaxed atomic stores = `sc1`), every
 // storing wave drains (`s_waitcnt vmcnt(0)`), barrier, ONE lane stores the word; a consumer polls with ONE wave
@@ -395,8 +395,9 @@ __device__ __forceinline__ void chain_stamp(long long* st, int k) {
   if (st != nullptr && threadIdx.x == 0) st[4 + k] = (long long)__builtin_amdgcn_s_memrealtime();
 }
 
-constexpr int CHAIN_FLAG_LD = 16;  // state word of tile (i, c) of the panel: flags[i * 16 + c] (panels are <= 2048 wide)
-constexpr uint32_t CHAIN_FINAL = 31;
+constexpr int CHAIN_FLAG_LD = 64;  // state word of tile (i, c) of the panel: flags[i * 64 + c] (chains of <= 64 block columns)
+constexpr uint32_t CHAIN_FINAL = 127;
+constexpr int CHAIN_COLCNT_OFF = 16;  // d_chain_ticket: [0] the ticket counter, [16 + c] final tiles of block column c
 
 template <typename T>
 struct ChainArgs {
@@ -406,7 +407,7 @@ struct ChainArgs {
   int32_t* info;
   uint32_t* flags;
   int32_t* ticket;
-  uint32_t epoch32;    // epoch * 32
+  uint32_t epoch32;    // epoch * 128 (the state words' high bits)
   int32_t pivot_base;  // global index of the panel's first pivot
   int32_t R;           // row tiles of the panel (rows of A0 down to the end of the matrix)
   int32_t nblk;        // block columns of the panel
@@ -444,11 +445,33 @@ __device__ __forceinline__ void chain_wait(const uint32_t* f0, uint32_t v0, cons
   __syncthreads();
 }
 
-// every storing wave has drained -> barrier -> one lane publishes the tile's new state
-__device__ __forceinline__ void chain_publish(uint32_t* word, uint32_t value) {
+// every storing wave has drained -> barrier -> one lane publishes the tile's new state; `colcnt` != NULL (the tile
+// is FINAL): its block column's count of final tiles goes up -- what the stream-side pollers watch (chain_poll_kernel)
+__device__ __forceinline__ void chain_publish(uint32_t* word, uint32_t value, int32_t* colcnt = nullptr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (colcnt != nullptr) __hip_atomic_fetch_add(colcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Stream-side end of a hand-off: ONE wave that returns once block column c of the running chain launch is final
+// (count >= target), so that the kernels behind it on ITS stream -- the forward-substitution step of that block,
+// the early share of the next block-column update -- start while the chain launch is still running.  Bounded like
+// every poll; a timeout poisons `info`.
+__global__ __launch_bounds__(64) void chain_poll_kernel(const int32_t* __restrict__ count, int32_t target,
+                                                        int32_t* __restrict__ info) {
+  if (threadIdx.x != 0) return;
+  for (int spin = 0;; ++spin) {
+    if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+    __builtin_amdgcn_s_sleep(16);
+    if ((spin & 255) == 255 &&
+        (spin >= (1 << 19) || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == STEP_TIMEOUT)) {
+      atomicExch(info, STEP_TIMEOUT);
+      break;
+    }
+  }
 }
 
 // update(i, c, k), i > c:  A_ic -= X_ik X_ck^T.  128 x 128 x 128 on the MFMAs, operands double-buffered through S
@@ -601,6 +624,23 @@ __device__ __forceinline__ void chain_update_diag(const ChainArgs<T>& q, T* S, i
 // slots staged in S).  The caller has waited for the tile's updates and for L_cc.  The solved tile is stored
 // write-through; V returns -Y (the operand layout of potf2's fold).
 template <typename T>
+__device__ __forceinline__ void chain_load_tile(const ChainArgs<T>& q, int i, int c, typename Mfma<T>::acc_t (&V)[8]) {
+  using M = Mfma<T>;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ld = q.ld;
+  const T* bu = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + w * 16;  // wave-uniform; lane offset below
+  const uint32_t boff = uint32_t(M::drow(lane, 0) * int(ld) + (lane & 15));
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) V[jb][r] = (bu + int64_t(jb * 16 + M::drow(0, r)) * ld)[boff];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in registers before a later acquire drops the L1
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// (the tile's 16 rows per wave are in V already: chain_load_tile, issued BEFORE the wait for L_cc)
+template <typename T>
 __device__ __forceinline__ void chain_solve(const ChainArgs<T>& q, T* S, int i, int c,
                                             typename Mfma<T>::acc_t (&V)[8], long long* st, int s0) {
   using M = Mfma<T>;
@@ -612,13 +652,8 @@ __device__ __forceinline__ void chain_solve(const ChainArgs<T>& q, T* S, int i, 
   T* Bt = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE;
   const T* Ljj = q.A0 + int64_t(c) * TILE * ld + int64_t(c) * TILE;
   const T* dinv = q.dinv + int64_t(c) * 2048;
-  // this wave's 16 rows of the tile, D layout
   T* bu = Bt + w * 16;  // wave-uniform; lane offset below
   const uint32_t boff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
-#pragma unroll
-  for (int jb = 0; jb < 8; ++jb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) V[jb][r] = (bu + int64_t(jb * 16 + M::drow(0, r)) * ld)[boff];
   // L_cc -> LDS in potf2's block image: the 28 blocks below the diagonal as they are, the diagonal
   // slots take the 16 x 16 inverses (all a solve needs of a diagonal block).  In two rounds of blocks (3 + 2 per
   // wave): the tile's 64 registers are live beside the staging registers, and five blocks at once spill.
@@ -711,21 +746,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       --t;
     }
     for (int k = q.cb; k < q.ce && kind < 0; ++k) {
-      const bool next_diag = k + 1 < q.ce;
-      if (next_diag) {
+      // tasks of step k in closed form (chains of up to 64 block columns: no loop over the columns per step)
+      const int nd = k + 1 < q.ce ? 1 : 0;
+      const int r0 = nd ? k + 2 : k + 1;
+      const int ns = q.R - r0 > 0 ? q.R - r0 : 0;
+      const int a = k + 1, b = q.nblk - 1;  // updated columns a .. b: R - c tiles each, minus diag(k+1)'s fold
+      const int nu = a <= b ? (b - a + 1) * q.R - (a + b) * (b - a + 1) / 2 - 1 : 0;
+      if (t >= nd + ns + nu) {
+        t -= nd + ns + nu;
+        continue;
+      }
+      if (nd) {
         if (t == 0) { kind = 1; tc = k + 1; break; }
         --t;
       }
-      const int r0 = next_diag ? k + 2 : k + 1;
-      const int ns = q.R - r0 > 0 ? q.R - r0 : 0;
-      if (t >= 0 && t < ns) { kind = 0; ti = r0 + t; tc = k; break; }
+      if (t < ns) { kind = 0; ti = r0 + t; tc = k; break; }
       t -= ns;
-      for (int c = k + 1; c < q.nblk; ++c) {
-        const int i0 = c == k + 1 ? c + 1 : c;
-        const int nu = q.R - i0 > 0 ? q.R - i0 : 0;
-        if (t >= 0 && t < nu) { ti = i0 + t; tc = c; tk = k; kind = ti == c ? 3 : 2; break; }
-        t -= nu;
+      for (int c = a; c <= b; ++c) {
+        const int i0 = c == a ? c + 1 : c;
+        const int cnt = q.R - i0;
+        if (t < cnt) { ti = i0 + t; tc = c; tk = k; kind = ti == c ? 3 : 2; break; }
+        t -= cnt;
       }
+      break;
     }
     s_task[0] = kind; s_task[1] = ti; s_task[2] = tc; s_task[3] = tk;
   }
@@ -764,12 +807,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int i = ti, c = tc;
     uint32_t* wt = q.flags + i * CHAIN_FLAG_LD + c;
     const uint32_t* wl = q.flags + c * CHAIN_FLAG_LD + c;
-    chain_wait<4>(c > q.cb ? wt : nullptr, E + uint32_t(c), (c == 0 && head_final) ? nullptr : wl, E + CHAIN_FINAL,
-                  nullptr, 0, q.info);
-    chain_stamp(st, 1);
+    // the tile first (its updates are done long before L_cc as a rule): its round trip hides behind potf2
+    if (c > q.cb) chain_wait<4>(wt, E + uint32_t(c), nullptr, 0, nullptr, 0, q.info);
     acc_t V[8];
+    chain_load_tile<T>(q, i, c, V);
+    if (!(c == 0 && head_final)) chain_wait<4>(wl, E + CHAIN_FINAL, nullptr, 0, nullptr, 0, q.info);
+    chain_stamp(st, 1);
     chain_solve<T>(q, S, i, c, V, st, 2);
-    chain_publish(wt, E + CHAIN_FINAL);
+    chain_publish(wt, E + CHAIN_FINAL, q.ticket + CHAIN_COLCNT_OFF + c);
     chain_stamp(st, 4);
     return;
   }
@@ -785,11 +830,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (c > q.cb) {
     // tile (c, c-1): its updates (from columns cb .. c-2 of this launch) and L_{c-1,c-1}
     const uint32_t* wl = q.flags + (c - 1) * CHAIN_FLAG_LD + (c - 1);
-    chain_wait<1>(c - 1 > q.cb ? frow + (c - 1) : nullptr, E + uint32_t(c - 1),
-                  (c - 1 == 0 && head_final) ? nullptr : wl, E + CHAIN_FINAL, nullptr, 0, q.info);
+    if (c - 1 > q.cb) chain_wait<4>(frow + (c - 1), E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
+    chain_load_tile<T>(q, c, c - 1, Vx);  // (its round trip hides behind potf2(c-1))
+    if (!(c - 1 == 0 && head_final)) chain_wait<1>(wl, E + CHAIN_FINAL, nullptr, 0, nullptr, 0, q.info);
     chain_stamp(st, 1);
     chain_solve<T>(q, S, c, c - 1, Vx, st, 2);
-    chain_publish(frow + (c - 1), E + CHAIN_FINAL);  // the updates behind column c-1 and the next solves need it NOW
+    // the updates behind column c-1 and the next solves need it NOW
+    chain_publish(frow + (c - 1), E + CHAIN_FINAL, q.ticket + CHAIN_COLCNT_OFF + (c - 1));
     chain_stamp(st, 4);
     // tile (c, c) with the updates from columns cb .. c-2 (the one from c-1 is the fold below)
     if (c - 1 > q.cb) chain_wait<1>(frow + c, E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
@@ -814,7 +861,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef POTF2_ST
   }
   chain_stamp(st, 6);  // factored, stores issued
-  chain_publish(frow + c, E + CHAIN_FINAL);
+  chain_publish(frow + c, E + CHAIN_FINAL, q.ticket + CHAIN_COLCNT_OFF + c);
   chain_stamp(st, 7);  // L_cc published
 }
 
@@ -1565,30 +1612,38 @@ int launch_panel_step(tgp_ctx* ctx, hipStream_t st, int64_t m, T* Ljj, int64_t l
 // the matrix; dinv0 = the inverses of the panel's first block).  head_done: L_cb,cb is already factored.
 template <typename T>
 int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int64_t pivot_base, int64_t R,
-                 int64_t nblk, int64_t cb, int64_t ce, bool head_done) {
+                 int64_t nblk, int64_t cb, int64_t ce, bool head_done, hipEvent_t counters_ready) {
   TGP_ARG_CHECK(R >= 1 && R <= CHAIN_MAX_ROW_TILES && cb >= 0 && cb < ce && ce <= nblk && nblk <= CHAIN_FLAG_LD && nblk <= R,
                 "chain: bad panel shape (R=%lld, columns [%lld, %lld))", (long long)R, (long long)cb, (long long)ce);
   // a panel's first block has no in-panel update pending: plain potf2 in front of the launch (in the look-ahead
   // schedule it already ran on the main stream, in front of the big update: head_done)
   if (cb == 0 && !head_done) TGP_TRY(launch_potf2<T>(ctx, st, A0, ld, dinv0, ctx->d_info, (int32_t)pivot_base));
+  // the pollers of the previous launch read the counters this launch zeroes: they must be through
+  if (ctx->chain_polls_pending) {
+    TGP_TRY(st_wait(ctx, st, ctx->ev_f));
+    ctx->chain_polls_pending = false;
+  }
   if (ctx->trace) {  // v: panel origin offset, ld, row tiles, first / end block column
+    if (counters_ready != nullptr) TGP_TRY(ev_record(ctx, counters_ready, st));
     trace_push(ctx, 11, st, trace_off(ctx, A0), ld, R, cb, ce, nblk);
     return TGP_OK;
   }
   int64_t tasks = cb > 0 ? 1 : 0;
-  for (int64_t k = cb; k < ce; ++k) {
-    const bool next_diag = k + 1 < ce;
-    tasks += next_diag ? 1 : 0;
-    tasks += std::max<int64_t>(0, R - (next_diag ? k + 2 : k + 1));
-    for (int64_t c = k + 1; c < nblk; ++c) tasks += std::max<int64_t>(0, R - (c == k + 1 ? c + 1 : c));
+  for (int64_t k = cb; k < ce; ++k) {  // the same closed form as the kernel's ticket decode
+    const int64_t nd = k + 1 < ce ? 1 : 0, r0 = nd ? k + 2 : k + 1;
+    const int64_t a = k + 1, b = nblk - 1;
+    tasks += nd + std::max<int64_t>(0, R - r0) + (a <= b ? (b - a + 1) * R - (a + b) * (b - a + 1) / 2 - 1 : 0);
   }
-  if (tasks == 0) return TGP_OK;
-  ctx->step_epoch = (ctx->step_epoch + 1) & 0x3FFFFFFu;  // the state words hold epoch * 32 + s
+  if (tasks == 0) {  // a one-block panel: potf2 in front was all of it; the pollers' event still marks this point
+    if (counters_ready != nullptr) TGP_TRY(ev_record(ctx, counters_ready, st));
+    return TGP_OK;
+  }
+  ctx->step_epoch = (ctx->step_epoch + 1) & 0x1FFFFFFu;  // the state words hold epoch * 128 + s
   if (ctx->step_epoch == 0) ctx->step_epoch = 1;          // 0 is the words' initial value
   const uint32_t epoch = ctx->step_epoch;
   ChainArgs<T> q;
   q.A0 = A0; q.ld = ld; q.dinv = dinv0; q.info = ctx->d_info; q.flags = ctx->d_chain_flags;
-  q.ticket = ctx->d_chain_ticket; q.epoch32 = epoch * 32u; q.pivot_base = (int32_t)pivot_base; q.R = (int32_t)R;
+  q.ticket = ctx->d_chain_ticket; q.epoch32 = epoch * 128u; q.pivot_base = (int32_t)pivot_base; q.R = (int32_t)R;
   q.nblk = (int32_t)nblk;
   q.cb = (int32_t)cb; q.ce = (int32_t)ce;
   q.stamps = nullptr;
@@ -1599,8 +1654,30 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
     q.stamps = ctx->d_chain_stamps + ctx->chain_stamp_base * 16;
     ctx->chain_stamp_base += tasks;
   }
-  TGP_HIP_TRY(hipMemsetAsync(ctx->d_chain_ticket, 0, sizeof(int32_t), st));
-  hipLaunchKernelGGL((chain_kernel<T>), dim3((unsigned)tasks), dim3(512), 0, st, q);  // one task per workgroup
+  // ticket counter + the block columns' counts of final tiles: zero in front of every launch
+  TGP_HIP_TRY(hipMemsetAsync(ctx->d_chain_ticket, 0, size_t(CHAIN_COLCNT_OFF + CHAIN_FLAG_LD) * sizeof(int32_t), st));
+  // pollers on other streams start behind THIS point: counters zeroed, the launch itself not awaited
+  if (counters_ready != nullptr) TGP_TRY(ev_record(ctx, counters_ready, st));
+  // one task per workgroup; `chain_lds_pad` bytes of dynamic LDS nobody uses keep a SECOND chain workgroup off the
+  // compute unit (76 + 10 KB > 160 / 2): the diagonal chain shares its MFMA pipes with no update task (potf2 + fold
+  // 37 us alone, 51-54 beside one: profiles/r04_b), while one trailing-update workgroup (74 KB) still fits beside it
+  // (fp32: the tile image is half the size, the pad makes up for it)
+  const size_t dyn = ctx->chain_lds_pad > 0 ? size_t(ctx->chain_lds_pad) + (sizeof(T) == 4 ? 36 * 256 * 4 : 0) : 0;
+  hipLaunchKernelGGL((chain_kernel<T>), dim3((unsigned)tasks), dim3(512), dyn, st, q);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+// `st` continues once block column c of the chain launch that is running (or queued) on another stream is final:
+// R - c tiles (the panel's first diagonal block, factored in front of a launch with cb == 0, is not counted)
+int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, int64_t R, int64_t c, bool first_external) {
+  if (ctx->trace) {  // v: panel origin offset (elements of the traced dtype), ld, block column
+    trace_push(ctx, 12, st, trace_off(ctx, static_cast<const double*>(A0)), ld, c);
+    return TGP_OK;
+  }
+  const int32_t target = (int32_t)(R - c - ((c == 0 && first_external) ? 1 : 0));
+  hipLaunchKernelGGL(chain_poll_kernel, dim3(1), dim3(64), 0, st, ctx->d_chain_ticket + CHAIN_COLCNT_OFF + c, target,
+                     ctx->d_info);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -1680,31 +1757,39 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
   hipStream_t S3 = ctx->update_stream;
   hipStream_t S2 = ctx->solve_on_update != 0 ? S3 : ctx->solve_stream;  // behind the update of the same block
   if (ctx->chain_kernel != 0 && kb / TILE <= CHAIN_FLAG_LD && (n - k0) / TILE <= CHAIN_MAX_ROW_TILES) {
-    // ONE persistent launch for the blocks to run now (two when the early share of the next gate branches off
-    // behind `after_blocks` blocks): potf2, the solves of the rows below and the in-panel updates are tile tasks
-    // of chain_kernel.  The forward-substitution steps of the blocks follow on the solve stream behind the launch.
+    // ONE persistent launch for the blocks to run now: potf2, the solves of the rows below and the in-panel updates
+    // are tile tasks of chain_kernel.  What the per-block path hangs on events behind block j -- the forward-
+    // substitution step of block j, the early share of the next block-column update behind `after_blocks` blocks --
+    // follows on the solve stream behind a ONE-wave poll of block column j's count of final tiles: the launch is
+    // never cut, and those kernels still start while it runs.
     const int64_t nblk = kb / TILE, R = (n - k0) / TILE;
     const int64_t cb = blk_begin, ce = blk_end < 0 ? nblk : std::min<int64_t>(nblk, blk_end);
     T* A0 = A + k0 * ld + k0;
     T* d0 = dinv + (k0 / TILE) * 2048;
+    if (cb >= ce) return TGP_OK;
     // (as in the per-block path: the early share exists when rows AND columns are left behind block after_blocks-1)
-    const bool want_mid = after_blocks > cb && after_blocks < ce && after_blocks < nblk && R > after_blocks;
-    int64_t seg[3] = {cb, want_mid ? after_blocks : ce, ce};
-    for (int part = 0; part < 2; ++part) {
-      const int64_t s0 = seg[part], s1 = seg[part + 1];
-      if (s0 >= s1) continue;
-      TGP_TRY(launch_chain<T>(ctx, st, A0, ld, d0, pivot_off + k0, R, nblk, s0, s1, head_done && s0 == 0));
-      const bool mid_here = want_mid && part == 0;
-      if (y != nullptr || mid_here) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
-      if (y != nullptr) {
-        TGP_TRY(st_wait(ctx, S2, ctx->ev_d));
-        for (int64_t c = s0; c < s1; ++c) {
-          const int64_t j0 = k0 + c * TILE;
-          TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, n - (j0 + TILE), A + j0 * ld + j0, ld, dinv + (j0 / TILE) * 2048,
-                                          y + j0));
-        }
+    const bool want_mid = after_blocks > cb && after_blocks <= ce && after_blocks < nblk && R > after_blocks;
+    const bool polls = y != nullptr || want_mid;
+    // (ev_d is recorded between the launch's memset and the kernel: the pollers wait for the zeroed counters only)
+    TGP_TRY(launch_chain<T>(ctx, st, A0, ld, d0, pivot_off + k0, R, nblk, cb, ce, head_done && cb == 0,
+                            polls ? ctx->ev_d : (hipEvent_t) nullptr));
+    if (polls) TGP_TRY(st_wait(ctx, S2, ctx->ev_d));
+    for (int64_t c = cb; c < ce && (y != nullptr || want_mid); ++c) {
+      const int64_t j0 = k0 + c * TILE;
+      const bool mid_here = want_mid && c + 1 == after_blocks;
+      if (y == nullptr && !mid_here) continue;
+      TGP_TRY(launch_chain_poll(ctx, S2, A0, ld, R, c, cb == 0));
+      if (y != nullptr)
+        TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, n - (j0 + TILE), A + j0 * ld + j0, ld, dinv + (j0 / TILE) * 2048,
+                                        y + j0));
+      if (mid_here) {
+        TGP_TRY(ev_record(ctx, ctx->ev_e, S2));
+        TGP_TRY(mid(ctx->ev_e));
       }
-      if (mid_here) TGP_TRY(mid(ctx->ev_d));
+    }
+    if (polls) {  // the next launch zeroes the counters only behind the last poller of this one
+      TGP_TRY(ev_record(ctx, ctx->ev_f, S2));
+      ctx->chain_polls_pending = true;
     }
     return TGP_OK;
   }
@@ -1817,6 +1902,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   if (!ctx->trace) TGP_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int32_t), S0));
   ctx->chain_stamp_base = 0;
   ctx->chain_launches = 0;
+  ctx->chain_polls_pending = false;
   const bool prof_on = ctx->profile != 0 && !ctx->trace;
   std::vector<ProfSpan> spans;
   ctx->ev_used = 0;
@@ -1866,13 +1952,66 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     int64_t w = NB;
     if (k0 == 0 && ctx->nb_first >= TILE) w = ctx->nb_first / TILE * TILE;  // the first chain hides behind nothing
     if (ctx->nb_wide_rows > 0 && k0 > 0 && rem >= ctx->nb_wide_rows) w = 2 * NB;
+    // persistent chain: with few enough rows left the WHOLE rest is one launch (no gate, no big update, no panel
+    // boundary any more: the chain's own update tasks are all the work there is)
+    if (ctx->chain_kernel != 0 && rem <= ctx->chain_full_rows && rem / TILE <= 64) w = rem;
     return rem < w ? rem : w;
   };
   const bool la = ctx->lookahead != 0 && S1 != nullptr;
+  if (la && ctx->chain_kernel != 0 && ctx->chain_depth2 != 0) {
+    // Persistent chain, depth-2 schedule: the CHAIN PIPELINE -- gate(p): panel p applied to the columns of panel
+    // p+1, then potf2 + the chain launch of panel p+1 -- lives on the priority stream and depends on the main stream
+    // only through pre(p-1), the small update that brought those columns up to panel p-1; the main stream carries
+    // nothing but trailing updates, pre(p) (panel p -> columns of panel p+2) and rest(p) (panel p -> everything
+    // right of that), back to back.  Until round 3 gate(p) sat on the main stream between rest(p-1) and rest(p)
+    // with potf2 and two event hops around it: ~0.55 ms per panel of a chip that had nothing else to run
+    // (profiles/r04_c).  Same idea as the block-column driver's pipeline (dist.hip).  The early share of the gate is
+    // gone with it: while updates dominate the gate hides beside rest(p-1), and the chain-bound tail is ONE launch.
+    std::vector<int64_t> s0;
+    for (int64_t k0 = 0; k0 < n; k0 += width(k0)) s0.push_back(k0);
+    s0.push_back(n);
+    const int64_t P = (int64_t)s0.size() - 1;
+    hipEvent_t ev_chain[2] = {ctx->ev_b, ctx->ev_g1}, ev_pre[2] = {ctx->ev_g2, ctx->ev_e};
+    auto first_role = [&](int64_t m, int64_t nn) -> int {
+      const int64_t tiles = (m / TILE) * (nn / TILE) - (nn / TILE) * (nn / TILE - 1) / 2;
+      return tiles <= ctx->first_small_tiles ? 4 : 0;
+    };
+    const bool asm_side = ctx->asm_pending;  // columns right of the first panel are still being assembled
+    ctx->asm_pending = false;
+    TGP_TRY(ev_record(ctx, ctx->ev_a, S0));
+    TGP_TRY(st_wait(ctx, S1, ctx->ev_a));
+    TGP_TRY(panel(S1, 0, s0[1] - s0[0], false, 0, no_mid));
+    TGP_TRY(ev_record(ctx, ev_chain[0], S1));
+    for (int64_t p = 0; p + 1 < P; ++p) {
+      const int64_t kb = s0[p + 1] - s0[p], next = s0[p + 1], wn = s0[p + 2] - s0[p + 1], mt = n - next;
+      // -- priority stream: gate(p), then the chain of panel p+1
+      if (p >= 1) TGP_TRY(st_wait(ctx, S1, ev_pre[(p - 1) & 1]));
+      if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S1, ctx->ev_asm));
+      TGP_TRY(trailing(S1, mt, wn, kb, A + s0[p] * ld + next, A + next * ld + next, first_role(mt, wn)));
+      TGP_TRY(potf2_at(S1, next, false));
+      TGP_TRY(panel(S1, next, wn, true, 0, no_mid));
+      TGP_TRY(ev_record(ctx, ev_chain[(p + 1) & 1], S1));
+      // -- main stream: panel p is final -> pre(p), rest(p)
+      TGP_TRY(st_wait(ctx, S0, ev_chain[p & 1]));
+      if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S0, ctx->ev_asm));
+      if (p + 2 < P) {
+        const int64_t next2 = s0[p + 2], wn2 = s0[p + 3] - s0[p + 2], mt2 = n - next2;
+        TGP_TRY(trailing(S0, mt2, wn2, kb, A + s0[p] * ld + next2, A + next2 * ld + next2, first_role(mt2, wn2)));
+        TGP_TRY(ev_record(ctx, ev_pre[p & 1], S0));
+        const int64_t next3 = s0[p + 3], m3 = n - next3;
+        if (m3 > 0) {
+          const int64_t t3 = m3 / TILE;
+          if (t3 * (t3 + 1) / 2 <= ctx->reserve_max_tiles) ctx->reserve_hint = ctx->chain_reserve;
+          TGP_TRY(trailing(S0, m3, m3, kb, A + s0[p] * ld + next3, A + next3 * ld + next3, 0));
+        }
+      }
+    }
+    TGP_TRY(st_wait(ctx, S0, ev_chain[(P - 1) & 1]));
+  } else
   if (!la) {
     TGP_TRY(join_assembly());
-    for (int64_t k0 = 0; k0 < n; k0 += NB) {
-      const int64_t kb = (n - k0 < NB) ? (n - k0) : NB;
+    for (int64_t k0 = 0, kb = 0; k0 < n; k0 += kb) {
+      kb = ctx->chain_kernel != 0 ? width(k0) : ((n - k0 < NB) ? (n - k0) : NB);
       TGP_TRY(panel(S0, k0, kb, false, 0, no_mid));
       const int64_t next = k0 + kb, mt = n - next;
       if (mt > 0) TGP_TRY(trailing(S0, mt, mt, kb, A + k0 * ld + next, A + next * ld + next, 0));

@@ -108,6 +108,44 @@ __global__ __launch_bounds__(256) void gemv_t_sub_kernel(int64_t m, const T* __r
   if (threadIdx.x == 0) y[blockIdx.x] -= red[0];
 }
 
+// x = y + a (a: the NEGATIVE sum of the updates that reached this block: the fan-in forward solve)
+template <typename T>
+__global__ __launch_bounds__(256) void add_into_kernel(int64_t cnt, const T* __restrict__ y, const T* __restrict__ a,
+                                                       T* __restrict__ x) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i < cnt) x[i] = y[i] + a[i];
+}
+
+// partial[c][r] = sum over the rows of chunk c (256 rows) of x[i, r]^2 -- x (rows, R) ROW-major; the second pass adds
+// the chunks in a fixed order (deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void colsumsq_chunk_kernel(int64_t rows, int64_t R, const T* __restrict__ x,
+                                                             double* __restrict__ partial) {
+  const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t i0 = int64_t(blockIdx.y) * 256, i1 = i0 + 256 < rows ? i0 + 256 : rows;
+  if (r >= R) return;
+  double s = 0;
+  for (int64_t i = i0; i < i1; ++i) {
+    const double v = double(x[i * R + r]);
+    s += v * v;
+  }
+  partial[int64_t(blockIdx.y) * R + r] = s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void negate_kernel(int64_t cnt, T* __restrict__ x) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i < cnt) x[i] = -x[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_final_kernel(int64_t chunks, int64_t R, const double* __restrict__ partial,
+                                                           T* __restrict__ out, int accumulate) {
+  const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (r >= R) return;
+  double s = accumulate ? double(out[r]) : 0.0;
+  for (int64_t c = 0; c < chunks; ++c) s += partial[c * R + r];
+  out[r] = T(s);
+}
+
 template <typename T>
 int join_assembly(tgp_dist* h) {
   tgp_ctx* ctx = h->ctx;
@@ -509,23 +547,11 @@ int tgp_dist_end(tgp_dist* h, int32_t* info, double* sumsq, double* logdet_half)
 // Backward substitution L^T x = z, block k (the owner only; others return at once):
 //   x_k <- L_kk^-T (z_k - L[rows below, block k]^T x[rows below])
 // in place in the replicated vector; the host then broadcasts x_k (n b entries) from the owner.
+static int bwd_block_impl(tgp_dist* h, int64_t k, void* x_dev);
 int tgp_dist_bwd_step(tgp_dist* h, int64_t k) {
   DIST_GUARD(h);
   TGP_ARG_CHECK(k >= 0 && k < h->nblk, "panel index out of range");
-  if (owner_of(h, k) != h->rank) return TGP_OK;
-  tgp_ctx* ctx = h->ctx;
-  return ddispatch(h->dtype, [&](auto tag) {
-    using T = decltype(tag);
-    const int64_t l = k / h->G, nb = h->nb, ld = h->npad, below = h->npad - (k + 1) * nb;
-    const T* col = (const T*)h->A + l * nb * ld;
-    T* xk = (T*)h->x + k * nb;
-    if (below > 0) {
-      hipLaunchKernelGGL((gemv_t_sub_kernel<T>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, below,
-                         col + (k + 1) * nb, ld, (const T*)h->x + (k + 1) * nb, xk);
-      TGP_HIP_TRY(hipGetLastError());
-    }
-    return trsv<T>(ctx, nb, col + k * nb, ld, (const T*)h->dinv + (k * nb / TILE) * 2048, 1, xk);
-  });
+  return bwd_block_impl(h, k, h->x);
 }
 
 // This rank's share of the conditional mean  K(X*, X) alpha  (reference gp.py:353-359,
@@ -572,6 +598,184 @@ int tgp_dist_cond_mean_partial(tgp_dist* h, const tgp_kop* prog, int nops, int64
   (void)hipFree(xt);
   if (st == TGP_E_HIP) set_error("HIP error in tgp_dist_cond_mean_partial");
   return st;
+}
+
+// Backward substitution block k on ANY device vector (n_pad entries); tgp_dist_bwd_step is this on the handle's own
+// replicated vector.
+static int bwd_block_impl(tgp_dist* h, int64_t k, void* x_dev) {
+  if (owner_of(h, k) != h->rank) return TGP_OK;
+  tgp_ctx* ctx = h->ctx;
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int64_t l = k / h->G, nb = h->nb, ld = h->npad, below = h->npad - (k + 1) * nb;
+    const T* col = (const T*)h->A + l * nb * ld;
+    T* xk = (T*)x_dev + k * nb;
+    if (below > 0) {
+      hipLaunchKernelGGL((gemv_t_sub_kernel<T>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, below,
+                         col + (k + 1) * nb, ld, (const T*)x_dev + (k + 1) * nb, xk);
+      TGP_HIP_TRY(hipGetLastError());
+    }
+    return trsv<T>(ctx, nb, col + k * nb, ld, (const T*)h->dinv + (k * nb / TILE) * 2048, 1, xk);
+  });
+}
+
+int tgp_dist_bwd_block(tgp_dist* h, int64_t k, void* x_dev) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk && x_dev != nullptr, "bwd_block: bad argument");
+  return bwd_block_impl(h, k, x_dev);
+}
+
+// Forward substitution on the RESIDENT factor, block k, fan-in form (reference solvers/direct.py:66-70 for a new
+// right-hand side -- north_star's "reduce-scatter of the solve RHS"): the owner of block column k holds the whole
+// column, so it alone turns x_k into updates of every row below; what a block row has collected from the columns a
+// rank owns sits in that rank's accumulator, and the caller REDUCES block k of the accumulators to the owner of k
+// (one nb x nrhs message per block) right before this call.  Owner only (the others return at once):
+//   x[block k] = L_kk^-1 (y[block k] + acc[block k]);     acc[rows below] -= L[rows below, k] x[block k]
+// (acc holds the NEGATIVE sums).  nrhs == 1: vectors of n_pad entries; nrhs a multiple of 128: (n_pad, nrhs)
+// ROW-major buffers -- block k of all right-hand sides is one contiguous chunk, and the chunk read column-major is
+// X_k^T (nrhs x nb), exactly the operand the MFMA kernels want: the solve is trsm_right_lt, the update one gemm_nt.
+int tgp_dist_fwd_block(tgp_dist* h, int64_t k, int64_t nrhs, const void* y_dev, void* acc_dev, void* x_dev) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk && y_dev && acc_dev && x_dev, "fwd_block: bad argument");
+  TGP_ARG_CHECK(nrhs == 1 || (nrhs > 0 && nrhs % TILE == 0), "fwd_block: nrhs must be 1 or a multiple of %d", TILE);
+  if (owner_of(h, k) != h->rank) return TGP_OK;
+  tgp_ctx* ctx = h->ctx;
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int64_t l = k / h->G, nb = h->nb, ld = h->npad, below = h->npad - (k + 1) * nb;
+    const T* Lkk = (const T*)h->A + l * nb * ld + k * nb;
+    const T* dk = (const T*)h->dinv + (k * nb / TILE) * 2048;
+    const int64_t cnt = nb * nrhs, off = k * nb * nrhs;
+    T* xk = (T*)x_dev + off;
+    hipLaunchKernelGGL((add_into_kernel<T>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, cnt,
+                       (const T*)y_dev + off, (const T*)acc_dev + off, xk);
+    TGP_HIP_TRY(hipGetLastError());
+    if (nrhs == 1) {
+      TGP_TRY(trsv<T>(ctx, nb, Lkk, ld, dk, 0, xk));
+      if (below > 0) TGP_TRY(gemv_sub<T>(ctx, below, nb, Lkk + nb, ld, xk, (T*)acc_dev + (k + 1) * nb));
+      return TGP_OK;
+    }
+    TGP_TRY(trsm_right_lt<T>(ctx, nrhs, nb, Lkk, ld, dk, xk, nrhs));
+    if (below > 0)
+      TGP_TRY(launch_gemm_nt<T>(ctx, ctx->stream, nrhs, below, nb, xk, nrhs, Lkk + nb, ld,
+                                (T*)acc_dev + (k + 1) * nb * nrhs, nrhs, 0, 0, 1));
+    return TGP_OK;
+  });
+}
+
+// out = sum over the OWNED block columns of L[:, k] y_k  (this rank's share of dot_triangular, reference
+// solvers/direct.py:72-73; the caller all-reduces).  Vectors of n_pad entries on the device.
+int tgp_dist_trmv_partial(tgp_dist* h, const void* y_dev, void* out_dev) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(y_dev && out_dev, "trmv_partial: null buffer");
+  tgp_ctx* ctx = h->ctx;
+  TGP_HIP_TRY(hipMemsetAsync(out_dev, 0, size_t(h->npad) * esz(h->dtype), ctx->stream));
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int64_t nb = h->nb, ld = h->npad;
+    // gemv_sub accumulates out -= P x over the owned panels (the factor's diagonal blocks are stored with zeros above
+    // the diagonal); ONE sign change at the end
+    for (int64_t l = 0; l < h->nloc; ++l) {
+      const int64_t k = l * h->G + h->rank;
+      const T* col = (const T*)h->A + l * nb * ld + k * nb;
+      TGP_TRY(gemv_sub<T>(ctx, h->npad - k * nb, nb, col, ld, (const T*)y_dev + k * nb, (T*)out_dev + k * nb));
+    }
+    hipLaunchKernelGGL((negate_kernel<T>), dim3((unsigned)((h->npad + 255) / 256)), dim3(256), 0, ctx->stream,
+                       h->npad, (T*)out_dev);
+    TGP_HIP_TRY(hipGetLastError());
+    return TGP_OK;
+  });
+}
+
+// K(X, X*) for every data point against m test points, as the right-hand sides of the fan-in forward solve:
+// out_dev (n_pad, m_pad) ROW-major (= K(X*, X) column-major with leading dimension m_pad), zero padded.
+// Reference solvers/direct.py:87-92 (Ks).
+int tgp_dist_cross_cov(tgp_dist* h, const tgp_kop* prog, int nops, int64_t m, const void* Xt_host, int64_t m_pad,
+                       void* out_dev) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(m >= 1 && m_pad >= m && m_pad % TILE == 0 && Xt_host && out_dev, "cross_cov: bad argument");
+  KProg kp;
+  TGP_TRY(make_kprog(prog, nops, &kp));
+  tgp_ctx* ctx = h->ctx;
+  const size_t es = esz(h->dtype);
+  void* xt = nullptr;
+  TGP_HIP_TRY(hipMalloc(&xt, size_t(m) * h->d * es));
+  int st = TGP_OK;
+  if (hipMemcpyAsync(xt, Xt_host, size_t(m) * h->d * es, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = TGP_E_HIP;
+  if (st == TGP_OK)
+    st = ddispatch(h->dtype, [&](auto tag) {
+      using T = decltype(tag);
+      // rows = test points (n1 = m), columns = data points (n2 = n), zero padding out to (m_pad, n_pad)
+      return launch_kmat<T>(ctx, kp, m, h->n, h->d, (const T*)xt, (const T*)h->X, (const T*)nullptr, (T*)out_dev, m_pad,
+                            m_pad, h->npad, 0);
+    });
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(xt);
+  if (st == TGP_E_HIP) set_error("HIP error in tgp_dist_cross_cov");
+  return st;
+}
+
+// out[r] (+)= sum over the rows of the OWNED blocks of x[i, r]^2, x (n_pad, nrhs) ROW-major: this rank's share of
+// colsum(A o A) behind the conditional variance (reference solvers/direct.py:94-95 without the M x M product).
+int tgp_dist_colsumsq_owned(tgp_dist* h, int64_t nrhs, const void* x_dev, void* out_dev) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(nrhs >= 1 && x_dev && out_dev, "colsumsq_owned: bad argument");
+  tgp_ctx* ctx = h->ctx;
+  const int64_t nb = h->nb, chunks = (nb + 255) / 256;
+  TGP_TRY(ensure_work(ctx, size_t(chunks) * size_t(nrhs) * sizeof(double)));
+  TGP_HIP_TRY(hipMemsetAsync(out_dev, 0, size_t(nrhs) * esz(h->dtype), ctx->stream));
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    for (int64_t l = 0; l < h->nloc; ++l) {  // block by block, in a fixed order
+      const int64_t k = l * h->G + h->rank;
+      hipLaunchKernelGGL((colsumsq_chunk_kernel<T>), dim3((unsigned)((nrhs + 255) / 256), (unsigned)chunks), dim3(256), 0,
+                         ctx->stream, nb, nrhs, (const T*)x_dev + k * nb * nrhs, (double*)ctx->d_work);
+      hipLaunchKernelGGL((colsum_final_kernel<T>), dim3((unsigned)((nrhs + 255) / 256)), dim3(256), 0, ctx->stream,
+                         chunks, nrhs, (const double*)ctx->d_work, (T*)out_dev, 1);
+    }
+    TGP_HIP_TRY(hipGetLastError());
+    return TGP_OK;
+  });
+}
+
+// out (nrhs x nrhs, column-major) = sum over the rows of the OWNED blocks of x_i x_i^T: this rank's share of A^T A
+// (reference solvers/direct.py:95); x (n_pad, nrhs) ROW-major, nrhs a multiple of 128.
+int tgp_dist_gram_owned(tgp_dist* h, int64_t nrhs, const void* x_dev, void* out_dev) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(nrhs > 0 && nrhs % TILE == 0 && x_dev && out_dev, "gram_owned: nrhs must be a multiple of %d", TILE);
+  tgp_ctx* ctx = h->ctx;
+  TGP_HIP_TRY(hipMemsetAsync(out_dev, 0, size_t(nrhs) * size_t(nrhs) * esz(h->dtype), ctx->stream));
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int64_t nb = h->nb;
+    for (int64_t l = 0; l < h->nloc; ++l) {  // out -= X_k^T (nrhs x nb) (-X_k^T)^T is not available: accumulate -G, negate
+      const int64_t k = l * h->G + h->rank;
+      const T* xk = (const T*)x_dev + k * nb * nrhs;
+      TGP_TRY(launch_gemm_nt<T>(ctx, ctx->stream, nrhs, nrhs, nb, xk, nrhs, xk, nrhs, (T*)out_dev, nrhs, 0, 0, 1));
+    }
+    hipLaunchKernelGGL((negate_kernel<T>), dim3((unsigned)((nrhs * nrhs + 255) / 256)), dim3(256), 0, ctx->stream,
+                       nrhs * nrhs, (T*)out_dev);
+    TGP_HIP_TRY(hipGetLastError());
+    return TGP_OK;
+  });
+}
+
+// After a rank-local failure: join every stream of the driver and forget the events of the interrupted pass, so that
+// a retry starts from a quiet device (round-3 advisor finding).
+int tgp_dist_abort(tgp_dist* h) {
+  DIST_GUARD(h);
+  tgp_ctx* ctx = h->ctx;
+  for (hipStream_t q : {ctx->asm_stream, ctx->panel_stream, ctx->update_stream, ctx->solve_stream, ctx->stream})
+    if (q) (void)hipStreamSynchronize(q);
+  (void)hipGetLastError();
+  for (bool& b : h->ev_solve_set) b = false;
+  for (bool& b : h->ev_rest_set) b = false;
+  for (bool& b : h->ev_pre_set) b = false;
+  h->solving = false;
+  h->asm_pending = h->asm_deferred = false;
+  h->s1_saw_asm = false;
+  ctx->chain_polls_pending = false;
+  return TGP_OK;
 }
 
 // test / inspection hook: copy local block column l (rows from its diagonal block down,

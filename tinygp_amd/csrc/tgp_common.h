@@ -127,13 +127,18 @@ struct tgp_ctx {
   // persistent panel chain (chol.hip, chain_kernel): ONE launch per panel (two with an early share) factors its
   // block columns, solves the rows below and applies the in-panel updates -- tile tasks behind a ticket counter,
   // hand-offs by per-tile flag words that carry the launch's epoch (0: potf2 | trsm | update launches per block)
-  int64_t chain_kernel = 0;
-  uint32_t* d_chain_flags = nullptr;  // CHAIN_MAX_ROW_TILES x 16 words, zero at allocation, never reset (epochs)
-  int32_t* d_chain_ticket = nullptr;  // zeroed in front of every launch
+  int64_t chain_kernel = 1;
+  uint32_t* d_chain_flags = nullptr;  // CHAIN_MAX_ROW_TILES x 64 words, zero at allocation, never reset (epochs)
+  int32_t* d_chain_ticket = nullptr;  // [0] ticket counter, [16 + c] final tiles of block column c: zeroed per launch
+  int64_t chain_full_rows = 4096;     // with at most this many rows left the WHOLE rest is one chain launch (measured
+                                      // at N = 16 384: 4096 26.6 ms, 6144 26.9, 8192 27.6; per-block chain 28.2)
+  int64_t chain_depth2 = 1;           // gate + chain of the next panel on the priority stream, two panels ahead
+  int64_t chain_lds_pad = 10240;      // dynamic LDS per chain workgroup that nobody uses: one chain workgroup per CU
   int64_t chain_stamps = 0;           // 1: every chain task records its phases' time stamps (tgp_chain_stamps)
   long long* d_chain_stamps = nullptr;  // CHAIN_STAMP_TASKS x 16, allocated on first use
   int64_t chain_stamp_base = 0;       // tasks recorded so far in this factorisation
   int64_t chain_launches = 0;
+  bool chain_polls_pending = false;  // ev_f marks the last poller of the previous chain launch (solve stream)
   // small device scratch: scal[0..15] doubles, info int
   double* d_scal = nullptr;
   int32_t* d_info = nullptr;
@@ -204,6 +209,15 @@ inline int st_wait(tgp_ctx* ctx, hipStream_t st, hipEvent_t ev) {
   return TGP_OK;
 }
 
+// width of the factorisation's FIRST panel (potrf's width(0)); the assembly of the columns to its right may
+// still be running when the first chain starts (capi.hip, assemble_lower)
+inline int64_t first_panel_cols(const tgp_ctx* ctx, int64_t n) {
+  int64_t w = ctx->nb_outer < TILE ? TILE : ctx->nb_outer / TILE * TILE;
+  if (ctx->nb_first >= TILE) w = ctx->nb_first / TILE * TILE;
+  if (ctx->chain_kernel != 0 && n <= ctx->chain_full_rows && n / TILE <= 64) w = n;
+  return n < w ? n : w;
+}
+
 int ensure_dinv(tgp_ctx* ctx, size_t bytes);
 int ensure_work(tgp_ctx* ctx, size_t bytes);
 int ensure_solve_stream(tgp_ctx* ctx);  // the solve stream exists only once something asks for it
@@ -267,7 +281,8 @@ constexpr int64_t CHAIN_STAMP_TASKS = 32768;
 // persistent chain over block columns [cb, ce) of the panel at A0 (R row tiles, nblk block columns; chol.hip)
 template <typename T>
 int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int64_t pivot_base, int64_t R,
-                 int64_t nblk, int64_t cb, int64_t ce, bool head_done);
+                 int64_t nblk, int64_t cb, int64_t ce, bool head_done, hipEvent_t counters_ready = nullptr);
+int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, int64_t R, int64_t c, bool first_external);
 template <typename T>
 int panel_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int64_t pivot_off,
                 int64_t j0, bool pend);

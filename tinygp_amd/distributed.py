@@ -182,6 +182,67 @@ class HipBlockOps:
                    "tgp_dist_cond_mean_partial")
         return out
 
+    # -- solves on the resident factor (buffers: device tensors, (npad,) or (npad, nrhs) row-major) ------------
+    def rhs_zeros(self, nrhs: int):
+        shape = (self.npad,) if nrhs == 1 else (self.npad, nrhs)
+        return self.torch.zeros(shape, dtype=self.x.dtype, device=self.device)
+
+    def rhs_from_host(self, Y: np.ndarray, nrhs: int):
+        """(n,) or (n, R) host array -> zero-padded device buffer of `nrhs` (1 or a multiple of 128) columns."""
+        buf = np.zeros((self.npad,) if nrhs == 1 else (self.npad, nrhs), dtype=self.dtype)
+        if nrhs == 1:
+            buf[: self.n] = Y.reshape(self.n)
+        else:
+            buf[: self.n, : Y.shape[1]] = Y
+        return self.torch.from_numpy(buf).to(self.device)
+
+    def rhs_to_host(self, buf) -> np.ndarray:
+        with self.stream(MAIN):  # behind the collective that produced it, on ITS stream
+            return buf.cpu().numpy()
+
+    def rhs_block(self, buf, k: int):
+        return buf[k * self.nb:(k + 1) * self.nb]
+
+    def fwd_block(self, k: int, nrhs: int, y, acc, x):
+        _ffi.check(self.lib.tgp_dist_fwd_block(self.h, k, nrhs, C.c_void_p(y.data_ptr()), C.c_void_p(acc.data_ptr()),
+                                               C.c_void_p(x.data_ptr())), "tgp_dist_fwd_block")
+
+    def bwd_block(self, k: int, x):
+        _ffi.check(self.lib.tgp_dist_bwd_block(self.h, k, C.c_void_p(x.data_ptr())), "tgp_dist_bwd_block")
+
+    def trmv_partial(self, y):
+        out = self.rhs_zeros(1)
+        _ffi.check(self.lib.tgp_dist_trmv_partial(self.h, C.c_void_p(y.data_ptr()), C.c_void_p(out.data_ptr())),
+                   "tgp_dist_trmv_partial")
+        return out
+
+    def cross_cov(self, prog, Pt: np.ndarray, m_pad: int):
+        kp, nops = _ffi.as_kprog(prog)
+        out = self.torch.empty((self.npad, m_pad), dtype=self.x.dtype, device=self.device)
+        _ffi.check(self.lib.tgp_dist_cross_cov(self.h, kp, nops, Pt.shape[0], _ffi.ptr(Pt), m_pad,
+                                               C.c_void_p(out.data_ptr())), "tgp_dist_cross_cov")
+        return out
+
+    def colsumsq_owned(self, nrhs: int, x):
+        out = self.torch.empty(nrhs, dtype=self.x.dtype, device=self.device)
+        _ffi.check(self.lib.tgp_dist_colsumsq_owned(self.h, nrhs, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr())),
+                   "tgp_dist_colsumsq_owned")
+        return out
+
+    def gram_owned(self, nrhs: int, x):
+        out = self.torch.empty((nrhs, nrhs), dtype=self.x.dtype, device=self.device)
+        _ffi.check(self.lib.tgp_dist_gram_owned(self.h, nrhs, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr())),
+                   "tgp_dist_gram_owned")
+        return out
+
+    def set_x(self, buf):
+        """The handle's own replicated vector <- a solved vector (the backward substitution works in place there)."""
+        self.x.copy_(buf)
+
+    def abort(self):
+        if self.h is not None:
+            self.lib.tgp_dist_abort(self.h)
+
     def column(self, l: int, rows: int) -> np.ndarray:
         out = np.empty((self.nb, rows), dtype=self.dtype)  # column-major (rows x nb)
         _ffi.check(self.lib.tgp_dist_get_column(self.h, l, _ffi.ptr(out)), "tgp_dist_get_column")
@@ -339,7 +400,14 @@ class BlockCyclicCholesky:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         v = float(t.item())
         if v < 0:
+            # every rank: join the streams (broadcasts and kernels of the interrupted pass may still be in flight on
+            # the ring slots and on x) and forget its markers before raising, so that a retry starts from a quiet
+            # device (round-3 advisor finding)
             self.factored = self.solved = self.have_alpha = False
+            self._resid = None
+            abort = getattr(ops, "abort", None)
+            if abort is not None:
+                abort()
             if self._err is not None:
                 raise self._err
             raise _ffi.TgpError("block-column driver: another rank failed during the factorisation")
@@ -358,19 +426,152 @@ class BlockCyclicCholesky:
             return -math.inf
         return ll
 
+    # -- solves on the resident factor (reference solvers/direct.py:66-73, 75-95) -------------------------------
+    def _reduce_to_owner(self, buf, k: int):
+        if self.G == 1 and not self.self_broadcast:
+            return
+        with self.ops.stream(MAIN):
+            self.dist.reduce(buf, dst=self._src(self.owner(k)), op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def _all_reduce(self, buf):
+        if self.G == 1 and not self.self_broadcast:
+            return
+        with self.ops.stream(MAIN):
+            self.dist.all_reduce(buf, group=self.group)
+
+    def _forward(self, y_dev, nrhs: int):
+        """``L^-1 Y`` for device right-hand sides (``nrhs`` = 1 or a multiple of 128), fan-in: block by block the
+        accumulators' slice is REDUCED to the block's owner (north_star's reduce of the solve RHS: nb x nrhs entries
+        per block), the owner solves its block and turns it into updates of the rows below -- its own column is all it
+        needs.  Returns the solved buffer, zero outside the OWNED blocks (``_all_reduce`` replicates it)."""
+        ops = self.ops
+        acc, x = ops.rhs_zeros(nrhs), ops.rhs_zeros(nrhs)
+        for k in range(self.nblk):
+            self._reduce_to_owner(ops.rhs_block(acc, k), k)
+            ops.fwd_block(k, nrhs, y_dev, acc, x)
+        return x
+
+    def _need_factor(self):
+        if not self.factored:
+            self.factor()
+
+    def solve_triangular(self, y, *, transpose: bool = False) -> np.ndarray:
+        """``L x = y`` / ``L^T x = y`` for a NEW right-hand side, y (N,) or (N, R), on the resident factor: O(N^2 R),
+        never a factorisation (reference solvers/direct.py:66-70).  Identical on every rank."""
+        self._need_factor()
+        y = np.asarray(y)
+        if y.ndim not in (1, 2) or y.shape[0] != self.n:
+            raise ValueError(f"y must have shape ({self.n},) or ({self.n}, R); got {y.shape}")
+        Y = np.ascontiguousarray(y, dtype=self.dtype)
+        ops = self.ops
+        if transpose or Y.ndim == 1:
+            cols = [Y] if Y.ndim == 1 else [np.ascontiguousarray(Y[:, r]) for r in range(Y.shape[1])]
+            out = []
+            for col in cols:  # (the backward substitution is a vector kernel: right-hand sides one by one)
+                if transpose:
+                    x = ops.rhs_from_host(col, 1)
+                    for k in reversed(range(self.nblk)):
+                        ops.bwd_block(k, x)
+                        if not (self.G == 1 and not self.self_broadcast):
+                            with ops.stream(MAIN):
+                                self.dist.broadcast(ops.rhs_block(x, k), src=self._src(self.owner(k)), group=self.group)
+                else:
+                    x = self._forward(ops.rhs_from_host(col, 1), 1)
+                    self._all_reduce(x)
+                out.append(ops.rhs_to_host(x)[: self.n])
+            res = out[0] if Y.ndim == 1 else np.stack(out, axis=1)
+        else:
+            R = Y.shape[1]
+            rp = -(-R // 128) * 128
+            x = self._forward(ops.rhs_from_host(Y, rp), rp)
+            self._all_reduce(x)
+            res = ops.rhs_to_host(x)[: self.n, :R]
+        if self.info:
+            res = np.full_like(res, np.nan)
+        return res
+
+    def dot_triangular(self, y) -> np.ndarray:
+        """``L @ y`` (reference solvers/direct.py:72-73): every rank multiplies its own block columns, one all-reduce."""
+        self._need_factor()
+        y = np.asarray(y)
+        Y = np.ascontiguousarray(y.reshape(self.n, -1), dtype=self.dtype)
+        out = np.empty_like(Y)
+        for r in range(Y.shape[1]):
+            part = self.ops.trmv_partial(self.ops.rhs_from_host(np.ascontiguousarray(Y[:, r]), 1))
+            self._all_reduce(part)
+            out[:, r] = self.ops.rhs_to_host(part)[: self.n]
+        if self.info:
+            out[:] = np.nan
+        return out.reshape(y.shape)
+
+    def _test_points(self, X_test):
+        Xt = np.asarray(X_test)
+        Pt = np.ascontiguousarray(Xt[:, None] if Xt.ndim == 1 else Xt, dtype=self.dtype)
+        if Pt.shape[1] != self.d:
+            raise ValueError("X_test must have the same number of input dimensions as X")
+        return Pt
+
+    RHS_CHUNK = 2048  # test points per forward solve of the conditional variance (bounds the (n_pad, chunk) buffers)
+
+    def condition_colsumsq(self, X_test, kernel=None) -> np.ndarray:
+        """``colsum(A o A)`` with ``A = L^-1 K(X, X*)`` (reference solvers/direct.py:87-95 without the M x M product):
+        the cross covariance is assembled on every rank, forward-solved in chunks of test points, each rank sums the
+        squares over the block rows it owns, ONE all-reduce of the (M,) vector.  The posterior variance is
+        ``k(x*, x*) - this`` (+ noise)."""
+        self._need_factor()
+        Pt = self._test_points(X_test)
+        prog = self.prog if kernel is None else kernel.program()
+        m = Pt.shape[0]
+        out = np.empty(m, dtype=self.dtype)
+        for m0 in range(0, m, self.RHS_CHUNK):
+            part = Pt[m0:m0 + self.RHS_CHUNK]
+            mp = -(-part.shape[0] // 128) * 128
+            a = self._forward(self.ops.cross_cov(prog, part, mp), mp)
+            s = self.ops.colsumsq_owned(mp, a)
+            self._all_reduce(s)
+            out[m0:m0 + part.shape[0]] = self.ops.rhs_to_host(s)[: part.shape[0]]
+        if self.info:
+            out[:] = np.nan
+        return out
+
+    def condition_gram(self, X_test, kernel=None) -> np.ndarray:
+        """``A^T A`` (M, M) with ``A = L^-1 K(X, X*)`` (reference solvers/direct.py:94-95): block rows of A stay on their
+        owners, every rank forms its share of the product on the MFMAs, ONE all-reduce of M x M."""
+        self._need_factor()
+        Pt = self._test_points(X_test)
+        prog = self.prog if kernel is None else kernel.program()
+        m = Pt.shape[0]
+        mp = -(-m // 128) * 128
+        a = self._forward(self.ops.cross_cov(prog, Pt, mp), mp)
+        g = self.ops.gram_owned(mp, a)
+        self._all_reduce(g)
+        out = self.ops.rhs_to_host(g)[:m, :m]
+        out = 0.5 * (out + out.T)
+        if self.info:
+            out = np.full_like(out, np.nan)
+        return out
+
     def alpha(self, resid):
-        """``K^-1 resid`` replicated on every rank (reference gp.py:330-334): the forward solve
-        rode along with the factorisation; the backward substitution walks the block columns
-        from the last to the first, the owner solves its ``nb`` slice and broadcasts it."""
+        """``K^-1 resid`` replicated on every rank (reference gp.py:330-334).  Right behind a fused pass over the SAME
+        residual the forward solve is already there; any other right-hand side is forward-solved on the resident
+        factor (fan-in, O(N^2)) -- never a new factorisation.  The backward substitution walks the block columns from
+        the last to the first, the owner solves its ``nb`` slice and broadcasts it."""
         r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
-        # the forward solve rides in the factorisation, so a DIFFERENT right-hand side means another pass
-        # (x holds L^-1 r_old, or K^-1 r_old after the backward substitution -- never reuse those)
-        if not (self.factored and self.solved and self._resid is not None and np.array_equal(self._resid, r)):
-            self.factor(r)
+        self._need_factor()
+        same = self.solved and self._resid is not None and np.array_equal(self._resid, r)
+        ops = self.ops
+        if not same:
+            x = self._forward(ops.rhs_from_host(r, 1), 1)
+            self._all_reduce(x)
+            ops.set_x(x)
+            xs = ops.rhs_to_host(x)
+            self._sumsq = float(np.sum(np.square(xs.astype(np.float64))))
+            self._resid, self.solved, self.have_alpha = r.copy(), True, False
         if not self.have_alpha:
-            ops = self.ops
             for k in reversed(range(self.nblk)):
                 ops.bwd_step(k)  # owner: x_k on the main stream (needs the slices below it: waited for underneath)
+                if self.G == 1 and not self.self_broadcast:
+                    continue
                 with ops.stream(MAIN):  # asynchronous: issued behind bwd_step, the next step waits on the stream
                     w = self.dist.broadcast(ops.x_slice(k), src=self._src(self.owner(k)), group=self.group,
                                             async_op=True)
@@ -378,14 +579,34 @@ class BlockCyclicCholesky:
             self.have_alpha = True
         return self.ops.x
 
+    def resident_log_probability(self, resid) -> float:
+        """``log_probability`` of a new residual on the resident factor: the fan-in forward solve, O(N^2)."""
+        r = np.ascontiguousarray(np.broadcast_to(resid, (self.n,)), dtype=self.dtype)
+        self._need_factor()
+        if not (self.solved and self._resid is not None and np.array_equal(self._resid, r)):
+            x = self._forward(self.ops.rhs_from_host(r, 1), 1)
+            self._all_reduce(x)
+            self.ops.set_x(x)
+            xs = self.ops.rhs_to_host(x)
+            self._sumsq = float(np.sum(np.square(xs.astype(np.float64))))
+            self._resid, self.solved, self.have_alpha = r.copy(), True, False
+        elif self.have_alpha:  # x holds K^-1 r by now: |L^-1 r|^2 was kept
+            pass
+        ll = -0.5 * self._sumsq - (self._logdet + 0.5 * self.n * math.log(2.0 * math.pi))
+        if self.info or not math.isfinite(ll):
+            return -math.inf
+        return ll
+
+    def normalization(self) -> float:
+        """``sum log L_ii + N/2 log 2 pi`` (reference solvers/direct.py:61-64)."""
+        self._need_factor()
+        return math.nan if self.info else self._logdet + 0.5 * self.n * math.log(2.0 * math.pi)
+
     def condition_mean(self, resid, X_test, kernel=None) -> np.ndarray:
         """Posterior mean ``K(X*, X) K^-1 resid`` at the test points (reference gp.py:353-359 with
         ``include_mean=False``; add ``mean(X*)`` on the host), identical on every rank."""
         self.alpha(resid)
-        Xt = np.asarray(X_test)
-        Pt = np.ascontiguousarray(Xt[:, None] if Xt.ndim == 1 else Xt, dtype=self.dtype)
-        if Pt.shape[1] != self.d:
-            raise ValueError("X_test must have the same number of input dimensions as X")
+        Pt = self._test_points(X_test)
         prog = self.prog if kernel is None else kernel.program()
         part = self.ops.cond_mean_partial(prog, Pt)
         with self.ops.stream(MAIN):  # the copy to the host must follow the all-reduce on ITS stream
