@@ -42,10 +42,13 @@ def _worker(rank, world, port, n, nb, dtype_name, m_test, q):
         ll = s.log_probability(y.astype(dt))
         xt = np.linspace(X[0], X[-1], m_test)
         mean = s.condition_mean(y.astype(dt), xt.astype(dt))
+        # solves on the RESIDENT factor with peers: fan-in forward solve (one reduce per block column), the (M,) all-reduce
+        Y = np.random.default_rng(3).normal(size=(n, 3)).astype(dt)
+        res = (s.solve_triangular(Y), s.solve_triangular(y.astype(dt), transpose=True), s.condition_colsumsq(xt.astype(dt)))
         ll2 = s.log_probability(y.astype(dt), kernel=1.1 * _k(kernels))  # the optimiser's next step
         # this rank's block columns of the factor (lower part), for the LAPACK comparison
         cols = [(j, s.ops.column(l, s.rows(j))) for l, j in enumerate(s.owned)]
-        q.put((rank, ll, s.info, mean, ll2, s.bytes_received, cols))
+        q.put((rank, ll, s.info, mean, ll2, s.bytes_received, cols, res))
         s.ops.close()
     finally:
         dist.destroy_process_group()
@@ -88,8 +91,16 @@ def test_block_column_driver_with_peers_on_one_gpu(world, n, nb, dtype_name, rto
     npad = nblk * nb
     es = 8 if dtype_name == "float64" else 4
     seen = set()
-    for rank, ll, info, mean, ll2, nbytes, cols in out:
+    import scipy.linalg as sla
+
+    Y = np.random.default_rng(3).normal(size=(n, 3))
+    Aw = sla.solve_triangular(L, _k(o)(X, xt), lower=True)
+    for rank, ll, info, mean, ll2, nbytes, cols, res in out:
         assert info == 0
+        np.testing.assert_allclose(res[0], sla.solve_triangular(L, Y, lower=True), rtol=rtol * 10, atol=1e-7 if dtype_name == "float64" else 5e-3)
+        np.testing.assert_allclose(res[1], sla.solve_triangular(L, y, lower=True, trans=1), rtol=rtol * 10,
+                                   atol=1e-7 if dtype_name == "float64" else 5e-2)
+        np.testing.assert_allclose(res[2], np.sum(Aw * Aw, axis=0), **tol)
         np.testing.assert_allclose(ll, want, rtol=rtol)
         np.testing.assert_allclose(ll2, want2, rtol=rtol)
         np.testing.assert_allclose(mean, want_mean, **tol)
@@ -111,4 +122,5 @@ def test_block_column_driver_with_peers_on_one_gpu(world, n, nb, dtype_name, rto
     assert len({t[4] for t in out}) == 1
     for t in out[1:]:
         assert np.array_equal(t[3], out[0][3])
+        assert np.array_equal(t[7][0], out[0][7][0]) and np.array_equal(t[7][2], out[0][7][2])  # replicated solves too
     del L

@@ -1984,14 +1984,9 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     TGP_TRY(ev_record(ctx, ev_chain[0], S1));
     for (int64_t p = 0; p + 1 < P; ++p) {
       const int64_t kb = s0[p + 1] - s0[p], next = s0[p + 1], wn = s0[p + 2] - s0[p + 1], mt = n - next;
-      // -- priority stream: gate(p), then the chain of panel p+1
-      if (p >= 1) TGP_TRY(st_wait(ctx, S1, ev_pre[(p - 1) & 1]));
-      if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S1, ctx->ev_asm));
-      TGP_TRY(trailing(S1, mt, wn, kb, A + s0[p] * ld + next, A + next * ld + next, first_role(mt, wn)));
-      TGP_TRY(potf2_at(S1, next, false));
-      TGP_TRY(panel(S1, next, wn, true, 0, no_mid));
-      TGP_TRY(ev_record(ctx, ev_chain[(p + 1) & 1], S1));
-      // -- main stream: panel p is final -> pre(p), rest(p)
+      // -- main stream FIRST in host order (its work of this step waits for nothing the host enqueues below, and the
+      // ~40 calls of a chain launch with its pollers would otherwise sit in front of it): panel p is final ->
+      // pre(p), rest(p)
       TGP_TRY(st_wait(ctx, S0, ev_chain[p & 1]));
       if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S0, ctx->ev_asm));
       if (p + 2 < P) {
@@ -2005,6 +2000,13 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
           TGP_TRY(trailing(S0, m3, m3, kb, A + s0[p] * ld + next3, A + next3 * ld + next3, 0));
         }
       }
+      // -- priority stream: gate(p), then the chain of panel p+1
+      if (p >= 1) TGP_TRY(st_wait(ctx, S1, ev_pre[(p - 1) & 1]));
+      if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S1, ctx->ev_asm));
+      TGP_TRY(trailing(S1, mt, wn, kb, A + s0[p] * ld + next, A + next * ld + next, first_role(mt, wn)));
+      TGP_TRY(potf2_at(S1, next, false));
+      TGP_TRY(panel(S1, next, wn, true, 0, no_mid));
+      TGP_TRY(ev_record(ctx, ev_chain[(p + 1) & 1], S1));
     }
     TGP_TRY(st_wait(ctx, S0, ev_chain[(P - 1) & 1]));
   } else

@@ -602,6 +602,20 @@ class BlockCyclicCholesky:
         self._need_factor()
         return math.nan if self.info else self._logdet + 0.5 * self.n * math.log(2.0 * math.pi)
 
+    def cond_mean_from_alpha(self, alpha, Pt, kernel=None) -> np.ndarray:
+        """``K(X*, X) alpha`` for a replicated host vector ``alpha`` (reference gp.py:357 via kernels/base.py:68-82)."""
+        a = np.ascontiguousarray(np.broadcast_to(alpha, (self.n,)), dtype=self.dtype)
+        self.ops.set_x(self.ops.rhs_from_host(a, 1))
+        self.solved = self.have_alpha = False  # x no longer belongs to the cached residual
+        self._resid = None
+        prog = self.prog if kernel is None else kernel.program()
+        part = self.ops.cond_mean_partial(prog, Pt)
+        self._all_reduce(part)
+        out = self.ops.rhs_to_host(part)
+        if self.info:
+            out = np.full_like(out, np.nan)
+        return out
+
     def condition_mean(self, resid, X_test, kernel=None) -> np.ndarray:
         """Posterior mean ``K(X*, X) K^-1 resid`` at the test points (reference gp.py:353-359 with
         ``include_mean=False``; add ``mean(X*)`` on the host), identical on every rank."""

@@ -339,6 +339,37 @@ class Polynomial(Kernel):
         return (dot + np.square(self.sigma)) ** self.order
 
 
+def host_diag(kernel: "Kernel", X):
+    """``kernel(X)`` -- the diagonal (N,) -- evaluated with the reference's formulas in NumPy, NEVER on the device
+    (O(N) host logic: the variance a distributed solver reports identically on every rank).  Sums / products and
+    host-side input transforms are walked here; the leaves carry the formulas (`_host_diag`)."""
+    if isinstance(kernel, Sum):
+        return host_diag(kernel.kernel1, X) + host_diag(kernel.kernel2, X)
+    if isinstance(kernel, Product):
+        return host_diag(kernel.kernel1, X) * host_diag(kernel.kernel2, X)
+    mapper = getattr(kernel, "_map_points", None)
+    if mapper is not None:  # transforms.*: the inner kernel on the transformed coordinates
+        return host_diag(kernel.kernel, _host_mapped(kernel, X))
+    return kernel._host_diag(X)
+
+
+def host_matrix(kernel: "Kernel", X1, X2):
+    """``kernel(X1, X2)`` (N1, N2) evaluated on the host only (see :func:`host_diag`)."""
+    if isinstance(kernel, Sum):
+        return host_matrix(kernel.kernel1, X1, X2) + host_matrix(kernel.kernel2, X1, X2)
+    if isinstance(kernel, Product):
+        return host_matrix(kernel.kernel1, X1, X2) * host_matrix(kernel.kernel2, X1, X2)
+    if getattr(kernel, "_map_points", None) is not None:
+        return host_matrix(kernel.kernel, _host_mapped(kernel, X1), _host_mapped(kernel, X2))
+    return kernel._host_matrix(X1, X2)
+
+
+def _host_mapped(kernel, X):
+    X = np.asarray(X)
+    out = np.asarray(kernel._map_points(X[:, None] if X.ndim == 1 else X))
+    return out[:, None] if out.ndim == 1 else out
+
+
 class Conditioned(Kernel):
     """The kernel of a process conditioned on data (reference ``base.py:129-153``):
 

@@ -4,7 +4,8 @@
 recurrences) and are outside the hot path this package replaces.
 """
 
-__all__ = ["Solver", "DirectSolver"]
+__all__ = ["Solver", "DirectSolver", "DistributedDirectSolver"]
 
 from tinygp_amd.solvers.direct import DirectSolver
+from tinygp_amd.solvers.distributed import DistributedDirectSolver
 from tinygp_amd.solvers.solver import Solver

@@ -1,0 +1,167 @@
+"""``DistributedDirectSolver``: the dense Cholesky solver over ALL the GPUs of a node, behind the same ``Solver``
+seam as :class:`DirectSolver` (reference ``solvers/solver.py:16-82``, chosen with
+``GaussianProcess(kernel, X, diag=..., solver=DistributedDirectSolver, **solver_kwargs)``, ``gp.py:101-112``).
+
+One process per GPU (``torchrun``); every rank constructs the same ``GaussianProcess`` and calls the same methods in
+the same order -- each call is a collective over the process group -- and every rank gets the same results.  The
+N x N matrix lives 1-D block-cyclic in block columns across the ranks (:mod:`tinygp_amd.distributed`): the
+factorisation broadcasts one panel per step over RCCL / xGMI, ``log_probability`` right behind a factorisation needs
+no further exchange, and every later solve runs on the RESIDENT factor -- fan-in forward substitution (one ``nb x R``
+reduce per block column), backward substitution with one ``nb`` broadcast per block, conditional variance /
+covariance with one all-reduce.  The reference has no multi-device path; its contract is the one this class keeps.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Any
+
+import numpy as np
+
+from tinygp_amd import _device
+from tinygp_amd.kernels.base import host_diag, host_matrix
+from tinygp_amd.noise import Diagonal, Noise
+from tinygp_amd.solvers.solver import Solver
+
+__all__ = ["DistributedDirectSolver"]
+
+
+class _Program:
+    """A lowered kernel program with the one method BlockCyclicCholesky asks of a kernel."""
+
+    def __init__(self, prog):
+        self._prog = prog
+
+    def program(self):
+        return self._prog
+
+
+class DistributedDirectSolver(Solver):
+    """Args:
+        kernel: a tree of stationary kernels (the device evaluates it; host-evaluated kernels are not distributed).
+        X: input coordinates, (N,) or (N, D), the same on every rank.
+        noise: a :class:`tinygp_amd.noise.Diagonal`.
+        covariance: must be ``None`` -- every rank assembles its own block columns from the kernel.
+        nb: block-column width (a multiple of 128; default 1024).
+        group: ``torch.distributed`` process group (default: the world).
+        ops, dist: per-rank operations / collective module (tests substitute CPU stand-ins; default: the HIP library
+            on ``LOCAL_RANK``'s GPU and ``torch.distributed``).
+    """
+
+    def __init__(self, kernel, X, noise: Noise, *, covariance: Any | None = None, nb: int = 1024, group=None,
+                 ops=None, dist=None):
+        from tinygp_amd.distributed import BlockCyclicCholesky
+
+        if covariance is not None:
+            raise NotImplementedError("DistributedDirectSolver assembles its block columns from the kernel on each "
+                                      "rank; a pre-computed covariance cannot be distributed")
+        if not isinstance(noise, Diagonal):
+            raise NotImplementedError("DistributedDirectSolver needs diagonal noise (noise.Diagonal)")
+        self.kernel, self.X, self.noise = kernel, X, noise
+        prog, Xdev = kernel._lower(X)  # DeviceLimit / NotImplementedError: no device program, nothing to distribute
+        noise_diag = np.asarray(noise.diagonal())
+        dt = _device.common_dtype(np.asarray(X), noise_diag)
+        P = _device.points(Xdev, dt)
+        self.dtype, self._P = dt, P
+        self.n, self.d = P.shape
+        if noise_diag.shape != (self.n,):
+            raise ValueError("the noise model must have one entry per data point")
+        self._noise_diag = np.ascontiguousarray(noise_diag, dtype=dt)
+        self._bc = BlockCyclicCholesky(_Program(prog), P, self._noise_diag, nb=nb, ops=ops, group=group, dist=dist)
+
+    # -- factorisation (deferred to the first use, like DirectSolver: a first log_probability is ONE fused pass) --
+    @property
+    def info(self) -> int:
+        self._bc._need_factor()
+        return self._bc.info
+
+    def _program_for(self, kernel):
+        """Program of ``kernel`` provided its input transform maps X onto the resident coordinates."""
+        prog, Xdev = kernel._lower(self.X)
+        if not np.array_equal(_device.points(Xdev, self.dtype), self._P):
+            raise NotImplementedError("conditioning with a kernel whose input transform differs from the GP's kernel "
+                                      "is not distributed")
+        return _Program(prog)
+
+    # -- Solver protocol -----------------------------------------------------------------------------------------
+    def variance(self):
+        """Reference ``direct.py:49,55-56``: ``kernel(X) + noise.diagonal()`` (O(N), the stationary formulas on the
+        host: identical on every rank)."""
+        return np.asarray(host_diag(self.kernel, self.X), dtype=self.dtype) + self._noise_diag
+
+    def covariance(self):
+        """Reference ``direct.py:58-59``.  Debugging aid: the FULL matrix on the host of every rank."""
+        K = np.asarray(host_matrix(self.kernel, self.X, self.X), dtype=self.dtype)
+        K[np.diag_indices(self.n)] += self._noise_diag
+        return K
+
+    def normalization(self):
+        """Reference ``direct.py:61-64``."""
+        return self.dtype.type(self._bc.normalization())
+
+    def solve_triangular(self, y, *, transpose: bool = False):
+        """Reference ``direct.py:66-70``, on the resident distributed factor."""
+        return self._bc.solve_triangular(y, transpose=transpose)
+
+    def dot_triangular(self, y):
+        """Reference ``direct.py:72-73``."""
+        return self._bc.dot_triangular(y)
+
+    def _kss(self, kernel, X_test, diag_only: bool):
+        Xt = self.X if X_test is None else X_test
+        if diag_only:
+            return np.asarray(host_diag(kernel, Xt), dtype=self.dtype)
+        return np.asarray(host_matrix(kernel, Xt, Xt), dtype=self.dtype)
+
+    def condition(self, kernel, X_test, noise):
+        """Reference ``direct.py:75-95``: ``Kss + noise - A^T A``, ``A = L^-1 K(X, X*)``: the forward solve is the
+        distributed fan-in one, each rank forms its share of ``A^T A`` on the MFMAs, one all-reduce of (M, M); the
+        (M, M) prior block is evaluated on the host of every rank."""
+        prog = self._program_for(kernel)
+        Xt = self.X if X_test is None else X_test
+        Pt = _device.points(kernel._lower(Xt)[1], self.dtype)
+        out = self._kss(kernel, X_test, False) - self._bc.condition_gram(Pt, kernel=prog)
+        return out + noise
+
+    def condition_variance(self, kernel, X_test):
+        """``diag(Kss - A^T A)`` without the (M, M) product: one all-reduce of an (M,) vector."""
+        prog = self._program_for(kernel)
+        Xt = self.X if X_test is None else X_test
+        Pt = _device.points(kernel._lower(Xt)[1], self.dtype)
+        return self._kss(kernel, X_test, True) - self._bc.condition_colsumsq(Pt, kernel=prog)
+
+    # -- fused hot paths used by GaussianProcess -------------------------------------------------------------------
+    def log_probability(self, resid):
+        """Reference ``gp.py:313-320``.  The first call is ONE fused distributed pass (assembly, factorisation, forward
+        solve); later calls solve on the resident factor."""
+        if not self._bc.factored:
+            v = self._bc.log_probability(resid)
+        else:
+            v = self._bc.resident_log_probability(resid)
+        return self.dtype.type(v if math.isfinite(v) else -np.inf)
+
+    def alpha(self, resid):
+        """``(K^-1 r, log_probability)`` (reference ``gp.py:330-334``)."""
+        ll = self.log_probability(resid)
+        a = self._bc.ops.rhs_to_host(self._bc.alpha(resid))[: self.n].astype(self.dtype, copy=True)
+        if self._bc.info:
+            a[:] = np.nan
+        return a, ll
+
+    def conditional_mean(self, kernel, X_test, alpha):
+        """``K(X_test, X) @ alpha`` (reference ``gp.py:357``): every rank multiplies its own columns (fused, K* never
+        formed), one all-reduce of (M,).  ``alpha`` is the vector :meth:`alpha` returned."""
+        prog = self._program_for(kernel)
+        Pt = _device.points(kernel._lower(X_test)[1], self.dtype)
+        return self._bc.cond_mean_from_alpha(alpha, Pt, prog)
+
+    def refactor(self, kernel=None) -> int:
+        """New hyper-parameters, same X / noise: re-assemble and re-factor in place on every rank."""
+        if kernel is not None:
+            prog = self._program_for(kernel)
+            self.kernel = kernel
+            return self._bc.factor(None, prog)
+        return self._bc.factor()
+
+    def close(self):
+        self._bc.ops.close()
