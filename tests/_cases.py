@@ -94,3 +94,34 @@ def gp_cases(mod, gp_cls):
     y5 = np.sin(x5[:, 0]) + 0.3 * np.cos(x5[:, 1])
     out["cloud5d_m32"] = (gp_cls(zoo["matern32"], x5, diag=0.01, mean=0.25), y5, x5[:7] + 0.1)
     return out
+
+
+def data_transforms():
+    """3-D cloud for the transform / dense-noise / matmul cases (shapes like test_kernels.py:13-20, its own seed)."""
+    rng = np.random.default_rng(1058397)
+    X = rng.uniform(-3, 3, (40, 3))
+    T = rng.uniform(-3, 3, (9, 3))
+    y = np.sin(X[:, 0]) + 0.2 * X[:, 1] - 0.1 * X[:, 2] ** 2
+    B = rng.normal(size=(40, 40))
+    dense = 0.05 * (B @ B.T) / 40 + 0.05 * np.eye(40)  # an SPD noise matrix (test_noise.py:52-66 uses a dense SPD block)
+    V = rng.normal(size=(9, 4))
+    return X, T, y, dense, V
+
+
+def transform_cases(mod):
+    """name -> kernel with an input transform, built from ANY module tree exposing `kernels` and `transforms`
+    (the reference package under oracle/refshim, or tinygp_amd): reference transforms.py:39-162, the kernels of
+    tests/test_transforms.py:10-49 plus anisotropic / full-matrix variants."""
+    k, t = mod.kernels, mod.transforms
+    chol = np.array([[1.5, 0.0, 0.0], [0.4, 0.9, 0.0], [-0.3, 0.2, 2.1]])
+    mat = np.array([[0.5, 0.1, 0.0], [0.0, 1.3, -0.2]])  # 3-D -> 2-D
+    return {
+        "linear_scalar": t.Linear(1 / 4.5, k.Matern32()),
+        "linear_vector": 1.3 * t.Linear(np.array([0.5, 2.0, 1.3]), k.ExpSquared()),
+        "linear_matrix": t.Linear(mat, k.Matern52(distance=k.L2Distance())),
+        "cholesky_scalar": t.Cholesky(4.5, k.Matern32()),
+        "cholesky_vector": t.Cholesky(np.array([4.5, 0.8, 2.0]), k.ExpSquared()) + 0.2 * k.Exp(1.5),
+        "cholesky_matrix": 0.7 * t.Cholesky(chol, k.ExpSquared()),
+        "subspace_1": t.Subspace(1, k.Matern32(0.8)),
+        "subspace_02": t.Subspace(np.array([0, 2]), k.RationalQuadratic(alpha=1.5)),
+    }

@@ -140,9 +140,19 @@ struct Mfma {
   }
 #if CHK_FLOAT
   static int drow(int lane, int r) { return (lane >> 4) * 4 + r; }
+  static constexpr bool FAST4 = false;
+  static int rot4(int lane, int t) { return (lane + t) & 15; }
+  static int arow4(int lane) { return lane & 15; }
 #else
   static int drow(int lane, int r) { return (lane >> 4) + 4 * r; }
+  static constexpr bool FAST4 = false;
+  static int rot4(int lane, int t) { return 4 * ((((lane >> 2) & 3) + t) & 3) + (lane & 3); }
+  static int arow4(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
 #endif
+  static X mma4(X a, X b, X c) {
+    (void)a; (void)b;
+    return c;
+  }
 };
 static T readlane(T v, int) { return v; }
 static T fast_rcp(T x) { return x; }

@@ -621,15 +621,9 @@ static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void*
   int status = dispatch(s->dtype, [&](auto tag) {
     using T = decltype(tag);
     T* A = (T*)s->A;
-    if (cov_host != nullptr) {
-      TGP_TRY(solver_scratch(s, size_t(s->n) * s->n * es));
-      TGP_HIP_TRY(hipMemcpyAsync(s->scratch, cov_host, size_t(s->n) * s->n * es,
-                                 hipMemcpyHostToDevice, ctx->stream));
-      TGP_TRY(launch_set_lower_from_rowmajor<T>(ctx, s->n, s->npad, (const T*)s->scratch, A, s->npad));
-    } else {
-      TGP_TRY(assemble_lower<T>(ctx, s->kp, s->n, s->d, (const T*)s->X, (const T*)s->diag, A, s->npad));
-    }
-    if (prof) TGP_HIP_TRY(hipEventRecord(e1, ctx->stream));
+    // the residual goes to the work vector FIRST: queued behind the assembly, the 131-KB copy ran beside the side
+    // stream's assembly of the other columns and took 170-240 us -- on the main stream, in front of the marker the
+    // first panel's chain waits for (profiles/r04_c)
     if (fused) {
       if (resid_host) {
         TGP_TRY(upload_vec(s, s->vec, resid_host));
@@ -639,6 +633,15 @@ static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void*
                                    ctx->stream));
       }
     }
+    if (cov_host != nullptr) {
+      TGP_TRY(solver_scratch(s, size_t(s->n) * s->n * es));
+      TGP_HIP_TRY(hipMemcpyAsync(s->scratch, cov_host, size_t(s->n) * s->n * es,
+                                 hipMemcpyHostToDevice, ctx->stream));
+      TGP_TRY(launch_set_lower_from_rowmajor<T>(ctx, s->n, s->npad, (const T*)s->scratch, A, s->npad));
+    } else {
+      TGP_TRY(assemble_lower<T>(ctx, s->kp, s->n, s->d, (const T*)s->X, (const T*)s->diag, A, s->npad));
+    }
+    if (prof) TGP_HIP_TRY(hipEventRecord(e1, ctx->stream));
     int32_t inf = 0;
     int st = potrf<T>(ctx, s->npad, A, s->npad, (T*)s->dinv, &inf, fused ? (T*)s->vec : (T*)nullptr);
     if (st < 0) return st;
@@ -1156,8 +1159,8 @@ int tgp_trace_factor(int64_t n_pad, const char* options, int32_t fused, int64_t*
   double* X = static_cast<double*>(fake(uintptr_t(4) << 40));
   ctx.trace_base = base;
   KProg kp{};
+  if (fused & 1) trace_push(&ctx, 8, ctx.stream);  // residual -> work vector (main stream, in front of the assembly)
   TGP_TRY(assemble_lower<double>(&ctx, kp, n_pad, 1, X, X, base, n_pad));
-  if (fused & 1) trace_push(&ctx, 8, ctx.stream);  // residual -> work vector (main stream)
   int32_t info = 0;
   const int st = potrf<double>(&ctx, n_pad, base, n_pad, dinv, &info, (fused & 1) ? y : nullptr);
   if (st < 0) return st;

@@ -35,6 +35,21 @@ template <> struct Mfma<double> {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ int drow(int lane, int r) { return (lane >> 4) + 4 * r; }
+  // v_mfma_f64_4x4x4_4b_f64: 73-76 TFLOP/s on this part against 46-49 for the 16x16x4 form (gemm.hip).  One
+  // instruction = four independent 4x4x4 products: lane (k = l>>4, q = (l>>2)&3, e = l&3) supplies A_q[e][k] and
+  // B_q[k][e], lane (i = l>>4, q, j = l&3) receives D_q[i][j].  A 16 x 16 x 4 step = four instructions whose B operand
+  // is read with its 4-row groups rotated by t = 0..3 (row rot4(lane, t) of the 16): acc[t] then holds, for the
+  // A-side row 4q + i and the B-side row rot4(lane, t), the product the 16x16x4 form keeps in its four-entry vector.
+  // MEASURED and switched off (profiles/r04_d): in the chain's update tasks (one workgroup per compute unit, wave tile
+  // 32 x 64, register-staged operands under the 128-VGPR cap) the form spills inside the k-loop and the tasks take
+  // 33-39 us instead of 19-25; in potf2's fold it spills 39-77 registers.  The 16x16x4 form stays until those kernels
+  // stage their operands LDS-direct like gemm.hip's.
+  static constexpr bool FAST4 = false;
+  static __device__ __forceinline__ double mma4(double a, double b, double c) {
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int rot4(int lane, int t) { return 4 * ((((lane >> 2) & 3) + t) & 3) + (lane & 3); }
+  static __device__ __forceinline__ int arow4(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
 };
 template <> struct Mfma<float> {
   using acc_t = f4;
@@ -42,6 +57,10 @@ template <> struct Mfma<float> {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ int drow(int lane, int r) { return (lane >> 4) * 4 + r; }
+  static constexpr bool FAST4 = false;  // (fp32 has no faster small form: the 16x16x4 instruction is the one to use)
+  static __device__ __forceinline__ float mma4(float a, float b, float c) { return c + a * b; }
+  static __device__ __forceinline__ int rot4(int lane, int t) { return (lane + t) & 15; }
+  static __device__ __forceinline__ int arow4(int lane) { return lane & 15; }
 };
 
 // 1/x and 1/sqrt(x) from the hardware seed + two Newton steps (<= 1 ulp-class; no IEEE
@@ -490,6 +509,9 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
   T* sA = S;                  // [2][FK * F_LD]
   T* sB = S + 2 * FK * F_LD;  // [2][FK * F_LD]
   const int wr = w >> 1, wc = w & 1;  // wave tile: 32 rows x 64 columns
+  // acc[a][b]: the 16 x 16 block (rows wr*32 + b*16.., columns wc*64 + a*16..) of the wave's 32 x 64 tile.  fp64: four
+  // scalars per lane from the 4x4x4_4b instruction (entry t <-> row rot4(lane, t), column arow4(lane) of the block);
+  // fp32: the 16x16x4 form's vector (entry r <-> row lrow, column drow(lane, r))
   acc_t acc[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -514,6 +536,9 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
       *reinterpret_cast<T2*>(&sB[buf * FK * F_LD + kk * F_LD + lane * 2]) = rb[r];
     }
   };
+  int rot[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) rot[t] = M::rot4(lane, t);
   load_global(0);
   store_lds(0);
   __syncthreads();
@@ -522,38 +547,77 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
     const int buf = kt & 1;
     if (kt + 1 < nkt) load_global(kt + 1);
     const T* pa = &sB[buf * FK * F_LD + lk * F_LD + wc * 64 + lrow];  // MFMA A operand <- Xj rows (C column)
-    const T* pb = &sA[buf * FK * F_LD + lk * F_LD + wr * 32 + lrow];  // MFMA B operand <- Xi rows (C row)
+    if constexpr (M::FAST4) {
+      const T* pb = &sA[buf * FK * F_LD + lk * F_LD + wr * 32];  // MFMA B operand <- Xi rows (C row), rotated reads
 #pragma unroll
-    for (int ks = 0; ks < FK / 4; ++ks) {
-      T aop[4], bop[2];
+      for (int ks = 0; ks < FK / 4; ++ks) {
+        T aop[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
+        for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) bop[b] = pb[ks * 4 * F_LD + b * 16];
+        for (int b = 0; b < 2; ++b) {
+          T bop[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+          for (int t = 0; t < 4; ++t) bop[t] = pb[ks * 4 * F_LD + b * 16 + rot[t]];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = M::mma(aop[a], bop[b], acc[a][b]);
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[a][b][t] = M::mma4(aop[a], bop[t], acc[a][b][t]);
+        }
+      }
+    } else {
+      const T* pb = &sA[buf * FK * F_LD + lk * F_LD + wr * 32 + lrow];  // MFMA B operand <- Xi rows (C row)
+#pragma unroll
+      for (int ks = 0; ks < FK / 4; ++ks) {
+        T aop[4], bop[2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bop[b] = pb[ks * 4 * F_LD + b * 16];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = M::mma(aop[a], bop[b], acc[a][b]);
+      }
     }
     if (kt + 1 < nkt) store_lds(buf ^ 1);
     __syncthreads();
   }
-  // C[wr*32 + b*16 + lrow, wc*64 + a*16 + drow(lane, r)] -= acc[a][b][r]
   T* Cu = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + int64_t(wc * 64) * ld + wr * 32;
-  const uint32_t coff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
+  if constexpr (M::FAST4) {
+    // C[wr*32 + b*16 + rot[t], wc*64 + a*16 + arow4(lane)] -= acc[a][b][t]
+    const int64_t ccol = M::arow4(lane);
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    T cc[2][4];
+    for (int a = 0; a < 4; ++a) {
+      T cc[2][4];
+      T* col = Cu + (int64_t(a * 16) + ccol) * ld;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cc[b][r] = (Cu + int64_t(a * 16 + M::drow(0, r)) * ld + b * 16)[coff];
+        for (int t = 0; t < 4; ++t) cc[b][t] = col[b * 16 + rot[t]];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        st_agent(Cu + int64_t(a * 16 + M::drow(0, r)) * ld + b * 16 + coff, T(cc[b][r] - acc[a][b][r]));
-    __builtin_amdgcn_sched_barrier(0);  // one pass of eight loads at a time (register budget: 128)
+        for (int t = 0; t < 4; ++t) st_agent(col + b * 16 + rot[t], T(cc[b][t] - acc[a][b][t]));
+      __builtin_amdgcn_sched_barrier(0);  // one pass of eight loads at a time (register budget: 128)
+    }
+  } else {
+    // C[wr*32 + b*16 + lrow, wc*64 + a*16 + drow(lane, r)] -= acc[a][b][r]
+    const uint32_t coff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      T cc[2][4];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cc[b][r] = (Cu + int64_t(a * 16 + M::drow(0, r)) * ld + b * 16)[coff];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          st_agent(Cu + int64_t(a * 16 + M::drow(0, r)) * ld + b * 16 + coff, T(cc[b][r] - acc[a][b][r]));
+      __builtin_amdgcn_sched_barrier(0);  // one pass of eight loads at a time (register budget: 128)
+    }
   }
 }
 
@@ -592,14 +656,38 @@ __device__ __forceinline__ void chain_update_diag(const ChainArgs<T>& q, T* S, i
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const T* row = &Xc[(ks * 4 + lk) * XC_LD + lrow];
-      const T b1 = row[i1 * 16], b2 = row[i2 * 16];
+      if constexpr (M::FAST4) {  // block rows i1 / i2 as the B operand, rotated reads (see Mfma<double>)
+        const T* rowb = &Xc[(ks * 4 + lk) * XC_LD];
 #pragma unroll
-      for (int tt = 0; tt < 5; ++tt) {
-        if (tt < nt) {
-          const int t = t0 + tt;
-          const bool first = t <= pr;
-          const int jj = first ? t : t - pr - 1;
-          Cf[tt] = M::mma(row[jj * 16], first ? b1 : b2, Cf[tt]);
+        for (int half = 0; half < 2; ++half) {
+          T bo[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bo[u] = rowb[(half ? i2 : i1) * 16 + M::rot4(lane, u)];
+#pragma unroll
+          for (int tt = 0; tt < 5; ++tt) {
+            if (tt < nt) {
+              const int t = t0 + tt;
+              const bool first = t <= pr;
+              if (first == (half == 0)) {
+                const int jj = first ? t : t - pr - 1;
+                const T av = row[jj * 16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Cf[tt][u] = M::mma4(av, bo[u], Cf[tt][u]);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        const T b1 = row[i1 * 16], b2 = row[i2 * 16];
+#pragma unroll
+        for (int tt = 0; tt < 5; ++tt) {
+          if (tt < nt) {
+            const int t = t0 + tt;
+            const bool first = t <= pr;
+            const int jj = first ? t : t - pr - 1;
+            Cf[tt] = M::mma(row[jj * 16], first ? b1 : b2, Cf[tt]);
+          }
         }
       }
     }
@@ -613,7 +701,9 @@ __device__ __forceinline__ void chain_update_diag(const ChainArgs<T>& q, T* S, i
       const int ii = first ? i1 : i2, jj = first ? t : t - pr - 1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        T* pe = Acc + int64_t(jj * 16 + M::drow(lane, r)) * ld + ii * 16 + lrow;
+        // entry r of a block's accumulator: (row, column) inside the 16 x 16 block
+        const int br = M::FAST4 ? M::rot4(lane, r) : lrow, bc = M::FAST4 ? M::arow4(lane) : M::drow(lane, r);
+        T* pe = Acc + int64_t(jj * 16 + bc) * ld + ii * 16 + br;
         st_agent(pe, T(*pe - Cf[tt][r]));
       }
     }
@@ -1984,29 +2074,43 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     TGP_TRY(ev_record(ctx, ev_chain[0], S1));
     for (int64_t p = 0; p + 1 < P; ++p) {
       const int64_t kb = s0[p + 1] - s0[p], next = s0[p + 1], wn = s0[p + 2] - s0[p + 1], mt = n - next;
-      // -- main stream FIRST in host order (its work of this step waits for nothing the host enqueues below, and the
-      // ~40 calls of a chain launch with its pollers would otherwise sit in front of it): panel p is final ->
-      // pre(p), rest(p)
-      TGP_TRY(st_wait(ctx, S0, ev_chain[p & 1]));
-      if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S0, ctx->ev_asm));
-      if (p + 2 < P) {
-        const int64_t next2 = s0[p + 2], wn2 = s0[p + 3] - s0[p + 2], mt2 = n - next2;
-        TGP_TRY(trailing(S0, mt2, wn2, kb, A + s0[p] * ld + next2, A + next2 * ld + next2, first_role(mt2, wn2)));
-        TGP_TRY(ev_record(ctx, ev_pre[p & 1], S0));
-        const int64_t next3 = s0[p + 3], m3 = n - next3;
-        if (m3 > 0) {
-          const int64_t t3 = m3 / TILE;
-          if (t3 * (t3 + 1) / 2 <= ctx->reserve_max_tiles) ctx->reserve_hint = ctx->chain_reserve;
-          TGP_TRY(trailing(S0, m3, m3, kb, A + s0[p] * ld + next3, A + next3 * ld + next3, 0));
+      // main stream: panel p is final -> pre(p), rest(p)
+      auto main_part = [&]() -> int {
+        TGP_TRY(st_wait(ctx, S0, ev_chain[p & 1]));
+        if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S0, ctx->ev_asm));
+        if (p + 2 < P) {
+          const int64_t next2 = s0[p + 2], wn2 = s0[p + 3] - s0[p + 2], mt2 = n - next2;
+          TGP_TRY(trailing(S0, mt2, wn2, kb, A + s0[p] * ld + next2, A + next2 * ld + next2, first_role(mt2, wn2)));
+          TGP_TRY(ev_record(ctx, ev_pre[p & 1], S0));
+          const int64_t next3 = s0[p + 3], m3 = n - next3;
+          if (m3 > 0) {
+            const int64_t t3 = m3 / TILE;
+            if (t3 * (t3 + 1) / 2 <= ctx->reserve_max_tiles) ctx->reserve_hint = ctx->chain_reserve;
+            TGP_TRY(trailing(S0, m3, m3, kb, A + s0[p] * ld + next3, A + next3 * ld + next3, 0));
+          }
         }
+        return TGP_OK;
+      };
+      // priority stream: gate(p), then the chain of panel p+1
+      auto chain_part = [&]() -> int {
+        if (p >= 1) TGP_TRY(st_wait(ctx, S1, ev_pre[(p - 1) & 1]));
+        if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S1, ctx->ev_asm));
+        TGP_TRY(trailing(S1, mt, wn, kb, A + s0[p] * ld + next, A + next * ld + next, first_role(mt, wn)));
+        TGP_TRY(potf2_at(S1, next, false));
+        TGP_TRY(panel(S1, next, wn, true, 0, no_mid));
+        TGP_TRY(ev_record(ctx, ev_chain[(p + 1) & 1], S1));
+        return TGP_OK;
+      };
+      // host order (chain_depth2 = 2: the main stream's calls first).  Either order is race-free -- each part waits
+      // only for events of EARLIER steps -- but which stream's kernels reach the device first shapes the start of
+      // the evaluation: the chain pipeline ahead of the first big update, or beside it
+      if (ctx->chain_depth2 == 2) {
+        TGP_TRY(main_part());
+        TGP_TRY(chain_part());
+      } else {
+        TGP_TRY(chain_part());
+        TGP_TRY(main_part());
       }
-      // -- priority stream: gate(p), then the chain of panel p+1
-      if (p >= 1) TGP_TRY(st_wait(ctx, S1, ev_pre[(p - 1) & 1]));
-      if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S1, ctx->ev_asm));
-      TGP_TRY(trailing(S1, mt, wn, kb, A + s0[p] * ld + next, A + next * ld + next, first_role(mt, wn)));
-      TGP_TRY(potf2_at(S1, next, false));
-      TGP_TRY(panel(S1, next, wn, true, 0, no_mid));
-      TGP_TRY(ev_record(ctx, ev_chain[(p + 1) & 1], S1));
     }
     TGP_TRY(st_wait(ctx, S0, ev_chain[(P - 1) & 1]));
   } else
