@@ -253,9 +253,12 @@ int tgp_solver_alpha(tgp_solver* s, const void* resid_host, void* alpha_host, do
  * ADD/MUL and unused p1); grad_noise_host (n,) = d ll / d noise_i = 1/2 (alpha_i^2 - K^-1_ii), or
  * NULL; alpha_host (n,) = K^-1 resid = d ll / d mean_i, or NULL.  Needs tgp_solver_factor first;
  * allocates ONE (n_pad + 128) x n_pad work matrix on first use (L^-1 in both orientations, then K^-1 in the lower one's
- * place; kept between calls up to 4 GiB, see option "keep_grad_buffers"). */
+ * place; kept between calls up to 4 GiB, see option "keep_grad_buffers").
+ * grad_logscale (d doubles, or NULL): d ll / d log s_q for a scaling x_q -> s_q x_q of input dimension q of the
+ * coordinates the solver holds -- what transforms.Linear / Cholesky with per-dimension scales need (reference
+ * transforms.py:39-133, kernels/stationary.py:41-43); one extra pass over K^-1 per dimension. */
 int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, double* grad_params,
-                    void* grad_noise_host, void* alpha_host);
+                    void* grad_noise_host, void* alpha_host, double* grad_logscale);
 /* mean = K(Xt, X) alpha (gp.py:353-357; K9 fused). Xt host (m,d) row-major */
 int tgp_solver_cond_mean(tgp_solver* s, const tgp_kop* prog, int nops, int64_t m,
                          const void* Xt_host, const void* alpha_host, void* mean_host);

@@ -44,3 +44,19 @@ def finite_difference_grad(build, theta, X, diag, y, *, rel_step=1e-5):
         lm = float(o.GaussianProcess(build(tm), X, diag=diag).log_probability(y))
         g[p] = (lp - lm) / (2 * h)
     return g
+
+
+class Scaled:
+    """Oracle kernel on per-dimension scaled inputs, ``k(s * x1, s * x2)``: what the reference's
+    ``transforms.Linear(scale, kernel)`` evaluates for a 0- or 1-dimensional scale (transforms.py:39-72) -- the oracle
+    restatement has no transforms module, and this is all the gradient tests need of one."""
+
+    def __init__(self, scale, kernel):
+        self.scale, self.kernel = np.asarray(scale, dtype=np.float64), kernel
+
+    def __call__(self, X1, X2=None):
+        X1 = np.asarray(X1) * self.scale
+        return self.kernel(X1) if X2 is None else self.kernel(X1, np.asarray(X2) * self.scale)
+
+    def __rmul__(self, c):
+        return Scaled(self.scale, c * self.kernel)

@@ -90,7 +90,7 @@ SIGNATURES = {
     "tgp_solver_set_resid": [_vp, _vp],
     "tgp_solver_logprob": [_vp, _vp, _pdbl],
     "tgp_solver_alpha": [_vp, _vp, _vp, _pdbl],
-    "tgp_solver_grad": [_vp, _vp, _pdbl, _pdbl, _vp, _vp],
+    "tgp_solver_grad": [_vp, _vp, _pdbl, _pdbl, _vp, _vp, _pdbl],
     "tgp_solver_cond_mean": [_vp, _pkop, _int, _i64, _vp, _vp, _vp],
     "tgp_solver_condition_cov": [_vp, _pkop, _int, _i64, _vp, _vp, _int, _vp],
     "tgp_solver_covariance": [_vp, _vp],
@@ -207,7 +207,7 @@ class Ctx:
         return old.value
 
     # the options that shape the factorisation's schedule (tgp_trace_factor takes the same names)
-    SCHEDULE_OPTIONS = ("nb_outer", "lookahead", "first_split", "first_small_tiles", "nb_wide_rows", "fused_step", "chain_kernel", "chain_full_rows", "chain_lds_pad", "chain_depth2",
+    SCHEDULE_OPTIONS = ("nb_outer", "lookahead", "first_split", "first_small_tiles", "nb_wide_rows", "fused_step", "chain_kernel", "chain_full_rows", "chain_lds_pad", "chain_depth2", "chain_pre_wait",
                         "gate_split", "chain_reserve", "reserve_max_tiles", "sub_panel", "sub_panel_min_rows",
                         "nb_first", "split_tail", "solve_on_update")
 

@@ -169,6 +169,7 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_f, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_g1, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_g2, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_h, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
@@ -211,6 +212,7 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
   if (ctx->ev_f) hipEventDestroy(ctx->ev_f);
   if (ctx->ev_g1) hipEventDestroy(ctx->ev_g1);
   if (ctx->ev_g2) hipEventDestroy(ctx->ev_g2);
+  if (ctx->ev_h) hipEventDestroy(ctx->ev_h);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
   if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
@@ -253,6 +255,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "chain_full_rows")) return &ctx->chain_full_rows;
   if (!strcmp(key, "chain_lds_pad")) return &ctx->chain_lds_pad;
   if (!strcmp(key, "chain_depth2")) return &ctx->chain_depth2;
+  if (!strcmp(key, "chain_pre_wait")) return &ctx->chain_pre_wait;
   if (!strcmp(key, "chain_reserve")) return &ctx->chain_reserve;
   if (!strcmp(key, "gate_split")) return &ctx->gate_split;
   if (!strcmp(key, "reserve_max_tiles")) return &ctx->reserve_max_tiles;
@@ -872,7 +875,7 @@ int tgp_solver_alpha(tgp_solver* s, const void* resid_host, void* alpha_host, do
 // Gradient of the log-probability (the reference gets it from JAX autodiff through
 // cholesky):  d ll / d theta = 1/2 sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij / d theta.
 int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, double* grad_params,
-                    void* grad_noise_host, void* alpha_host) {
+                    void* grad_noise_host, void* alpha_host, double* grad_logscale) {
   SOLVER_GUARD(s);
   NEED_FACTOR(s);
   TGP_ARG_CHECK(s->has_prog, "gradients need a kernel program (not a host covariance)");
@@ -905,6 +908,7 @@ int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, doub
     return gst;
   }
   std::vector<double> g(size_t(2 * s->kp.n), 0.0);
+  std::vector<double> gdim(size_t(grad_logscale ? s->d : 0), 0.0);
   gst = (dispatch(s->dtype, [&](auto tag) {
     using T = decltype(tag);
     const T* L = (const T*)s->A;
@@ -936,6 +940,13 @@ int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, doub
                                    hipMemcpyDeviceToHost, ctx->stream));
       }
     }
+    // d / d log(scale of input dimension q): one pass per dimension over the same K^-1 (transforms with a
+    // per-dimension scale; which_op = -1 - q selects the coordinate mode of the derivative kernel)
+    for (int q = 0; q < (int)gdim.size(); ++q) {
+      TGP_TRY(launch_kgrad<T>(ctx, s->kp, -1 - q, 0, s->n, s->d, (const T*)s->X, (const T*)alpha, Kinv, ldk,
+                              ctx->d_scal + 2));
+      TGP_HIP_TRY(hipMemcpyAsync(&gdim[size_t(q)], ctx->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (grad_noise_host) {
       TGP_TRY(launch_noise_grad<T>(ctx, s->n, (const T*)alpha, Kinv, ldk, (T*)s->vec2));
       TGP_HIP_TRY(hipMemcpyAsync(grad_noise_host, s->vec2, size_t(s->n) * es, hipMemcpyDeviceToHost,
@@ -958,6 +969,7 @@ int tgp_solver_grad(tgp_solver* s, const void* resid_host, double* logprob, doub
   }
   if (gst < 0) return gst;
   for (size_t i = 0; i < g.size(); ++i) grad_params[i] = g[i];
+  for (size_t i = 0; i < gdim.size(); ++i) grad_logscale[i] = gdim[i];
   return TGP_OK;
 }
 
@@ -1149,6 +1161,7 @@ int tgp_trace_factor(int64_t n_pad, const char* options, int32_t fused, int64_t*
   ctx.ev_f = (hipEvent_t)fake(0x160);
   ctx.ev_g1 = (hipEvent_t)fake(0x170);
   ctx.ev_g2 = (hipEvent_t)fake(0x180);
+  ctx.ev_h = (hipEvent_t)fake(0x190);
   TGP_TRY(apply_options(&ctx, options));  // every option of tgp_ctx_set_option, library defaults otherwise
   std::vector<tgp_trace_rec> recs;
   ctx.trace = &recs;

@@ -2075,10 +2075,15 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     for (int64_t p = 0; p + 1 < P; ++p) {
       const int64_t kb = s0[p + 1] - s0[p], next = s0[p + 1], wn = s0[p + 2] - s0[p + 1], mt = n - next;
       // main stream: panel p is final -> pre(p), rest(p)
+      // (chain-bound panels only, and only in the host order that records the marker first)
+      const int64_t t3p = p + 3 <= P ? (n - s0[p + 3 < P ? p + 3 : P]) / TILE : 0;
+      const bool pre_waits = ctx->chain_pre_wait != 0 && ctx->chain_depth2 != 2 &&
+                             t3p * (t3p + 1) / 2 <= ctx->reserve_max_tiles;
       auto main_part = [&]() -> int {
         TGP_TRY(st_wait(ctx, S0, ev_chain[p & 1]));
         if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S0, ctx->ev_asm));
         if (p + 2 < P) {
+          if (pre_waits) TGP_TRY(st_wait(ctx, S0, ctx->ev_h));  // behind the next panel's first potf2 (see tgp_common.h)
           const int64_t next2 = s0[p + 2], wn2 = s0[p + 3] - s0[p + 2], mt2 = n - next2;
           TGP_TRY(trailing(S0, mt2, wn2, kb, A + s0[p] * ld + next2, A + next2 * ld + next2, first_role(mt2, wn2)));
           TGP_TRY(ev_record(ctx, ev_pre[p & 1], S0));
@@ -2097,6 +2102,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
         if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S1, ctx->ev_asm));
         TGP_TRY(trailing(S1, mt, wn, kb, A + s0[p] * ld + next, A + next * ld + next, first_role(mt, wn)));
         TGP_TRY(potf2_at(S1, next, false));
+        if (pre_waits) TGP_TRY(ev_record(ctx, ctx->ev_h, S1));
         TGP_TRY(panel(S1, next, wn, true, 0, no_mid));
         TGP_TRY(ev_record(ctx, ev_chain[(p + 1) & 1], S1));
         return TGP_OK;

@@ -147,6 +147,34 @@ __device__ __forceinline__ T eval_kprog_deriv(const KProg& kp, int which_op, int
   return d0;
 }
 
+// Forward-mode derivative of the whole program with respect to the LOG-SCALE of one input dimension d (x_d -> s x_d
+// for every point): what `transforms.Linear` / `Cholesky` with a per-dimension scale need (reference
+// transforms.py:39-133; JAX differentiates through them for free).  Every stationary leaf depends on the
+// coordinates through dist / p0 resp. sq / p0^2 only, so
+//   d leaf / d log s_d = -p0 * (d leaf / d p0) * w_d,   w_d = dx_d^2 / r2 (L2 metric) or |dx_d| / r1 (L1),
+// (the w_d sum to one: scaling every dimension is scaling 1 / p0).  w1 / w2 are this pair's weights.
+template <typename T>
+__device__ __forceinline__ T eval_kprog_deriv_dim(const KProg& kp, T r1, T r2, T w1, T w2) {
+  T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+  T d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, d6 = 0, d7 = 0;
+  for (int i = 0; i < kp.n; ++i) {
+    const int op = kp.op[i];
+    if (op >= TGP_K_ADD) {
+      const T v = (op == TGP_K_ADD) ? (s1 + s0) : (s1 * s0);
+      const T dv = (op == TGP_K_ADD) ? (d1 + d0) : (d1 * s0 + s1 * d0);
+      s0 = v; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
+      d0 = dv; d1 = d2; d2 = d3; d3 = d4; d4 = d5; d5 = d6; d6 = d7;
+      continue;
+    }
+    const T v = leaf_value<T>(kp, i, r1, r2);
+    const T w = kp.metric[i] == TGP_METRIC_L2 ? w2 : w1;
+    const T dv = (op == TGP_K_CONST) ? T(0) : -T(kp.p0[i]) * leaf_deriv<T>(kp, i, 0, r1, r2) * w;
+    s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
+    d7 = d6; d6 = d5; d5 = d4; d4 = d3; d3 = d2; d2 = d1; d1 = d0; d0 = dv;
+  }
+  return d0;
+}
+
 constexpr int KT = 128;  // tile edge
 
 // ---- fast path: the program is one exp-family leaf, optionally times a constant ("amp * leaf") --
@@ -350,13 +378,16 @@ __global__ __launch_bounds__(256) void kgrad_kernel(KProg kp, int which_op, int 
       const int jl = g * (KT / 2) + c;
       const int64_t gj = c0 + jl;
       if (gj >= n || gj > gi) continue;
-      T r1 = 0, r2 = 0;
+      T r1 = 0, r2 = 0, dxd = 0;
       for (int t = 0; t < d; ++t) {
         const T dx = s1[il * d + t] - s2[jl * d + t];
         r1 += fabs(dx);
         r2 += dx * dx;
+        if (t == -1 - which_op) dxd = dx;  // (which_op < 0: the log-scale of input dimension -1 - which_op)
       }
-      const T dk = eval_kprog_deriv<T>(kp, which_op, which_param, r1, r2);
+      const T dk = which_op >= 0 ? eval_kprog_deriv<T>(kp, which_op, which_param, r1, r2)
+                                 : eval_kprog_deriv_dim<T>(kp, r1, r2, r1 > T(0) ? fabs(dxd) / r1 : T(0),
+                                                           r2 > T(0) ? dxd * dxd / r2 : T(0));
       const T gij = ai * alpha[gj] - Kinv[gj * ld + gi];
       acc += double(gij) * double(dk) * (gi == gj ? 0.5 : 1.0);
     }

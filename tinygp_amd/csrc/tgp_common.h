@@ -87,6 +87,7 @@ struct tgp_ctx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_e = nullptr;
   hipEvent_t ev_f = nullptr;  // second marker of the far in-panel updates (fused panel step: they alternate)
   hipEvent_t ev_g1 = nullptr, ev_g2 = nullptr;  // split gate: column block 1 / column blocks 2.. of the next panel updated
+  hipEvent_t ev_h = nullptr;  // depth-2 schedule: the next panel's first potf2 has been issued (priority stream)
   bool gate_pending = false;  // set by potrf in front of a panel whose block column arrives in those pieces
   int64_t nb_outer = 1024;  // measured best for N = 4k .. 32k (profiles/r01_f_nb_sweep.txt)
   int64_t lookahead = 1;
@@ -133,6 +134,10 @@ struct tgp_ctx {
   int64_t chain_full_rows = 4096;     // with at most this many rows left the WHOLE rest is one chain launch (measured
                                       // at N = 16 384: 4096 26.6 ms, 6144 26.9, 8192 27.6; per-block chain 28.2)
   int64_t chain_depth2 = 1;           // gate + chain of the next panel on the priority stream, two panels ahead
+  // depth-2 schedule, chain-bound panels (the big update has at most reserve_max_tiles tiles): pre(p) starts behind
+  // the next panel's first potf2 -- issued at once it fills every compute unit with three 48-KB workgroups, and the
+  // one-workgroup potf2 (74 KB) on the chain pipeline waited 120-290 us for room (profiles/r04_c)
+  int64_t chain_pre_wait = 1;
   int64_t chain_lds_pad = 10240;      // dynamic LDS per chain workgroup that nobody uses: one chain workgroup per CU
   int64_t chain_stamps = 0;           // 1: every chain task records its phases' time stamps (tgp_chain_stamps)
   long long* d_chain_stamps = nullptr;  // CHAIN_STAMP_TASKS x 16, allocated on first use
@@ -180,6 +185,7 @@ inline int64_t trace_event_id(const tgp_ctx* ctx, hipEvent_t ev) {
   if (ev == ctx->ev_f) return 6;
   if (ev == ctx->ev_g1) return 7;
   if (ev == ctx->ev_g2) return 8;
+  if (ev == ctx->ev_h) return 9;
   return -1;
 }
 template <typename T>

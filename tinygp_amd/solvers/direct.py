@@ -339,8 +339,10 @@ class DirectSolver(Solver):
 
     def log_probability_and_grad(self, resid):
         """``(log_probability, grads)`` with ``grads = {"kernel": [...], "noise_diag": (N,),
-        "mean": (N,)}``: derivatives with respect to ``kernel.parameters()`` (same order), to
-        every noise variance, and to every entry of the mean vector (= K^-1 r).  The
+        "mean": (N,), "transform": ...}``: derivatives with respect to ``kernel.parameters()`` (same order), to
+        every noise variance, to every entry of the mean vector (= K^-1 r), and -- when the kernel tree holds ONE
+        ``transforms.Linear`` / ``Cholesky`` with a scalar or per-dimension parameter -- to that ``scale`` /
+        ``factor`` (same shape; ``None`` otherwise).  The
         reference's users get this from ``jax.value_and_grad`` around ``log_probability``
         (docs/tutorials/quickstart.ipynb); here it is
         ``1/2 tr((alpha alpha^T - K^-1) dK/dtheta)`` with ``K^-1 = L^-T L^-1`` formed by a
@@ -356,16 +358,30 @@ class DirectSolver(Solver):
         gnoise = np.empty(self.n, dtype=self.dtype)
         alpha = np.empty(self.n, dtype=self.dtype)
         out = C.c_double()
+        # an input transform with per-dimension scales (transforms.Linear / Cholesky, reference transforms.py:39-133;
+        # kernels/stationary.py:41-43 sends users there for anisotropic length scales): the device also returns
+        # d ll / d log s_q per dimension of the transformed coordinates, one extra pass over K^-1 each
+        from tinygp_amd.transforms import find_transforms
+
+        tfs = find_transforms(self.kernel)
+        glog = (C.c_double * self.d)() if len(tfs) == 1 else None
         _ffi.check(_ffi.lib().tgp_solver_grad(self._handle, _ffi.ptr(r), C.byref(out), gp_,
-                                              _ffi.ptr(gnoise), _ffi.ptr(alpha)), "tgp_solver_grad")
+                                              _ffi.ptr(gnoise), _ffi.ptr(alpha), glog), "tgp_solver_grad")
         kgrad = [gp_[2 * i + q] for i, pair in enumerate(slots) for q in (0, 1) if pair[q] is not None]
+        tgrad = None
+        if glog is not None:
+            try:
+                tgrad = tfs[0]._logscale_gradient(np.array(list(glog)))
+            except NotImplementedError:
+                tgrad = None  # (Subspace, a Python callable, a full matrix: no per-dimension scale)
         ll = out.value
         if self.info or not np.isfinite(ll):
             ll = -np.inf
             kgrad = [np.nan] * len(kgrad)
             gnoise[:] = np.nan
             alpha[:] = np.nan
-        return self.dtype.type(ll), {"kernel": kgrad, "noise_diag": gnoise, "mean": alpha}
+            tgrad = None if tgrad is None else np.full_like(np.asarray(tgrad, dtype=np.float64), np.nan)
+        return self.dtype.type(ll), {"kernel": kgrad, "noise_diag": gnoise, "mean": alpha, "transform": tgrad}
 
     def alpha(self, resid):
         """``(K^-1 r, log_probability)`` -- the two solves of reference ``gp.py:330-334``."""

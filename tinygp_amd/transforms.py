@@ -38,8 +38,28 @@ class _PreTransform(Kernel):
         raise NotImplementedError(
             f"{type(self).__name__} carries an input transform: lower it with _lower(X)")
 
-    def _slots(self, out):  # gradients flow to the inner kernel's parameters only
+    def _slots(self, out):  # the inner kernel's parameters; the transform's own: _logscale_gradient
         self.kernel._slots(out)
+
+    def _logscale_gradient(self, glog):
+        """Gradient of log_probability with respect to THIS transform's parameter, from the device's
+        ``d ll / d log s_q`` per dimension q of the transformed coordinates (``tgp_solver_grad``'s
+        ``grad_logscale``).  Only transforms that scale each input dimension by its own factor have one."""
+        raise NotImplementedError(f"{type(self).__name__} has no per-dimension scale to differentiate")
+
+
+def find_transforms(kernel) -> list:
+    """Every input transform in a kernel tree (depth first)."""
+    out = []
+    if isinstance(kernel, _PreTransform):
+        out.append(kernel)
+        out += find_transforms(kernel.kernel)
+    else:
+        for name in ("kernel1", "kernel2"):
+            sub = getattr(kernel, name, None)
+            if sub is not None:
+                out += find_transforms(sub)
+    return out
 
 
 class Transform(_PreTransform):
@@ -68,6 +88,16 @@ class Linear(_PreTransform):
             return P @ s.T
         raise ValueError("'scale' must be 0-, 1-, or 2-dimensional")
 
+    def _logscale_gradient(self, glog):
+        # x'_q = s_q x_q:  d/d s_q = (d/d log s_q) / s_q;  a scalar scale moves every dimension at once
+        s = np.asarray(self.scale, dtype=np.float64)
+        if s.ndim == 0:
+            return float(np.sum(glog) / s)
+        if s.ndim == 1:
+            return np.asarray(glog, dtype=np.float64) / s
+        raise NotImplementedError("gradient with respect to a full (matrix) Linear scale is not available: the "
+                                  "device holds the transformed coordinates only")
+
 
 class Cholesky(_PreTransform):
     """``kernel(L^-1 x)`` for a lower-triangular (or diagonal / scalar) factor
@@ -85,6 +115,16 @@ class Cholesky(_PreTransform):
 
             return sla.solve_triangular(f, P.T, lower=True).T
         raise ValueError("'scale' must be 0-, 1-, or 2-dimensional")
+
+    def _logscale_gradient(self, glog):
+        # x'_q = x_q / f_q:  log s_q = -log f_q,  d/d f_q = -(d/d log s_q) / f_q
+        f = np.asarray(self.factor, dtype=np.float64)
+        if f.ndim == 0:
+            return float(-np.sum(glog) / f)
+        if f.ndim == 1:
+            return -np.asarray(glog, dtype=np.float64) / f
+        raise NotImplementedError("gradient with respect to a full (matrix) Cholesky factor is not available: the "
+                                  "device holds the transformed coordinates only")
 
     @classmethod
     def from_parameters(cls, diagonal, off_diagonal, kernel: Kernel) -> "Cholesky":
