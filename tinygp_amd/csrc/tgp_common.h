@@ -137,7 +137,7 @@ struct tgp_ctx {
   // depth-2 schedule, chain-bound panels (the big update has at most reserve_max_tiles tiles): pre(p) starts behind
   // the next panel's first potf2 -- issued at once it fills every compute unit with three 48-KB workgroups, and the
   // one-workgroup potf2 (74 KB) on the chain pipeline waited 120-290 us for room (profiles/r04_c)
-  int64_t chain_pre_wait = 1;
+  int64_t chain_pre_wait = 0;  // (measured: no effect at N = 16 384, -3 % at N = 8 192 -- off)
   int64_t chain_lds_pad = 10240;      // dynamic LDS per chain workgroup that nobody uses: one chain workgroup per CU
   int64_t chain_stamps = 0;           // 1: every chain task records its phases' time stamps (tgp_chain_stamps)
   long long* d_chain_stamps = nullptr;  // CHAIN_STAMP_TASKS x 16, allocated on first use
