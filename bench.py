@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured co
 # doubled per MI355X_MICROARCH.md "HBM" for wide coalesced reads).  PMC collection serialises kernels, so it cannot
 # run inside the timed region; the constant is stamped with the SHA-256 of the kernel source it was collected on
 # and is reported only while gemm.hip still has that hash and the schedule options are the defaults (else null).
-PMC_TRAFFIC = {"file": "profiles/r03_h_final_evidence.md", "bytes_per_launch": None, "launches": None,
+PMC_TRAFFIC = {"file": "profiles/r04_e_final_evidence.md", "bytes_per_launch": None, "launches": None,
                "gemm_hip_sha256_16": None}
 try:  # written by scripts/pmc_to_bench.py from the PMC databases of the evidence batch
     PMC_TRAFFIC.update(json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()))

@@ -31,14 +31,14 @@ python scripts/prof_top.py $(ls $O/kt_n65536/*.db | head -1) 8
 rm -rf $O/kt_n65536
 echo "== PMC: fabric traffic of the trailing update (separate passes), c2"; date
 for cn in FETCH_SIZE WRITE_SIZE; do
-timeout 300 rocprofv3 --pmc $cn --kernel-trace -d $O/pmc_$cn -o bench -- python bench.py --steps 2 --warmup 1 $B --no-profile > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc $cn --kernel-trace -d $O/pmc_$cn -o bench -- python bench.py --steps 2 --warmup 1 $B --no-profile --opt chain_polls=0 > /dev/null 2>&1
 echo "-- c2 $cn"; python scripts/pmc_summary.py $(ls $O/pmc_$cn/*.db | head -1) $cn | head -5
 done
 python scripts/pmc_to_bench.py $(ls $O/pmc_FETCH_SIZE/*.db | head -1) $(ls $O/pmc_WRITE_SIZE/*.db | head -1) profiles/r04_e_final_evidence.md | cut -c1-400
 cp gpurun_out/pmc_traffic.json $O/pmc_traffic.json
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 echo "== PMC: MFMA busy, c2"; date
-timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d $O/pmc_mfma -o bench -- python bench.py --steps 2 --warmup 1 $B --no-profile > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d $O/pmc_mfma -o bench -- python bench.py --steps 2 --warmup 1 $B --no-profile --opt chain_polls=0 > /dev/null 2>&1
 python scripts/pmc_multi.py $(ls $O/pmc_mfma/*.db | head -1) | head -6
 rm -rf $O/pmc_mfma
 echo "== persistent chain: stamped timeline (N = 1024, 4096)"; date
