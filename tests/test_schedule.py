@@ -264,14 +264,10 @@ CONFIGS = [
     (5120, 512, 1, 3, 1100, 3, 0, dict(chain_kernel=1, chain_full_rows=2048)),
     (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_full_rows=8192)),
     (16384, 1024, 1, 5, 1100, 2, 0, dict(chain_kernel=1, chain_full_rows=0)),
-    # ... beside a big update the chain goes out one block column per launch (the default), two, or whole
-    (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_cols_busy=0)),
-    (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_cols_busy=2)),
-    (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_cols_busy=3, chain_depth2=2)),
     # ... and without pollers (forward steps and early shares behind the whole launch)
     (5120, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0)),
     (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0)),
-    (16384, 1024, 0, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0, chain_cols_busy=0)),
+    (16384, 1024, 0, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0)),
 ]
 
 

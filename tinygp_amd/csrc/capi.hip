@@ -256,7 +256,6 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "chain_lds_pad")) return &ctx->chain_lds_pad;
   if (!strcmp(key, "chain_depth2")) return &ctx->chain_depth2;
   if (!strcmp(key, "chain_pre_wait")) return &ctx->chain_pre_wait;
-  if (!strcmp(key, "chain_cols_busy")) return &ctx->chain_cols_busy;
   if (!strcmp(key, "chain_polls")) return &ctx->chain_polls;
   if (!strcmp(key, "chain_reserve")) return &ctx->chain_reserve;
   if (!strcmp(key, "gate_split")) return &ctx->gate_split;

@@ -1853,44 +1853,39 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
     // follows on the solve stream behind a ONE-wave poll of block column j's count of final tiles: the launch is
     // never cut, and those kernels still start while it runs.
     const int64_t nblk = kb / TILE, R = (n - k0) / TILE;
-    const int64_t cb0 = blk_begin, ce0 = blk_end < 0 ? nblk : std::min<int64_t>(nblk, blk_end);
+    const int64_t cb = blk_begin, ce = blk_end < 0 ? nblk : std::min<int64_t>(nblk, blk_end);
     T* A0 = A + k0 * ld + k0;
     T* d0 = dinv + (k0 / TILE) * 2048;
-    if (cb0 >= ce0) return TGP_OK;
-    // beside a big trailing update: a few block columns per launch (ctx->chain_cols_busy), see tgp_common.h
-    const int64_t step = ctx->chain_split_hint > 0 ? ctx->chain_split_hint : ce0 - cb0;
-    ctx->chain_split_hint = 0;
+    if (cb >= ce) return TGP_OK;
+    // ONE launch for the whole range.  (Measured and dropped, profiles/r04_d: a few block columns per launch beside a
+    // big trailing update -- fewer waiting workgroups holding compute units: the update's launches ran at 0.70 instead
+    // of 0.62 of peak, the evaluation took 30.5 instead of 27.4 ms; the launch gaps put the chain on the critical path.)
     // (as in the per-block path: the early share exists when rows AND columns are left behind block after_blocks-1)
-    const bool want_mid = after_blocks > cb0 && after_blocks <= ce0 && after_blocks < nblk && R > after_blocks;
-    const bool use_polls = ctx->chain_polls != 0;
-    for (int64_t cb = cb0; cb < ce0; cb += step) {
-      const int64_t ce = std::min<int64_t>(ce0, cb + step);
-      const bool mid_in = want_mid && after_blocks > cb && after_blocks <= ce;
-      const bool follow = y != nullptr || mid_in;
-      const bool polls = follow && use_polls;
-      // (ev_d is recorded between the launch's memset and the kernel: the pollers wait for the zeroed counters only;
-      // without pollers it is recorded BEHIND the kernel and the followers wait for the whole launch)
-      TGP_TRY(launch_chain<T>(ctx, st, A0, ld, d0, pivot_off + k0, R, nblk, cb, ce, head_done && cb == 0,
-                              polls ? ctx->ev_d : (hipEvent_t) nullptr));
-      if (follow && !polls) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
-      if (follow) TGP_TRY(st_wait(ctx, S2, ctx->ev_d));
-      for (int64_t c = cb; c < ce && follow; ++c) {
-        const int64_t j0 = k0 + c * TILE;
-        const bool mid_here = mid_in && c + 1 == after_blocks;
-        if (y == nullptr && !mid_here) continue;
-        if (polls) TGP_TRY(launch_chain_poll(ctx, S2, A0, ld, R, c, cb == 0));
-        if (y != nullptr)
-          TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, n - (j0 + TILE), A + j0 * ld + j0, ld, dinv + (j0 / TILE) * 2048,
-                                          y + j0));
-        if (mid_here) {
-          TGP_TRY(ev_record(ctx, ctx->ev_e, S2));
-          TGP_TRY(mid(ctx->ev_e));
-        }
+    const bool mid_in = after_blocks > cb && after_blocks <= ce && after_blocks < nblk && R > after_blocks;
+    const bool follow = y != nullptr || mid_in;
+    const bool polls = follow && ctx->chain_polls != 0;
+    // (ev_d is recorded between the launch's memset and the kernel: the pollers wait for the zeroed counters only;
+    // without pollers -- chain_polls = 0 -- it is recorded BEHIND the kernel and the followers wait for the whole launch)
+    TGP_TRY(launch_chain<T>(ctx, st, A0, ld, d0, pivot_off + k0, R, nblk, cb, ce, head_done && cb == 0,
+                            polls ? ctx->ev_d : (hipEvent_t) nullptr));
+    if (follow && !polls) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
+    if (follow) TGP_TRY(st_wait(ctx, S2, ctx->ev_d));
+    for (int64_t c = cb; c < ce && follow; ++c) {
+      const int64_t j0 = k0 + c * TILE;
+      const bool mid_here = mid_in && c + 1 == after_blocks;
+      if (y == nullptr && !mid_here) continue;
+      if (polls) TGP_TRY(launch_chain_poll(ctx, S2, A0, ld, R, c, cb == 0));
+      if (y != nullptr)
+        TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, n - (j0 + TILE), A + j0 * ld + j0, ld, dinv + (j0 / TILE) * 2048,
+                                        y + j0));
+      if (mid_here) {
+        TGP_TRY(ev_record(ctx, ctx->ev_e, S2));
+        TGP_TRY(mid(ctx->ev_e));
       }
-      if (polls) {  // the next launch zeroes the counters only behind the last poller of this one
-        TGP_TRY(ev_record(ctx, ctx->ev_f, S2));
-        ctx->chain_polls_pending = true;
-      }
+    }
+    if (polls) {  // the next launch zeroes the counters only behind the last poller of this one
+      TGP_TRY(ev_record(ctx, ctx->ev_f, S2));
+      ctx->chain_polls_pending = true;
     }
     return TGP_OK;
   }
@@ -2007,6 +2002,11 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   const bool prof_on = ctx->profile != 0 && !ctx->trace;
   std::vector<ProfSpan> spans;
   ctx->ev_used = 0;
+  hipEvent_t prof_t0 = nullptr;  // TGP_SPAN_DUMP=1 (with ctx->profile): where each trailing-update launch sits in the evaluation
+  if (prof_on && getenv("TGP_SPAN_DUMP") != nullptr) {
+    TGP_TRY(prof_event(ctx, &prof_t0));
+    TGP_HIP_TRY(hipEventRecord(prof_t0, S0));
+  }
 
   // Panel = 128-column blocks (panel_chain above).  `head_done`: the first block's potf2 was
   // already issued by the caller.
@@ -2114,10 +2114,6 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
         TGP_TRY(trailing(S1, mt, wn, kb, A + s0[p] * ld + next, A + next * ld + next, first_role(mt, wn)));
         TGP_TRY(potf2_at(S1, next, false));
         if (pre_waits) TGP_TRY(ev_record(ctx, ctx->ev_h, S1));
-        {  // this chain runs beside rest(p): a big one -> a few block columns per launch
-          const int64_t t3 = p + 3 <= P ? (n - s0[p + 3 < P ? p + 3 : P]) / TILE : 0;
-          ctx->chain_split_hint = (t3 * (t3 + 1) / 2 > ctx->reserve_max_tiles) ? ctx->chain_cols_busy : 0;
-        }
         TGP_TRY(panel(S1, next, wn, true, 0, no_mid));
         TGP_TRY(ev_record(ctx, ev_chain[(p + 1) & 1], S1));
         return TGP_OK;
@@ -2256,6 +2252,11 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       TGP_HIP_TRY(hipEventElapsedTime(&ms, sp.e0, sp.e1));
       ctx->prof_syrk_ms += ms;
       ctx->prof_syrk_flops += sp.flops;
+      if (prof_t0 != nullptr) {
+        float at = 0;
+        TGP_HIP_TRY(hipEventElapsedTime(&at, prof_t0, sp.e0));
+        fprintf(stderr, "span at %8.3f ms  + %7.3f ms  %8.2f GF  %5.1f TF/s\n", at, ms, sp.flops * 1e-9, sp.flops / ms * 1e-9);
+      }
     }
   }
   if (info == STEP_TIMEOUT) {

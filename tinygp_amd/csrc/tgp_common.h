@@ -137,12 +137,6 @@ struct tgp_ctx {
   // depth-2 schedule, chain-bound panels (the big update has at most reserve_max_tiles tiles): pre(p) starts behind
   // the next panel's first potf2 -- issued at once it fills every compute unit with three 48-KB workgroups, and the
   // one-workgroup potf2 (74 KB) on the chain pipeline waited 120-290 us for room (profiles/r04_c)
-  // beside a BIG trailing update (more than reserve_max_tiles tiles) a panel's chain is launched this many block columns
-  // at a time (0: always the whole panel): a whole-panel launch keeps up to 256 workgroups resident that mostly WAIT for
-  // their dependencies -- each holds half a compute unit the update could use (N = 65 536: trailing update 0.75 of
-  // peak per launch instead of 0.83, profiles/r04_e) -- and the launch gaps it saves hide behind the update anyway
-  int64_t chain_cols_busy = 1;
-  int64_t chain_split_hint = 0;  // set by potrf in front of such a panel, consumed by panel_chain
   int64_t chain_polls = 1;       // 0: forward steps / early shares behind the chain launch (kernel-serialising profilers)
   int64_t chain_pre_wait = 0;  // (measured: no effect at N = 16 384, -3 % at N = 8 192 -- off)
   int64_t chain_lds_pad = 10240;      // dynamic LDS per chain workgroup that nobody uses: one chain workgroup per CU
