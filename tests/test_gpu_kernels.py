@@ -51,6 +51,44 @@ def test_kernel_matrix_matches_oracle(name, golden_dir):
     np.testing.assert_allclose(got32, ko(x1, x2), rtol=5e-4, atol=5e-4)
 
 
+def test_division_free_quotients_are_bit_identical_to_the_division():
+    """kmat_fast_kernel takes r / l and r^2 / l^2 as one multiply + four FMAs on the reciprocal (Markstein; kmat.hip,
+    UDiv) instead of the division sequence: every entry must be the division's, bit for bit -- over scales with short,
+    long and all-ones significands (the excluded case: the kernel divides), tiny and huge scales, and coordinates whose
+    distances leave the range the fast route is proven for (the kernel redoes those lanes with the division)."""
+    from tinygp_amd import _ffi
+
+    ctx = _ffi.default_ctx()
+    rng = np.random.default_rng(5)
+    all_ones = float(np.frombuffer(np.uint64(0x3FFFFFFFFFFFFFFF).tobytes(), dtype=np.float64)[0])  # 2 - 2^-52
+    scales = [0.9, 3.0, 1.0 / 3.0, 2.5, all_ones, float(np.sqrt(all_ones)), 1e-40, 1e-25, 1e25, 1e40,
+              float(rng.uniform(0.1, 10))]
+    for d in (1, 3):
+        a, b = rng.normal(size=(256, d)) * 3.0, rng.normal(size=(256, d)) * 3.0
+        sets = [("plain", a, b)]
+        big = a.copy()
+        big[7] = 1e160                      # distances ~1e160, squared ~1e320 = inf: beyond 2^300
+        big[100, 0] = np.inf
+        sets.append(("huge", big, b))
+        tiny = a * 1e-170                   # squared distances underflow to subnormals / zero
+        sets.append(("tiny", tiny, b * 1e-170))
+        for s in scales:
+            zoo = [kernels.ExpSquared(s), 1.7 * kernels.ExpSquared(s, distance=kernels.L1Distance()),
+                   kernels.Matern32(s) * 0.6, 2.5 * kernels.Matern52(s, distance=kernels.L2Distance()),
+                   kernels.Matern52(s), kernels.Exp(s)]
+            for k in zoo:
+                for tag, x1, x2 in sets:
+                    with np.errstate(all="ignore"):
+                        ctx.set_option("kmat_plain_div", 0)
+                        fast = k(x1, x2)
+                        ctx.set_option("kmat_plain_div", 1)
+                        try:
+                            plain = k(x1, x2)
+                        finally:
+                            ctx.set_option("kmat_plain_div", 0)
+                    assert np.array_equal(fast, plain, equal_nan=True), (type(k), s, d, tag)
+
+
 def test_kernel_matrix_ragged_shapes():
     """Edge shapes: single point, non-multiples of the 128 tile, D > 4 (dynamic-D path)."""
     rng = np.random.default_rng(7)

@@ -271,3 +271,15 @@ def test_host_diag_validates_like_the_pairs_route_and_constant_takes_pytrees():
     c = kernels.Constant(2.5)
     assert c._host_matrix(X, (t[:3], t[:3])).shape == (7, 3) and np.all(c._host_matrix(X, X) == 2.5)
     assert c._host_diag(X).shape == (7,)
+
+
+def test_division_free_quotient_is_the_ieee_quotient(tmp_path):
+    """csrc/kmat.hip, UDiv: 2 x 10^7 structured / random pairs through the same five operations on the host."""
+    import subprocess
+    from pathlib import Path
+
+    exe = tmp_path / "markstein_check"
+    src = Path(__file__).with_name("markstein_check.c")
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", str(src), "-o", str(exe), "-lm"], check=True)
+    out = subprocess.run([str(exe), "20000000"], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches=0" in out.stdout, out.stdout + out.stderr

@@ -257,6 +257,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "chain_depth2")) return &ctx->chain_depth2;
   if (!strcmp(key, "chain_pre_wait")) return &ctx->chain_pre_wait;
   if (!strcmp(key, "chain_polls")) return &ctx->chain_polls;
+  if (!strcmp(key, "kmat_plain_div")) return &ctx->kmat_plain_div;
   if (!strcmp(key, "chain_reserve")) return &ctx->chain_reserve;
   if (!strcmp(key, "gate_split")) return &ctx->gate_split;
   if (!strcmp(key, "reserve_max_tiles")) return &ctx->reserve_max_tiles;

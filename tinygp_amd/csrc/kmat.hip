@@ -205,23 +205,70 @@ static FastProg fast_prog(const KProg& kp) {
   return f;
 }
 
-template <typename T, int OP, int L2>
-__device__ __forceinline__ T leaf_fast(T r1, T r2, T p0, T p0sq) {
+// a / b for a wave-uniform divisor whose reciprocal y = RN(1 / b) was taken once per thread: the IEEE quotient, bit for
+// bit, in one multiply and four FMAs instead of the ~11-instruction division sequence (v_div_scale x2, quarter-rate
+// v_rcp, 5 FMAs, v_div_fmas, v_div_fixup) -- Markstein's theorem: with y the correctly rounded reciprocal and q1 a
+// faithful quotient, RN(q1 + (a - b q1) y) is the correctly rounded a / b, EXCEPT for divisors whose significand is all
+// ones (the one case where RN(1 / b) is not close enough): UDiv::exact is false there and for divisors outside
+// [2^-200, 2^200], and the caller divides.  q0 = RN(a y) is within 2.5 ulp, q1 = RN(q0 + (a - b q0) y) is faithful
+// (both residuals are exact: FMA).  Dividends above 2^600 (infinities) must take the division -- the caller tracks the
+// largest distance it saw (`seen` in kmat_fast_kernel) and redoes its entries with FAST = false beyond 2^300; below 2^-600 nothing of
+// the fast path can be trusted to the last bit any more (the residuals leave the normal range), but there the
+// quotient is below 2^-400 by either route and every leaf that consumes it returns exactly 1 (exp(-q / 2),
+// (1 + a) exp(-a), ...: 1 + O(q) rounds to 1) -- the kernel VALUE is the division's.  The entries stay the reference's quotients
+// (kernels/stationary.py:104-106: r / scale, r2 / scale^2), which a multiply by the reciprocal alone does not give:
+// up to 36 ulp in exp() on config 2.  Checked against the division on 4 x 10^8 structured and random
+// pairs on the host (tests/markstein_check.c) and entry for entry on the device (tests/test_gpu_kernels.py).
+template <typename T>
+struct UDiv {
+  T b, y;
+  bool exact;
+  __device__ __forceinline__ explicit UDiv(T b_) : b(b_), y(T(1) / b_), exact(false) {
+    if constexpr (sizeof(T) == 8) {
+      unsigned long long u;
+      __builtin_memcpy(&u, &b_, 8);
+      const unsigned long long frac = u & 0xFFFFFFFFFFFFFull;
+      exact = b_ >= 0x1p-200 && b_ <= 0x1p200 && frac != 0xFFFFFFFFFFFFFull;
+    }
+  }
+  template <bool FAST>
+  __device__ __forceinline__ T div(T a) const {
+    if constexpr (!FAST || sizeof(T) != 8) {
+      return a / b;
+    } else {
+      const T q0 = a * y;
+      const T r0 = __builtin_fma(-b, q0, a);
+      const T q1 = __builtin_fma(r0, y, q0);
+      const T r1 = __builtin_fma(-b, q1, a);
+      return __builtin_fma(r1, y, q1);
+    }
+  }
+};
+
+template <typename T, int OP, int L2, bool FAST>
+__device__ __forceinline__ T leaf_fast(T r1, T r2, const UDiv<T>& by_p0, const UDiv<T>& by_p0sq, const UDiv<T>& by3) {
   if constexpr (OP == TGP_K_EXPSQ) {
     const T sq = L2 ? r2 : r1 * r1;
-    return exp(T(-0.5) * (sq / p0sq));
+    return exp(T(-0.5) * by_p0sq.template div<FAST>(sq));
   } else {
     const T dist = L2 ? ((r2 == T(0)) ? r1 : sqrt(r2)) : r1;
     if constexpr (OP == TGP_K_EXP) {
-      return exp(-dist / p0);
+      return exp(-by_p0.template div<FAST>(dist));
     } else if constexpr (OP == TGP_K_M32) {
-      const T a = MathC<T>::SQRT3 * (dist / p0);
+      const T a = MathC<T>::SQRT3 * by_p0.template div<FAST>(dist);
       return (T(1) + a) * exp(-a);
     } else {
-      const T a = MathC<T>::SQRT5 * (dist / p0);
-      return (T(1) + a + (a * a) / T(3)) * exp(-a);
+      const T a = MathC<T>::SQRT5 * by_p0.template div<FAST>(dist);
+      return (T(1) + a + by3.template div<FAST>(a * a)) * exp(-a);
     }
   }
+}
+
+// (the gradient and matrix-vector kernels: the division itself)
+template <typename T, int OP, int L2>
+__device__ __forceinline__ T leaf_fast(T r1, T r2, T p0, T p0sq) {
+  const UDiv<T> by_p0(p0), by_p0sq(p0sq), by3(T(3));
+  return leaf_fast<T, OP, L2, false>(r1, r2, by_p0, by_p0sq, by3);
 }
 
 // Full interior tiles only (every row and column inside n1 x n2): no bounds checks in the loop.
@@ -234,12 +281,26 @@ __global__ __launch_bounds__(256) void kmat_fast_kernel(T p0, T amp, int64_t n1,
                                                         const T* __restrict__ X1,
                                                         const T* __restrict__ X2,
                                                         const T* __restrict__ diag, T* __restrict__ out,
-                                                        int64_t ld, int flags, int tc0) {
+                                                        int64_t ld, int flags, int tc0, int tri_h) {
   typedef T T2 __attribute__((ext_vector_type(2)));
   constexpr int NCOL = 32;
   const int cq = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int tr = blockIdx.x, tc = blockIdx.y + tc0;
-  if ((flags & KMAT_LOWER) && tr < tc) return;
+  int tr, tc;
+  if (flags & KMAT_LOWER) {
+    // 1-D grid over the tiles on and below the diagonal, column by column (local column j = 0.. holds tri_h - j tiles):
+    // a 2-D grid whose upper half returns at once spent 0.07 of 0.27 ms at N = 16 384 dispatching empty workgroups
+    // (scripts/probe_kmat.hip, profiles/r04_d)
+    const int b = blockIdx.x;
+    const double h2 = 2.0 * tri_h + 1.0;
+    int j = int((h2 - sqrt(h2 * h2 - 8.0 * double(b))) * 0.5);
+    while (j > 0 && j * tri_h - j * (j - 1) / 2 > b) --j;
+    while ((j + 1) * tri_h - (j + 1) * j / 2 <= b) ++j;
+    tc = tc0 + j;
+    tr = tc + (b - (j * tri_h - j * (j - 1) / 2));
+  } else {
+    tr = blockIdx.x;
+    tc = blockIdx.y + tc0;
+  }
   __shared__ T s2all[KT * D];
   for (int t = threadIdx.x; t < KT * D; t += 256) s2all[t] = X2[int64_t(tc) * KT * D + t];
   __syncthreads();
@@ -253,32 +314,46 @@ __global__ __launch_bounds__(256) void kmat_fast_kernel(T p0, T amp, int64_t n1,
     for (int t = 0; t < D; ++t) xr[h][t] = X1[(gi + h) * D + t];
   const bool on_diag = diag != nullptr && tr == tc;
   const T dg0 = on_diag ? diag[gi] : T(0), dg1 = on_diag ? diag[gi + 1] : T(0);
-  const T p0sq = p0 * p0;
+  const UDiv<T> by_p0(p0), by_p0sq(p0 * p0), by3(T(3));
   const int ldiag = 2 * l - cq * NCOL;  // column index (within the wave's 32) of this lane's first diagonal entry
   T* o = out + c0 * ld + gi;
+  auto columns = [&](auto fast) -> T {
+    constexpr bool FAST = decltype(fast)::value;
+    T seen = 0;  // the largest distance of this lane's entries (a NaN passes through both routes alike)
 #pragma unroll 4
-  for (int c = 0; c < NCOL; ++c) {
-    T v[2];
+    for (int c = 0; c < NCOL; ++c) {
+      T v[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      T r1 = 0, r2 = 0;
+      for (int h = 0; h < 2; ++h) {
+        T r1 = 0, r2 = 0;
 #pragma unroll
-      for (int t = 0; t < D; ++t) {
-        const T dx = xr[h][t] - s2[c * D + t];
-        r1 += fabs(dx);
-        r2 += dx * dx;
+        for (int t = 0; t < D; ++t) {
+          const T dx = xr[h][t] - s2[c * D + t];
+          r1 += fabs(dx);
+          r2 += dx * dx;
+        }
+        v[h] = amp * leaf_fast<T, OP, L2, FAST>(r1, r2, by_p0, by_p0sq, by3);
+        if constexpr (FAST) seen = fmax(seen, L2 ? r2 : r1);
       }
-      v[h] = amp * leaf_fast<T, OP, L2>(r1, r2, p0, p0sq);
+      if (on_diag) {  // noise.py:77-78 fused
+        if (c == ldiag) v[0] += dg0;
+        if (c == ldiag + 1) v[1] += dg1;
+      }
+      T2 pair;
+      pair.x = v[0];
+      pair.y = v[1];
+      // (non-temporal stores: 6 % in the stand-alone probe at N = 16 384, nothing at 32 768 and nothing in the library)
+      *reinterpret_cast<T2*>(o + int64_t(c) * ld) = pair;
     }
-    if (on_diag) {  // noise.py:77-78 fused
-      if (c == ldiag) v[0] += dg0;
-      if (c == ldiag + 1) v[1] += dg1;
-    }
-    T2 pair;
-    pair.x = v[0];
-    pair.y = v[1];
-    *reinterpret_cast<T2*>(o + int64_t(c) * ld) = pair;
+    return seen;
+  };
+  // (wave-uniform: the divisors are kernel arguments; KMAT_PLAIN_DIV is the tests' switch to the division itself)
+  bool plain = true;
+  if (sizeof(T) == 8 && !(flags & KMAT_PLAIN_DIV) && by_p0.exact && by_p0sq.exact) {
+    // every dividend -- r, r^2, (sqrt(5) r / l)^2 -- stays below 2^1010 while r <= 2^300
+    plain = !(columns(std::true_type{}) <= T(0x1p300));
   }
+  if (plain) columns(std::false_type{});
 }
 
 // D = 0: dynamic dimension (coordinates re-read from LDS); D > 0: row point in registers.
@@ -695,11 +770,17 @@ int launch_kmat_cols(tgp_ctx* ctx, hipStream_t st, const KProg& kp, int64_t n1, 
     ftr = int(n1 / KT);
     ftc = int(n2 / KT);
     const int64_t fc = std::min<int64_t>(tc0 + ntc, ftc) - tc0;  // column tiles of this call that are full
-    if (ftr > 0 && fc > 0) {
+    // lower-only: column tile c holds the row tiles c .. ftr-1 (the matrix is square there)
+    const int64_t tri_h = (flags & KMAT_LOWER) ? ftr - tc0 : 0;
+    const int64_t tri_c = std::min<int64_t>(fc, tri_h);  // columns of this call with a tile on or below the diagonal
+    const bool any = (flags & KMAT_LOWER) ? (tri_c > 0) : (ftr > 0 && fc > 0);
+    if (any) {
       dim3 fgrid((unsigned)ftr, (unsigned)fc);
+      if (flags & KMAT_LOWER) fgrid = dim3((unsigned)(tri_c * tri_h - tri_c * (tri_c - 1) / 2));
 #define TGP_FAST3(DD, OP, L2)                                                                     \
   hipLaunchKernelGGL((kmat_fast_kernel<T, DD, OP, L2>), fgrid, dim3(256), 0, st, T(fp.p0),        \
-                     T(fp.amp), n1, n2, X1, X2, diag, out, ld, flags, (int)tc0)
+                     T(fp.amp), n1, n2, X1, X2, diag, out, ld, flags | (ctx->kmat_plain_div != 0 ? KMAT_PLAIN_DIV : 0), (int)tc0,  \
+                     (int)tri_h)
 #define TGP_FAST2(DD, OP)                                                                         \
   do {                                                                                           \
     if (fp.l2) TGP_FAST3(DD, OP, 1); else TGP_FAST3(DD, OP, 0);                                   \

@@ -137,6 +137,7 @@ struct tgp_ctx {
   // depth-2 schedule, chain-bound panels (the big update has at most reserve_max_tiles tiles): pre(p) starts behind
   // the next panel's first potf2 -- issued at once it fills every compute unit with three 48-KB workgroups, and the
   // one-workgroup potf2 (74 KB) on the chain pipeline waited 120-290 us for room (profiles/r04_c)
+  int64_t kmat_plain_div = 0;    // tests: the assembly's quotients by the division instruction sequence (kmat.hip, UDiv)
   int64_t chain_polls = 1;       // 0: forward steps / early shares behind the chain launch (kernel-serialising profilers)
   int64_t chain_pre_wait = 0;  // (measured: no effect at N = 16 384, -3 % at N = 8 192 -- off)
   int64_t chain_lds_pad = 10240;      // dynamic LDS per chain workgroup that nobody uses: one chain workgroup per CU
@@ -241,6 +242,7 @@ int launch_kmat_cols(tgp_ctx* ctx, hipStream_t st, const KProg& kp, int64_t n1, 
                      int64_t cols_out, int flags, int64_t tc0, int64_t ntc);
 constexpr int KMAT_LOWER = 1;         // only tiles on/below the diagonal
 constexpr int KMAT_PAD_IDENTITY = 2;  // padding = identity (else zeros)
+constexpr int KMAT_PLAIN_DIV = 4;     // straight-line evaluator: the division itself instead of UDiv (ctx kmat_plain_div; tests)
 
 template <typename T>
 int launch_kdiag(tgp_ctx* ctx, const KProg& kp, int64_t n, int d, const T* X, const T* add, T* out);
