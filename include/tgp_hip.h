@@ -110,10 +110,22 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       panel_step_kernel); 0 (default): potf2 | trsm | in-panel update as separate
  *                       launches.  "gate_split" (with fused_step = 1): the block-column update
  *                       between two chains in three column pieces, the chain starts behind the first
- *   "chain_kernel"      1: the panel chain is ONE persistent launch per panel (two when an early share of the next
- *                       gate branches off): tile tasks behind a ticket counter factor the diagonal blocks, solve
- *                       the rows below and apply the in-panel updates left-looking, hand-offs by per-tile flag
- *                       words (chol.hip, chain_kernel); no update stream, no per-block launches or events
+ *   "chain_kernel"      1 (default): the panel chain is ONE persistent launch per panel: tile tasks behind a ticket
+ *                       counter factor the diagonal blocks, solve the rows below and apply the in-panel updates
+ *                       right-looking (one 128^3 task per tile and source column), hand-offs by per-tile state words
+ *                       (chol.hip, chain_kernel); no update stream, no per-block launches or events.  0: rounds 1-3's
+ *                       per-block launches.  With it:
+ *                       "chain_full_rows" (4096): with at most this many rows left the whole rest is ONE launch;
+ *                       "chain_depth2" (1; 2 = the main stream's calls first on the host; 0 = off): the chain
+ *                       pipeline -- gate, potf2, chain of the next panel -- on the priority stream, the main stream
+ *                       carries trailing updates only;  "chain_lds_pad" (10240): unused dynamic LDS that keeps a
+ *                       second chain workgroup off a compute unit;  "chain_pre_wait" (0): pre(p) behind the next
+ *                       panel's first potf2 on chain-bound panels;  "chain_polls" (1): consumers of a block column
+ *                       (forward steps, early shares) follow behind a one-wave poll while the launch runs; 0: behind
+ *                       the whole launch -- for profilers that run kernels one at a time (rocprofv3 --pmc);
+ *                       "chain_stamps" (0): tgp_chain_stamps below
+ *   "kmat_plain_div"    1: the straight-line assembly kernel takes r / l, r^2 / l^2 by the division sequence instead
+ *                       of the bit-identical reciprocal + FMA form (kmat.hip, UDiv) -- the tests' switch
  *   "chain_reserve"     workgroup slots (of two per CU) that a trailing update running beside a panel
  *                       chain leaves to the chain's kernels (default 128; 0: the update fills the chip)
  *   "reserve_max_tiles" ... when the update has at most this many 128x128 tiles (default 1200)
@@ -399,6 +411,8 @@ int tgp_dist_get_column(tgp_dist* h, int64_t l, void* out_host);
  *       11 persistent chain   v = {panel origin offset, ld, row tiles, first block column, end block column}
  *                                  (potf2 of blocks [max(first, 1), end), the solves of the rows below and the
  *                                  in-panel updates of those block columns: ONE launch)
+ *       12 chain poll         v = {panel origin offset, ld, block column}: the stream continues once that block
+ *                                  column of the chain launch in front of it (host order) is final
  * `fused`: 1 = forward substitution fused into the factorisation.  `options`: "key=value,..." over the
  * names of tgp_ctx_set_option (the format of the TGP_HIP_OPTIONS environment variable), NULL or "" for
  * the library defaults -- the dry run takes every tuning the real run takes.
