@@ -813,6 +813,168 @@ __device__ __forceinline__ void chain_solve(const ChainArgs<T>& q, T* S, int i, 
   chain_stamp(st, s0 + 1);  // solved, stores issued
 }
 
+// ---- the diagonal chain's two-phase solve + fold (diag tasks only) ---------------------------------------------
+// potf2 stores column block kb of L_cc and its 16 x 16 inverse under step kb+1, so the first 64 columns and four
+// inverses are in memory when three of its eight elimination steps are still to come.  It publishes them as a HALF
+// (potf2_body.inc, POTF2_PRE_SYNC / POTF2_POST_SYNC), and the next diagonal task does everything that needs no more
+// than that while the factorisation finishes: the first four 16-column blocks of X_{c+1,c} (the solve's recurrence
+// walks the column blocks in order) and the first half of the fold, X[:, :64] X[:, :64]^T, which it applies to tile
+// (c+1, c+1) in global memory.  Behind the FINAL flag remain: 26 of the 36 blocks of L_cc to stage, four column
+// blocks to solve, the second half of the fold (potf2_body.inc with POTF2_FOLD_H0 = 1) -- about 9 us less between two
+// potf2 than with everything behind the final flag (profiles/r04_b).
+//
+// blocks [b_lo, b_hi) of the solve's LDS image of L_cc (potf2's block image: block b = bi (bi + 1) / 2 + bj; the 28
+// blocks below the diagonal as they are, the diagonal slots take the 16 x 16 inverses); block b is wave b % 8's.  In
+// rounds of three blocks per wave: the tile's 64 registers are live beside the staging registers.
+template <typename T>
+__device__ __forceinline__ void chain_stage_blocks(const ChainArgs<T>& q, T* S, int c, int b_lo, int b_hi) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lrow = lane & 15, lk = lane >> 4;
+  const int64_t ld = q.ld;
+  const T* Ljj = q.A0 + int64_t(c) * TILE * ld + int64_t(c) * TILE;
+  const T* dinv = q.dinv + int64_t(c) * 2048;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    constexpr int NTR = 3;
+    T tr[NTR][4];
+    const int t_lo = round * NTR, t_n = round == 0 ? NTR : 5 - NTR;
+#pragma unroll
+    for (int tq = 0; tq < NTR; ++tq) {
+      const int b = w + 8 * (t_lo + tq);
+      if (tq < t_n && b >= b_lo && b < b_hi) {
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+        const int bj = b - bi * (bi + 1) / 2;
+        if (bi == bj) {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) tr[tq][qq] = dinv[bi * 256 + qq * 64 + lane];
+        } else {
+          const int voff = lk * int(ld) + lrow;
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) tr[tq][qq] = (Ljj + int64_t(bj * 16 + qq * 4) * ld + bi * 16)[voff];
+        }
+      }
+    }
+#pragma unroll
+    for (int tq = 0; tq < NTR; ++tq) {
+      const int b = w + 8 * (t_lo + tq);
+      if (tq < t_n && b >= b_lo && b < b_hi) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) S[b * 256 + qq * 64 + lane] = tr[tq][qq];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// column blocks [JB0, JB1) of X_ic = A_ic L_cc^-T (chain_solve's recurrence; V[kb], kb < JB0, hold -X's earlier blocks)
+template <typename T, int JB0, int JB1>
+__device__ __forceinline__ void chain_solve_cols(const ChainArgs<T>& q, const T* S, int i, int c,
+                                                 typename Mfma<T>::acc_t (&V)[8]) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lrow = lane & 15;
+  const int64_t ld = q.ld;
+  T* bs = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + w * 16;  // wave-uniform; lane offset below
+  asm volatile("" : "+s"(bs));
+  const uint32_t boff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
+#pragma unroll
+  for (int jb = JB0; jb < JB1; ++jb) {
+    acc_t acc = V[jb], acc2 = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb < jb; ++kb) {
+      const T* Lb = &S[blk(jb, kb)];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const T l = Lb[M::drow(lane, s) * 16 + lrow];
+        if (s & 1) acc2 = M::mma(l, V[kb][s], acc2);
+        else acc = M::mma(l, V[kb][s], acc);
+      }
+    }
+    acc += acc2;
+    const T* Db = &S[blk(jb, jb)];
+    acc_t y = acc_t{0, 0, 0, 0}, y2 = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const T d = Db[M::drow(lane, s) * 16 + lrow];
+      if (s & 1) y2 = M::mma(d, acc[s], y2);
+      else y = M::mma(d, acc[s], y);
+    }
+    y += y2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st_agent(bs + int64_t(jb * 16 + M::drow(0, r)) * ld + boff, T(y[r]));
+    V[jb] = -y;
+  }
+}
+
+// Cf += (32 columns of X, two operand blocks Va, Vb of every wave's 16 rows) x the same, transposed: the lower 36
+// blocks of the 128 x 128 product, distributed as in potf2_body.inc's fold (rows p and 7 - p: waves p and p + 4),
+// slabs exchanged through Xc ([32 k][144]: 36 KB).  The caller separates two calls on one Xc by a barrier.
+template <typename T>
+__device__ __forceinline__ void chain_fold_part(T* Xc, const typename Mfma<T>::acc_t& Va,
+                                                const typename Mfma<T>::acc_t& Vb, typename Mfma<T>::acc_t (&Cf)[5]) {
+  using M = Mfma<T>;
+  constexpr int XC_LD = 144;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lrow = lane & 15, lk = lane >> 4;
+  const int pr = w & 3, i1 = pr, i2 = 7 - pr;
+  const int t0 = (w < 4) ? 0 : 5, nt = (w < 4) ? 5 : 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    Xc[(r * 4 + lk) * XC_LD + w * 16 + lrow] = Va[r];
+    Xc[((4 + r) * 4 + lk) * XC_LD + w * 16 + lrow] = Vb[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const T* row = &Xc[(ks * 4 + lk) * XC_LD + lrow];
+    const T b1 = row[i1 * 16], b2 = row[i2 * 16];
+#pragma unroll
+    for (int tt = 0; tt < 5; ++tt) {
+      if (tt < nt) {
+        const int t = t0 + tt;
+        const bool first = t <= pr;
+        const int jj = first ? t : t - pr - 1;
+        Cf[tt] = M::mma(row[jj * 16], first ? b1 : b2, Cf[tt]);
+      }
+    }
+  }
+}
+
+// tile (c, c) -= Cf in global memory (agent-scope loads, write-through stores): blocks and lanes as in the fold
+template <typename T>
+__device__ __forceinline__ void chain_apply_fold(T* A, int64_t ld, const typename Mfma<T>::acc_t (&Cf)[5]) {
+  using M = Mfma<T>;
+  using bits_t = typename AgentBits<T>::t;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lrow = lane & 15;
+  const int pr = w & 3, i1 = pr, i2 = 7 - pr;
+  const int t0 = (w < 4) ? 0 : 5, nt = (w < 4) ? 5 : 4;
+#pragma unroll
+  for (int tt = 0; tt < 5; ++tt) {
+    if (tt < nt) {
+      const int t = t0 + tt;
+      const bool first = t <= pr;
+      const int ii = first ? i1 : i2, jj = first ? t : t - pr - 1;
+      T* blk0 = A + int64_t(jj * 16) * ld + ii * 16 + lrow;
+      T old[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bits_t u = __hip_atomic_load(reinterpret_cast<const bits_t*>(blk0 + int64_t(M::drow(lane, r)) * ld),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_memcpy(&old[r], &u, sizeof(T));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st_agent(blk0 + int64_t(M::drow(lane, r)) * ld, T(old[r] - Cf[tt][r]));
+    }
+  }
+}
+
 // One task per workgroup (grid = number of tasks): a task loop inside the kernel lets the compiler hoist the
 // lane-derived values of every phase across the whole loop body -- 100+ spilled VGPRs under the 128-register cap
 // that keeps two chain workgroups on a CU beside the trailing update.  Tickets are taken at workgroup start, so
@@ -917,21 +1079,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int32_t pivot_base = q.pivot_base + c * TILE;
   uint32_t* frow = q.flags + c * CHAIN_FLAG_LD;
   acc_t Vx[8];  // (+-) X_{c,c-1}: row w * 16 + lrow, column jb * 16 + drow(lane, r)
-  if (c > q.cb) {
-    // tile (c, c-1): its updates (from columns cb .. c-2 of this launch) and L_{c-1,c-1}
-    const uint32_t* wl = q.flags + (c - 1) * CHAIN_FLAG_LD + (c - 1);
+  const bool solves = c > q.cb;        // tile (c, c-1) is solved here (a continuation launch finds it final)
+  const bool in_launch = c - 1 >= 1;   // L_{c-1,c-1} is factored inside a chain launch: HALF and FINAL flags exist
+  const uint32_t* wl = q.flags + (c - 1) * CHAIN_FLAG_LD + (c - 1);
+  if (solves) {
+    // tile (c, c-1) with its updates from columns cb .. c-2 of this launch (its round trip hides behind potf2(c-1))
     if (c - 1 > q.cb) chain_wait<4>(frow + (c - 1), E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
-    chain_load_tile<T>(q, c, c - 1, Vx);  // (its round trip hides behind potf2(c-1))
-    if (!(c - 1 == 0 && head_final)) chain_wait<1>(wl, E + CHAIN_FINAL, nullptr, 0, nullptr, 0, q.info);
-    chain_stamp(st, 1);
-    chain_solve<T>(q, S, c, c - 1, Vx, st, 2);
-    // the updates behind column c-1 and the next solves need it NOW
-    chain_publish(frow + (c - 1), E + CHAIN_FINAL, q.ticket + CHAIN_COLCNT_OFF + (c - 1));
-    chain_stamp(st, 4);
-    // tile (c, c) with the updates from columns cb .. c-2 (the one from c-1 is the fold below)
-    if (c - 1 > q.cb) chain_wait<1>(frow + c, E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
-    else __syncthreads();  // (every wave is done with L_{c-1,c-1}'s image in S)
-    chain_stamp(st, 5);
+    chain_load_tile<T>(q, c, c - 1, Vx);
+    // phase 1, behind the HALF of L_{c-1,c-1} (word of the unused tile (c-2, c-1)): column blocks 0..3 of X
+    if (in_launch) chain_wait<1>(q.flags + (c - 2) * CHAIN_FLAG_LD + (c - 1), E + 1u, nullptr, 0, nullptr, 0, q.info);
+    chain_stamp(st, 8);
+    chain_stage_blocks<T>(q, S, c - 1, 0, 10);
+    __syncthreads();
+    chain_solve_cols<T, 0, 4>(q, S, c, c - 1, Vx);
   } else {
     using M = Mfma<T>;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -943,10 +1103,58 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int r = 0; r < 4; ++r) Vx[jb][r] = (Xp + int64_t(jb * 16 + M::drow(0, r)) * ld + w * 16)[xoff];
   }
   {
+    // first half of the fold, X[:, :64] X[:, :64]^T, 32 columns at a time through the part of S the ten staged blocks
+    // leave free, and straight onto tile (c, c) in memory -- which by now carries every update from columns
+    // cb .. c-2 as a rule (the wait is the one that used to sit in front of potf2)
+    acc_t Cf[5];
+#pragma unroll
+    for (int tt = 0; tt < 5; ++tt) Cf[tt] = acc_t{0, 0, 0, 0};
+    T* Xc = S + 10 * 256;
+    chain_fold_part<T>(Xc, Vx[0], Vx[1], Cf);
+    __syncthreads();
+    chain_fold_part<T>(Xc, Vx[2], Vx[3], Cf);
+    if (c - 1 > q.cb) chain_wait<1>(frow + c, E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
+    chain_apply_fold<T>(A, ld, Cf);
+    chain_stamp(st, 9);
+  }
+  if (solves) {
+    // phase 2, behind the FINAL flag (its barrier also ends the reads of the fold's exchange buffer)
+    if (in_launch) chain_wait<1>(wl, E + CHAIN_FINAL, nullptr, 0, nullptr, 0, q.info);
+    else __syncthreads();
+    chain_stamp(st, 1);
+    chain_stage_blocks<T>(q, S, c - 1, 10, 36);
+    __syncthreads();
+    chain_stamp(st, 2);
+    chain_solve_cols<T, 4, 8>(q, S, c, c - 1, Vx);
+    chain_stamp(st, 3);
+    // the updates behind column c-1 and the next solves need X NOW (drains this phase's stores AND phase 1's tile update)
+    chain_publish(frow + (c - 1), E + CHAIN_FINAL, q.ticket + CHAIN_COLCNT_OFF + (c - 1));
+    chain_stamp(st, 4);
+  }
+  if (!(solves && in_launch)) {
+    // no acquire since the tile update above: drain it and drop this compute unit's L1 before potf2 reads the tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+  }
+  chain_stamp(st, 5);
+  {
     constexpr bool FOLD = true;
+    uint32_t* half_word = q.flags + (c - 1) * CHAIN_FLAG_LD + c;  // (c >= 1 here; tile (c-1, c) does not exist)
 #define POTF2_ST(p, v) st_agent((p), T(v))
 #define POTF2_V_IN_REGS Vx
+#define POTF2_FOLD_H0 1
+#define POTF2_PRE_SYNC(kb) do { if ((kb) == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define POTF2_POST_SYNC(kb)                                                                            \
+  do {                                                                                                \
+    if ((kb) == 4 && threadIdx.x == 0)                                                                \
+      __hip_atomic_store(half_word, E + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              \
+  } while (0)
 #include "potf2_body.inc"
+#undef POTF2_POST_SYNC
+#undef POTF2_PRE_SYNC
+#undef POTF2_FOLD_H0
 #undef POTF2_V_IN_REGS
 #undef POTF2_ST
   }
