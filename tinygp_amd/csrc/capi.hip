@@ -179,8 +179,8 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipMemset(ctx->d_step_flag, 0, 64));
   TGP_HIP_TRY(hipMalloc(&ctx->d_chain_flags, size_t(tgp::CHAIN_MAX_ROW_TILES) * 64 * sizeof(uint32_t)));
   TGP_HIP_TRY(hipMemset(ctx->d_chain_flags, 0, size_t(tgp::CHAIN_MAX_ROW_TILES) * 64 * sizeof(uint32_t)));
-  TGP_HIP_TRY(hipMalloc(&ctx->d_chain_ticket, 512));
-  TGP_HIP_TRY(hipMemset(ctx->d_chain_ticket, 0, 512));
+  TGP_HIP_TRY(hipMalloc(&ctx->d_chain_ticket, 1024));
+  TGP_HIP_TRY(hipMemset(ctx->d_chain_ticket, 0, 1024));
   hipDeviceProp_t prop;
   TGP_HIP_TRY(hipGetDeviceProperties(&prop, device));
   ctx->cus = prop.multiProcessorCount;

@@ -416,7 +416,9 @@ __device__ __forceinline__ void chain_stamp(long long* st, int k) {
 
 constexpr int CHAIN_FLAG_LD = 64;  // state word of tile (i, c) of the panel: flags[i * 64 + c] (chains of <= 64 block columns)
 constexpr uint32_t CHAIN_FINAL = 127;
-constexpr int CHAIN_COLCNT_OFF = 16;  // d_chain_ticket: [0] the ticket counter, [16 + c] final tiles of block column c
+constexpr int CHAIN_COLCNT_OFF = 16;  // d_chain_ticket: [0] the ticket counter, [16 + c] final tiles of block column c,
+constexpr int CHAIN_QCNT_OFF = 96;    // [96 + k] finished quarters of the update of tile (k+2, k+1) from column k
+constexpr int CHAIN_TICKET_WORDS = CHAIN_QCNT_OFF + CHAIN_FLAG_LD;
 
 template <typename T>
 struct ChainArgs {
@@ -495,8 +497,11 @@ __global__ __launch_bounds__(64) void chain_poll_kernel(const int32_t* __restric
 
 // update(i, c, k), i > c:  A_ic -= X_ik X_ck^T.  128 x 128 x 128 on the MFMAs, operands double-buffered through S
 // as in trsm_fold_body; the tile is read and written once, write-through.
-template <typename T>
-__device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, int i, int c, int k) {
+// QUARTER: rows 32 qr .. 32 qr + 31 of the tile only, every wave 16 of its 128 columns -- a quarter of the MFMA work per
+// wave.  The update of tile (k+2, k+1) from column k is the LAST thing the next diagonal task waits for (its solve of
+// that tile runs beside potf2(k+1) only if the tile is there in time): four workgroups take a quarter each.
+template <typename T, bool QUARTER>
+__device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, int i, int c, int k, int qr) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   typedef T T2 __attribute__((ext_vector_type(2)));
@@ -508,13 +513,15 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
   static_assert(4 * FK * F_LD == 36 * 256, "the operand buffers are exactly potf2's tile image");
   T* sA = S;                  // [2][FK * F_LD]
   T* sB = S + 2 * FK * F_LD;  // [2][FK * F_LD]
-  const int wr = w >> 1, wc = w & 1;  // wave tile: 32 rows x 64 columns
+  const int wr = QUARTER ? qr : (w >> 1);              // wave tile: 32 rows x 64 columns (a quarter task: 32 x 16)
+  const int cbase = QUARTER ? w * 16 : (w & 1) * 64;   // its first column
+  constexpr int NA = QUARTER ? 1 : 4;                  // 16-column blocks per wave
   // acc[a][b]: the 16 x 16 block (rows wr*32 + b*16.., columns wc*64 + a*16..) of the wave's 32 x 64 tile.  fp64: four
   // scalars per lane from the 4x4x4_4b instruction (entry t <-> row rot4(lane, t), column arow4(lane) of the block);
   // fp32: the 16x16x4 form's vector (entry r <-> row lrow, column drow(lane, r))
-  acc_t acc[4][2];
+  acc_t acc[NA][2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
   const T* Xi = q.A0 + int64_t(k) * TILE * ld + int64_t(i) * TILE;
@@ -546,21 +553,21 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) load_global(kt + 1);
-    const T* pa = &sB[buf * FK * F_LD + lk * F_LD + wc * 64 + lrow];  // MFMA A operand <- Xj rows (C column)
+    const T* pa = &sB[buf * FK * F_LD + lk * F_LD + cbase + lrow];  // MFMA A operand <- Xj rows (C column)
     if constexpr (M::FAST4) {
       const T* pb = &sA[buf * FK * F_LD + lk * F_LD + wr * 32];  // MFMA B operand <- Xi rows (C row), rotated reads
 #pragma unroll
       for (int ks = 0; ks < FK / 4; ++ks) {
-        T aop[4];
+        T aop[NA];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
+        for (int a = 0; a < NA; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           T bop[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) bop[t] = pb[ks * 4 * F_LD + b * 16 + rot[t]];
 #pragma unroll
-          for (int a = 0; a < 4; ++a)
+          for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[a][b][t] = M::mma4(aop[a], bop[t], acc[a][b][t]);
         }
@@ -569,13 +576,13 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
       const T* pb = &sA[buf * FK * F_LD + lk * F_LD + wr * 32 + lrow];  // MFMA B operand <- Xi rows (C row)
 #pragma unroll
       for (int ks = 0; ks < FK / 4; ++ks) {
-        T aop[4], bop[2];
+        T aop[NA], bop[2];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
+        for (int a = 0; a < NA; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
 #pragma unroll
         for (int b = 0; b < 2; ++b) bop[b] = pb[ks * 4 * F_LD + b * 16];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b) acc[a][b] = M::mma(aop[a], bop[b], acc[a][b]);
       }
@@ -583,12 +590,12 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
     if (kt + 1 < nkt) store_lds(buf ^ 1);
     __syncthreads();
   }
-  T* Cu = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + int64_t(wc * 64) * ld + wr * 32;
+  T* Cu = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + int64_t(cbase) * ld + wr * 32;
   if constexpr (M::FAST4) {
     // C[wr*32 + b*16 + rot[t], wc*64 + a*16 + arow4(lane)] -= acc[a][b][t]
     const int64_t ccol = M::arow4(lane);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < NA; ++a) {
       T cc[2][4];
       T* col = Cu + (int64_t(a * 16) + ccol) * ld;
 #pragma unroll
@@ -605,7 +612,7 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
     // C[wr*32 + b*16 + lrow, wc*64 + a*16 + drow(lane, r)] -= acc[a][b][r]
     const uint32_t coff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < NA; ++a) {
       T cc[2][4];
 #pragma unroll
       for (int b = 0; b < 2; ++b)
@@ -813,164 +820,147 @@ __device__ __forceinline__ void chain_solve(const ChainArgs<T>& q, T* S, int i, 
   chain_stamp(st, s0 + 1);  // solved, stores issued
 }
 
-// ---- the diagonal chain's two-phase solve + fold (diag tasks only) ---------------------------------------------
-// potf2 stores column block kb of L_cc and its 16 x 16 inverse under step kb+1, so the first 64 columns and four
-// inverses are in memory when three of its eight elimination steps are still to come.  It publishes them as a HALF
-// (potf2_body.inc, POTF2_PRE_SYNC / POTF2_POST_SYNC), and the next diagonal task does everything that needs no more
-// than that while the factorisation finishes: the first four 16-column blocks of X_{c+1,c} (the solve's recurrence
-// walks the column blocks in order) and the first half of the fold, X[:, :64] X[:, :64]^T, which it applies to tile
-// (c+1, c+1) in global memory.  Behind the FINAL flag remain: 26 of the 36 blocks of L_cc to stage, four column
-// blocks to solve, the second half of the fold (potf2_body.inc with POTF2_FOLD_H0 = 1) -- about 9 us less between two
-// potf2 than with everything behind the final flag (profiles/r04_b).
-//
-// blocks [b_lo, b_hi) of the solve's LDS image of L_cc (potf2's block image: block b = bi (bi + 1) / 2 + bj; the 28
-// blocks below the diagonal as they are, the diagonal slots take the 16 x 16 inverses); block b is wave b % 8's.  In
-// rounds of three blocks per wave: the tile's 64 registers are live beside the staging registers.
+// ---- the diagonal chain's STREAMED solve + fold (diag tasks only) ----------------------------------------------
+// potf2 stores column block j of L_cc and its 16 x 16 inverse under step j+1, so both are in memory long before the
+// factorisation ends.  It publishes its progress step by step (potf2_body.inc, POTF2_PRE_SYNC / POTF2_POST_SYNC: the
+// word of the unused tile (c-1, c) = epoch + number of column blocks in memory), and the NEXT diagonal task follows
+// one column block behind, right-looking: behind step word > j it takes column block j of L_cc (8 - j blocks, one per
+// wave, agent-scope loads: no acquire, every wave polls for itself), finishes X_j = R_j Linv_jj^T from the running
+// residual R, stores it, takes it out of the residuals to the right (R_jb -= X_j L_jb,j^T) and adds X_j X_j^T to the
+// fold of tile (c+1, c+1) -- 16 columns of the 128 at a time, slabs exchanged through LDS as in potf2_body.inc.
+// When L_cc's FINAL flag arrives only column block 7 is left: X_7, its store, one 16-column piece of the fold.
+// Between two potf2 of the chain remain ~8 us instead of ~26 (stamps: profiles/r04_b).
 template <typename T>
-__device__ __forceinline__ void chain_stage_blocks(const ChainArgs<T>& q, T* S, int c, int b_lo, int b_hi) {
+struct ChainStream {
+  static constexpr int XC_LD = 144;           // 144 mod 32 == 16: conflict-free operand reads
+  static constexpr int LC = 8 * 256;          // one column block of L_cc: up to 8 blocks of 16 x 16
+  static constexpr int XC = 16 * XC_LD;       // one 16-column slab of X, [k][row]
+  static_assert(2 * (LC + XC) <= 36 * 256, "both double buffers live in S");
+};
+
+// wave-level wait until *word has reached `want` within the same epoch (bounded: a lost producer poisons info);
+// returns what it saw, so that a reader that is several steps behind polls ONCE
+__device__ __forceinline__ uint32_t chain_wave_wait_ge(const uint32_t* word, uint32_t want, int32_t* info) {
+  for (int spin = 0;; ++spin) {
+    const uint32_t v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (int32_t(v - want) >= 0 && int32_t(v - want) < 128) return v;
+    __builtin_amdgcn_s_sleep(1);
+    if ((spin & 255) == 255 &&
+        (spin >= (1 << 18) || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == STEP_TIMEOUT)) {
+      if ((threadIdx.x & 63) == 0) atomicExch(info, STEP_TIMEOUT);
+      return want;
+    }
+  }
+}
+
+// SOLVE: tile (i, c) in V (chain_load_tile) -> X = A_ic L_cc^-T stored, V = -X, and Cf = the lower blocks of X X^T
+// (distributed as potf2_body.inc's fold: rows p and 7 - p belong to waves p and p + 4).  !SOLVE: V holds a final X.
+// `steps` != NULL: L_cc is being factored by another workgroup of this launch (step word / final word as above).
+// barrier that orders LDS traffic only: __syncthreads() also waits for every global store and prefetch in flight --
+// X_j's write-through stores, the next column block's loads -- which put 2 us into each of the stream's 16 barriers
+__device__ __forceinline__ void chain_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename T, bool SOLVE>
+__device__ __forceinline__ void chain_diag_stream(const ChainArgs<T>& q, T* S, int i, int c,
+                                                  typename Mfma<T>::acc_t (&V)[8], typename Mfma<T>::acc_t (&Cf)[5],
+                                                  const uint32_t* steps, const uint32_t* final_word, uint32_t E) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  using CS = ChainStream<T>;
+  using bits_t = typename AgentBits<T>::t;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lrow = lane & 15, lk = lane >> 4;
   const int64_t ld = q.ld;
   const T* Ljj = q.A0 + int64_t(c) * TILE * ld + int64_t(c) * TILE;
   const T* dinv = q.dinv + int64_t(c) * 2048;
-#pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    constexpr int NTR = 3;
-    T tr[NTR][4];
-    const int t_lo = round * NTR, t_n = round == 0 ? NTR : 5 - NTR;
-#pragma unroll
-    for (int tq = 0; tq < NTR; ++tq) {
-      const int b = w + 8 * (t_lo + tq);
-      if (tq < t_n && b >= b_lo && b < b_hi) {
-        int bi = 0;
-        while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
-        const int bj = b - bi * (bi + 1) / 2;
-        if (bi == bj) {
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) tr[tq][qq] = dinv[bi * 256 + qq * 64 + lane];
-        } else {
-          const int voff = lk * int(ld) + lrow;
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) tr[tq][qq] = (Ljj + int64_t(bj * 16 + qq * 4) * ld + bi * 16)[voff];
-        }
-      }
-    }
-#pragma unroll
-    for (int tq = 0; tq < NTR; ++tq) {
-      const int b = w + 8 * (t_lo + tq);
-      if (tq < t_n && b >= b_lo && b < b_hi) {
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) S[b * 256 + qq * 64 + lane] = tr[tq][qq];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// column blocks [JB0, JB1) of X_ic = A_ic L_cc^-T (chain_solve's recurrence; V[kb], kb < JB0, hold -X's earlier blocks)
-template <typename T, int JB0, int JB1>
-__device__ __forceinline__ void chain_solve_cols(const ChainArgs<T>& q, const T* S, int i, int c,
-                                                 typename Mfma<T>::acc_t (&V)[8]) {
-  using M = Mfma<T>;
-  using acc_t = typename M::acc_t;
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lrow = lane & 15;
-  const int64_t ld = q.ld;
   T* bs = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + w * 16;  // wave-uniform; lane offset below
   asm volatile("" : "+s"(bs));
   const uint32_t boff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
-#pragma unroll
-  for (int jb = JB0; jb < JB1; ++jb) {
-    acc_t acc = V[jb], acc2 = acc_t{0, 0, 0, 0};
-#pragma unroll
-    for (int kb = 0; kb < jb; ++kb) {
-      const T* Lb = &S[blk(jb, kb)];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const T l = Lb[M::drow(lane, s) * 16 + lrow];
-        if (s & 1) acc2 = M::mma(l, V[kb][s], acc2);
-        else acc = M::mma(l, V[kb][s], acc);
-      }
-    }
-    acc += acc2;
-    const T* Db = &S[blk(jb, jb)];
-    acc_t y = acc_t{0, 0, 0, 0}, y2 = acc_t{0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const T d = Db[M::drow(lane, s) * 16 + lrow];
-      if (s & 1) y2 = M::mma(d, acc[s], y2);
-      else y = M::mma(d, acc[s], y);
-    }
-    y += y2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st_agent(bs + int64_t(jb * 16 + M::drow(0, r)) * ld + boff, T(y[r]));
-    V[jb] = -y;
-  }
-}
-
-// Cf += (32 columns of X, two operand blocks Va, Vb of every wave's 16 rows) x the same, transposed: the lower 36
-// blocks of the 128 x 128 product, distributed as in potf2_body.inc's fold (rows p and 7 - p: waves p and p + 4),
-// slabs exchanged through Xc ([32 k][144]: 36 KB).  The caller separates two calls on one Xc by a barrier.
-template <typename T>
-__device__ __forceinline__ void chain_fold_part(T* Xc, const typename Mfma<T>::acc_t& Va,
-                                                const typename Mfma<T>::acc_t& Vb, typename Mfma<T>::acc_t (&Cf)[5]) {
-  using M = Mfma<T>;
-  constexpr int XC_LD = 144;
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lrow = lane & 15, lk = lane >> 4;
   const int pr = w & 3, i1 = pr, i2 = 7 - pr;
   const int t0 = (w < 4) ? 0 : 5, nt = (w < 4) ? 5 : 4;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    Xc[(r * 4 + lk) * XC_LD + w * 16 + lrow] = Va[r];
-    Xc[((4 + r) * 4 + lk) * XC_LD + w * 16 + lrow] = Vb[r];
-  }
-  __syncthreads();
+  for (int tt = 0; tt < 5; ++tt) Cf[tt] = acc_t{0, 0, 0, 0};
+  // column block jn of L_cc -> registers (this wave's block (jn + w, jn); agent-scope loads: no acquire needed)
+  T tr[4];
+  auto issue_loads = [&](int jn) {
+    const int bi = jn + w;
+    if (bi < 8) {
+      const T* src = bi == jn ? dinv + jn * 256 + lane : Ljj + int64_t(jn * 16) * ld + bi * 16 + (lk * int(ld) + lrow);
+      const int64_t stride = bi == jn ? 64 : 4 * ld;
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const T* row = &Xc[(ks * 4 + lk) * XC_LD + lrow];
-    const T b1 = row[i1 * 16], b2 = row[i2 * 16];
-#pragma unroll
-    for (int tt = 0; tt < 5; ++tt) {
-      if (tt < nt) {
-        const int t = t0 + tt;
-        const bool first = t <= pr;
-        const int jj = first ? t : t - pr - 1;
-        Cf[tt] = M::mma(row[jj * 16], first ? b1 : b2, Cf[tt]);
+      for (int qq = 0; qq < 4; ++qq) {
+        const bits_t u = __hip_atomic_load(reinterpret_cast<const bits_t*>(src + qq * stride), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_memcpy(&tr[qq], &u, sizeof(T));
       }
     }
-  }
-}
-
-// tile (c, c) -= Cf in global memory (agent-scope loads, write-through stores): blocks and lanes as in the fold
-template <typename T>
-__device__ __forceinline__ void chain_apply_fold(T* A, int64_t ld, const typename Mfma<T>::acc_t (&Cf)[5]) {
-  using M = Mfma<T>;
-  using bits_t = typename AgentBits<T>::t;
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lrow = lane & 15;
-  const int pr = w & 3, i1 = pr, i2 = 7 - pr;
-  const int t0 = (w < 4) ? 0 : 5, nt = (w < 4) ? 5 : 4;
+  };
+  // column blocks of L_cc known to be in memory (wave-uniform); a reader that starts late -- its tile's last update
+  // arrives when potf2(c) is almost done -- sees several at once and runs through them with the NEXT block's loads
+  // in flight under the current block's arithmetic
+  int known = steps == nullptr ? 8 : 0;
+  bool have = false;
 #pragma unroll
-  for (int tt = 0; tt < 5; ++tt) {
-    if (tt < nt) {
-      const int t = t0 + tt;
-      const bool first = t <= pr;
-      const int ii = first ? i1 : i2, jj = first ? t : t - pr - 1;
-      T* blk0 = A + int64_t(jj * 16) * ld + ii * 16 + lrow;
-      T old[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bits_t u = __hip_atomic_load(reinterpret_cast<const bits_t*>(blk0 + int64_t(M::drow(lane, r)) * ld),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_memcpy(&old[r], &u, sizeof(T));
+  for (int j = 0; j < 8; ++j) {
+    T* Lc = S + (j & 1) * CS::LC;                 // blocks (j + s, j), s = 0 .. 7 - j; slot 0 = Linv_jj
+    T* Xc = S + 2 * CS::LC + (j & 1) * CS::XC;    // -X_j, [k][row]
+    if constexpr (SOLVE) {
+      if (!have) {
+        if (known <= j) {
+          if (j < 7) known = int(chain_wave_wait_ge(steps, E + uint32_t(j + 1), q.info) - E);
+          else { chain_wave_wait_ge(final_word, E + CHAIN_FINAL, q.info); known = 8; }
+          known = __builtin_amdgcn_readfirstlane(known);
+        }
+        issue_loads(j);
       }
+      if (j + w < 8) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) st_agent(blk0 + int64_t(M::drow(lane, r)) * ld, T(old[r] - Cf[tt][r]));
+        for (int qq = 0; qq < 4; ++qq) Lc[w * 256 + qq * 64 + lane] = tr[qq];
+      }
+      chain_lds_barrier();
+      have = j < 7 && known > j + 1;
+      if (have) issue_loads(j + 1);
+      {  // X_j = R_j Linv_jj^T
+        acc_t y = acc_t{0, 0, 0, 0}, y2 = acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const T d = Lc[M::drow(lane, s) * 16 + lrow];
+          if (s & 1) y2 = M::mma(d, V[j][s], y2);
+          else y = M::mma(d, V[j][s], y);
+        }
+        y += y2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st_agent(bs + int64_t(j * 16 + M::drow(0, r)) * ld + boff, T(y[r]));
+        V[j] = -y;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xc[(r * 4 + lk) * CS::XC_LD + w * 16 + lrow] = V[j][r];
+    if constexpr (SOLVE) {
+#pragma unroll
+      for (int jb = j + 1; jb < 8; ++jb) {  // R_jb -= X_j L_jb,j^T
+        const T* Lb = Lc + (jb - j) * 256;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) V[jb] = M::mma(Lb[M::drow(lane, s) * 16 + lrow], V[j][s], V[jb]);
+      }
+    }
+    chain_lds_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const T* row = &Xc[(ks * 4 + lk) * CS::XC_LD + lrow];
+      const T b1 = row[i1 * 16], b2 = row[i2 * 16];
+#pragma unroll
+      for (int tt = 0; tt < 5; ++tt) {
+        if (tt < nt) {
+          const int t = t0 + tt;
+          const bool first = t <= pr;
+          const int jj = first ? t : t - pr - 1;
+          Cf[tt] = M::mma(row[jj * 16], first ? b1 : b2, Cf[tt]);
+        }
+      }
     }
   }
 }
@@ -984,7 +974,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   __shared__ __attribute__((aligned(16))) T S[36 * 256];
   __shared__ T Rs[2 * 16];
   __shared__ T Dg[256];
-  __shared__ int s_task[5];
+  __shared__ int s_task[6];
   using acc_t = typename Mfma<T>::acc_t;
   if (threadIdx.x == 0) {
     // ticket -> task.  diag(cb) first in a continuation launch (a panel's very first block is factored in front of
@@ -1003,7 +993,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int r0 = nd ? k + 2 : k + 1;
       const int ns = q.R - r0 > 0 ? q.R - r0 : 0;
       const int a = k + 1, b = q.nblk - 1;  // updated columns a .. b: R - c tiles each, minus diag(k+1)'s fold
-      const int nu = a <= b ? (b - a + 1) * q.R - (a + b) * (b - a + 1) / 2 - 1 : 0;
+      // (tile (k+2, k+1), the first of them, is taken by FOUR workgroups: chain_update_full<QUARTER>)
+      const int crit = (a <= b && q.R - (a + 1) >= 1) ? 3 : 0;
+      const int nu = (a <= b ? (b - a + 1) * q.R - (a + b) * (b - a + 1) / 2 - 1 : 0) + crit;
       if (t >= nd + ns + nu) {
         t -= nd + ns + nu;
         continue;
@@ -1017,6 +1009,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int c = a; c <= b; ++c) {
         const int i0 = c == a ? c + 1 : c;
         const int cnt = q.R - i0;
+        if (c == a && crit) {
+          if (t < 4) { ti = i0; tc = c; tk = k; kind = 4; s_task[5] = t; break; }
+          t -= 3;
+        }
         if (t < cnt) { ti = i0 + t; tc = c; tk = k; kind = ti == c ? 3 : 2; break; }
         t -= cnt;
       }
@@ -1047,10 +1043,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     chain_wait<8>(q.flags + i * CHAIN_FLAG_LD + k, E + CHAIN_FINAL, q.flags + c * CHAIN_FLAG_LD + k, E + CHAIN_FINAL,
                   k > q.cb ? wt : nullptr, E + uint32_t(k), q.info);
     chain_stamp(st, 1);  // operands final, the tile carries every earlier update
-    if (kind == 2) chain_update_full<T>(q, S, i, c, k);
+    if (kind == 2) chain_update_full<T, false>(q, S, i, c, k, 0);
+    else if (kind == 4) chain_update_full<T, true>(q, S, i, c, k, __builtin_amdgcn_readfirstlane(s_task[5]));
     else chain_update_diag<T>(q, S, c, k);
     chain_stamp(st, 2);
-    chain_publish(wt, E + uint32_t(k + 1));
+    if (kind == 4) {  // the last of the four quarters publishes the tile's new state
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0 &&
+          __hip_atomic_fetch_add(q.ticket + CHAIN_QCNT_OFF + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3)
+        __hip_atomic_store(wt, E + uint32_t(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      chain_publish(wt, E + uint32_t(k + 1));
+    }
     chain_stamp(st, 3);
     return;
   }
@@ -1079,19 +1084,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int32_t pivot_base = q.pivot_base + c * TILE;
   uint32_t* frow = q.flags + c * CHAIN_FLAG_LD;
   acc_t Vx[8];  // (+-) X_{c,c-1}: row w * 16 + lrow, column jb * 16 + drow(lane, r)
-  const bool solves = c > q.cb;        // tile (c, c-1) is solved here (a continuation launch finds it final)
-  const bool in_launch = c - 1 >= 1;   // L_{c-1,c-1} is factored inside a chain launch: HALF and FINAL flags exist
-  const uint32_t* wl = q.flags + (c - 1) * CHAIN_FLAG_LD + (c - 1);
-  if (solves) {
+  acc_t Cfx[5];  // the fold X_{c,c-1} X_{c,c-1}^T, lower blocks (chain_diag_stream)
+  if (c > q.cb) {
     // tile (c, c-1) with its updates from columns cb .. c-2 of this launch (its round trip hides behind potf2(c-1))
     if (c - 1 > q.cb) chain_wait<4>(frow + (c - 1), E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
     chain_load_tile<T>(q, c, c - 1, Vx);
-    // phase 1, behind the HALF of L_{c-1,c-1} (word of the unused tile (c-2, c-1)): column blocks 0..3 of X
-    if (in_launch) chain_wait<1>(q.flags + (c - 2) * CHAIN_FLAG_LD + (c - 1), E + 1u, nullptr, 0, nullptr, 0, q.info);
-    chain_stamp(st, 8);
-    chain_stage_blocks<T>(q, S, c - 1, 0, 10);
-    __syncthreads();
-    chain_solve_cols<T, 0, 4>(q, S, c, c - 1, Vx);
+    chain_stamp(st, 1);
+    // L_{c-1,c-1} is factored inside this launch unless it is the panel's first block: follow it step by step
+    const uint32_t* steps = c - 1 >= 1 ? q.flags + (c - 2) * CHAIN_FLAG_LD + (c - 1) : nullptr;
+    chain_diag_stream<T, true>(q, S, c, c - 1, Vx, Cfx, steps, q.flags + (c - 1) * CHAIN_FLAG_LD + (c - 1), E);
+    chain_stamp(st, 3);
+    // the updates behind column c-1 and the next solves need X NOW
+    chain_publish(frow + (c - 1), E + CHAIN_FINAL, q.ticket + CHAIN_COLCNT_OFF + (c - 1));
+    chain_stamp(st, 4);
+    // tile (c, c) with the updates from columns cb .. c-2 (the one from c-1 is the fold in Cfx)
+    if (c - 1 > q.cb) chain_wait<1>(frow + c, E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
   } else {
     using M = Mfma<T>;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1101,60 +1108,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Vx[jb][r] = (Xp + int64_t(jb * 16 + M::drow(0, r)) * ld + w * 16)[xoff];
-  }
-  {
-    // first half of the fold, X[:, :64] X[:, :64]^T, 32 columns at a time through the part of S the ten staged blocks
-    // leave free, and straight onto tile (c, c) in memory -- which by now carries every update from columns
-    // cb .. c-2 as a rule (the wait is the one that used to sit in front of potf2)
-    acc_t Cf[5];
-#pragma unroll
-    for (int tt = 0; tt < 5; ++tt) Cf[tt] = acc_t{0, 0, 0, 0};
-    T* Xc = S + 10 * 256;
-    chain_fold_part<T>(Xc, Vx[0], Vx[1], Cf);
-    __syncthreads();
-    chain_fold_part<T>(Xc, Vx[2], Vx[3], Cf);
-    if (c - 1 > q.cb) chain_wait<1>(frow + c, E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
-    chain_apply_fold<T>(A, ld, Cf);
-    chain_stamp(st, 9);
-  }
-  if (solves) {
-    // phase 2, behind the FINAL flag (its barrier also ends the reads of the fold's exchange buffer)
-    if (in_launch) chain_wait<1>(wl, E + CHAIN_FINAL, nullptr, 0, nullptr, 0, q.info);
-    else __syncthreads();
-    chain_stamp(st, 1);
-    chain_stage_blocks<T>(q, S, c - 1, 10, 36);
-    __syncthreads();
-    chain_stamp(st, 2);
-    chain_solve_cols<T, 4, 8>(q, S, c, c - 1, Vx);
-    chain_stamp(st, 3);
-    // the updates behind column c-1 and the next solves need X NOW (drains this phase's stores AND phase 1's tile update)
-    chain_publish(frow + (c - 1), E + CHAIN_FINAL, q.ticket + CHAIN_COLCNT_OFF + (c - 1));
-    chain_stamp(st, 4);
-  }
-  if (!(solves && in_launch)) {
-    // no acquire since the tile update above: drain it and drop this compute unit's L1 before potf2 reads the tile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
+    chain_diag_stream<T, false>(q, S, c, c - 1, Vx, Cfx, nullptr, nullptr, E);
+    __syncthreads();  // (every wave is done with the slabs in S)
   }
   chain_stamp(st, 5);
   {
     constexpr bool FOLD = true;
-    uint32_t* half_word = q.flags + (c - 1) * CHAIN_FLAG_LD + c;  // (c >= 1 here; tile (c-1, c) does not exist)
+    uint32_t* step_word = q.flags + (c - 1) * CHAIN_FLAG_LD + c;  // (c >= 1 here; tile (c-1, c) does not exist)
 #define POTF2_ST(p, v) st_agent((p), T(v))
 #define POTF2_V_IN_REGS Vx
-#define POTF2_FOLD_H0 1
-#define POTF2_PRE_SYNC(kb) do { if ((kb) == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define POTF2_CF_IN_REGS Cfx
+#define POTF2_PRE_SYNC(kb) do { if ((kb) >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
 #define POTF2_POST_SYNC(kb)                                                                            \
   do {                                                                                                \
-    if ((kb) == 4 && threadIdx.x == 0)                                                                \
-      __hip_atomic_store(half_word, E + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              \
+    if ((kb) >= 1 && threadIdx.x == 0)                                                                \
+      __hip_atomic_store(step_word, E + uint32_t(kb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    \
   } while (0)
 #include "potf2_body.inc"
 #undef POTF2_POST_SYNC
 #undef POTF2_PRE_SYNC
-#undef POTF2_FOLD_H0
+#undef POTF2_CF_IN_REGS
 #undef POTF2_V_IN_REGS
 #undef POTF2_ST
   }
@@ -1930,7 +1903,8 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
   for (int64_t k = cb; k < ce; ++k) {  // the same closed form as the kernel's ticket decode
     const int64_t nd = k + 1 < ce ? 1 : 0, r0 = nd ? k + 2 : k + 1;
     const int64_t a = k + 1, b = nblk - 1;
-    tasks += nd + std::max<int64_t>(0, R - r0) + (a <= b ? (b - a + 1) * R - (a + b) * (b - a + 1) / 2 - 1 : 0);
+    tasks += nd + std::max<int64_t>(0, R - r0) + (a <= b ? (b - a + 1) * R - (a + b) * (b - a + 1) / 2 - 1 : 0) +
+             ((a <= b && R - (a + 1) >= 1) ? 3 : 0);
   }
   if (tasks == 0) {  // a one-block panel: potf2 in front was all of it; the pollers' event still marks this point
     if (counters_ready != nullptr) TGP_TRY(ev_record(ctx, counters_ready, st));
@@ -1953,7 +1927,7 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
     ctx->chain_stamp_base += tasks;
   }
   // ticket counter + the block columns' counts of final tiles: zero in front of every launch
-  TGP_HIP_TRY(hipMemsetAsync(ctx->d_chain_ticket, 0, size_t(CHAIN_COLCNT_OFF + CHAIN_FLAG_LD) * sizeof(int32_t), st));
+  TGP_HIP_TRY(hipMemsetAsync(ctx->d_chain_ticket, 0, size_t(CHAIN_TICKET_WORDS) * sizeof(int32_t), st));
   // pollers on other streams start behind THIS point: counters zeroed, the launch itself not awaited
   if (counters_ready != nullptr) TGP_TRY(ev_record(ctx, counters_ready, st));
   // one task per workgroup; `chain_lds_pad` bytes of dynamic LDS nobody uses keep a SECOND chain workgroup off the
