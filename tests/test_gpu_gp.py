@@ -518,6 +518,49 @@ def test_potf2_stress_n3000(lookahead, fused_step):
             ctx.set_option(k, v)
 
 
+def test_evaluations_in_flight_on_separate_contexts_do_not_interfere():
+    """Three host threads, one context + solver + matrix each, evaluate concurrently on the one GPU (what a sampler with
+    independent chains does): every value must be the one a lone evaluation of the same hyper-parameter point gives, bit
+    for bit -- the persistent chain's state words, tickets and counters are per context, its launches of different
+    contexts share the chip (scripts/two_in_flight.py is the throughput version of this)."""
+    import threading
+
+    from tinygp_amd import _ffi
+
+    n, reps, T = 2048, 12, 3
+    X, y = _cases.synthetic.make_inputs(n, 1)
+
+    def kernel_at(step, who):
+        u = ((step * 7 + who * 3) % 11 - 5) / 5.0
+        return (1.5 * (1 + 0.02 * u))**2 * kernels.ExpSquared(2.5 * (1 + 0.03 * u))
+
+    solvers = []
+    for who in range(T):
+        s = DirectSolver(kernel_at(-1, who), X, noise.Diagonal(np.full(n, 0.01)), ctx=_ffi.Ctx(device=0))
+        s.set_residual(y)
+        solvers.append(s)
+    out = [[None] * reps for _ in range(T)]
+    go = threading.Barrier(T)
+
+    def work(who):
+        go.wait()
+        for k in range(reps):
+            out[who][k] = solvers[who].factor_log_probability(None, kernel_at(k, who))
+
+    th = [threading.Thread(target=work, args=(w,)) for w in range(T)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    lone = DirectSolver(kernel_at(-1, 0), X, noise.Diagonal(np.full(n, 0.01)))
+    lone.set_residual(y)
+    for who in range(T):
+        assert solvers[who].info == 0
+        for k in range(reps):
+            assert out[who][k] == lone.factor_log_probability(None, kernel_at(k, who)), (who, k)
+        solvers[who].close()
+
+
 def _factor_property_checks(gp, X, k, diag, seed):
     """Size-independent properties: (i) L^-T L^-1 (K z) == z with K z from the fused
     kernel mat-vec, which never touches the factor; (ii) L^-1 (L z) == z."""
