@@ -4,9 +4,10 @@
 
   python scripts/chain_timeline.py [N ...]
 
-diag task stamps:   0 start | 1 tile (c,c-1) in registers | 3 X_{c,c-1} solved and stored, fold accumulated (column block by
-                    column block behind the step flags of potf2(c-1)) | 4 X published | 5 tile (c,c) ready, potf2 starts |
-                    6 factored | 7 L_cc published
+xsolve task stamps: 0 start | 1 tile (c,c-1) in registers | 3 X_{c,c-1} solved and stored (column block by column block behind
+                    the step flags of potf2(c-1)) | 4 X published
+diag task stamps:   0 start | 3 fold of X_{c,c-1} accumulated (16 columns at a time behind xsolve(c)'s counter) |
+                    5 tile (c,c) ready, potf2 starts | 6 factored | 7 L_cc published
 solve task stamps:  0 start | 1 tile and L_cc ready | 2 staged | 3 solved | 4 published
 update task stamps: 0 start | 1 operands and tile ready | 2 computed, stores issued | 3 published"""
 import ctypes as C
@@ -43,14 +44,17 @@ for n in [int(a) for a in sys.argv[1:]] or [1024, 4096]:
     diag = recs[recs[:, 0] == 1]
     diag = diag[np.lexsort((diag[:, 2], diag[:, 3] & 255))]
     prev_pub = None
-    print("launch col |  start   tile  streamed   Xpub potf2in factored published | "
+    xs = {int(r[2]): r for r in recs[recs[:, 0] == 5]}
+    print("launch col | xsolve: start   tile streamed   Xpub | diag: start  folded potf2in factored published | "
           "prev.published->potf2  potf2  period")
     for r in diag:
         s_ = [us(v) if v else float("nan") for v in r[4:14]]
+        x = xs.get(int(r[2]))
+        x_ = [us(v) if v else float("nan") for v in x[4:14]] if x is not None else [float("nan")] * 10
         per = s_[7] - prev_pub if prev_pub is not None else float("nan")
         gap = s_[5] - prev_pub if prev_pub is not None else float("nan")
-        print(f"{r[3] & 255:4d} {r[2]:4d}   | {s_[0]:6.1f} {s_[1]:6.1f} {s_[3]:8.1f} {s_[4]:6.1f} {s_[5]:7.1f} {s_[6]:8.1f} "
-              f"{s_[7]:9.1f} | {gap:12.1f} {s_[6] - s_[5]:14.1f}  {per:7.1f}")
+        print(f"{r[3] & 255:4d} {r[2]:4d}   | {x_[0]:13.1f} {x_[1]:6.1f} {x_[3]:8.1f} {x_[4]:6.1f} | {s_[0]:11.1f} {s_[3]:7.1f} "
+              f"{s_[5]:7.1f} {s_[6]:8.1f} {s_[7]:9.1f} | {gap:12.1f} {s_[6] - s_[5]:14.1f}  {per:7.1f}")
         prev_pub = s_[7]
     for kind, name, ph in ((0, "solve", ("wait", "stage", "solve", "publish")), (2, "update", ("wait", "compute", "publish")),
                            (4, "update of tile (k+2, k+1), a quarter per task", ("wait", "compute", "publish")),

@@ -418,7 +418,8 @@ constexpr int CHAIN_FLAG_LD = 64;  // state word of tile (i, c) of the panel: fl
 constexpr uint32_t CHAIN_FINAL = 127;
 constexpr int CHAIN_COLCNT_OFF = 16;  // d_chain_ticket: [0] the ticket counter, [16 + c] final tiles of block column c,
 constexpr int CHAIN_QCNT_OFF = 96;    // [96 + k] finished quarters of the update of tile (k+2, k+1) from column k
-constexpr int CHAIN_TICKET_WORDS = CHAIN_QCNT_OFF + CHAIN_FLAG_LD;
+constexpr int CHAIN_XSTEP_OFF = 160;  // [160 + c] column blocks of X_{c,c-1} complete in memory (0..8): xsolve(c) -> diag(c)
+constexpr int CHAIN_TICKET_WORDS = CHAIN_XSTEP_OFF + CHAIN_FLAG_LD;
 
 template <typename T>
 struct ChainArgs {
@@ -853,19 +854,34 @@ __device__ __forceinline__ uint32_t chain_wave_wait_ge(const uint32_t* word, uin
   }
 }
 
-// SOLVE: tile (i, c) in V (chain_load_tile) -> X = A_ic L_cc^-T stored, V = -X, and Cf = the lower blocks of X X^T
-// (distributed as potf2_body.inc's fold: rows p and 7 - p belong to waves p and p + 4).  !SOLVE: V holds a final X.
-// `steps` != NULL: L_cc is being factored by another workgroup of this launch (step word / final word as above).
-// barrier that orders LDS traffic only: __syncthreads() also waits for every global store and prefetch in flight --
-// X_j's write-through stores, the next column block's loads -- which put 2 us into each of the stream's 16 barriers
+// barrier that orders LDS traffic only (the streams keep global stores and the next block's loads in flight across it)
 __device__ __forceinline__ void chain_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename T, bool SOLVE>
-__device__ __forceinline__ void chain_diag_stream(const ChainArgs<T>& q, T* S, int i, int c,
-                                                  typename Mfma<T>::acc_t (&V)[8], typename Mfma<T>::acc_t (&Cf)[5],
-                                                  const uint32_t* steps, const uint32_t* final_word, uint32_t E) {
+// wave-level wait until the counter *p (zeroed per launch) has reached `want`; returns what it saw
+__device__ __forceinline__ int chain_wave_wait_count(const int32_t* p, int want, int32_t* info) {
+  for (int spin = 0;; ++spin) {
+    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v >= want) return v;
+    __builtin_amdgcn_s_sleep(1);
+    if ((spin & 255) == 255 &&
+        (spin >= (1 << 18) || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == STEP_TIMEOUT)) {
+      if ((threadIdx.x & 63) == 0) atomicExch(info, STEP_TIMEOUT);
+      return want;
+    }
+  }
+}
+
+// xsolve(c'): tile (i, c) = (c', c'-1) in V (chain_load_tile) -> X = A_ic L_cc^-T, streamed behind potf2(c)'s step word
+// (`steps` != NULL: L_cc is being factored by another workgroup of this launch) and stored column block by column
+// block; *xstep = number of column blocks of X complete in memory (published one step behind: the stores of block
+// j-1 have had step j's loads and barrier to drain).  The fold of X is diag(c')'s work -- on ANOTHER compute unit: solve
+// and fold together are 288 MFMAs per wave at the 16x16x4 form's rate, 26 us on one unit wherever they start.
+template <typename T>
+__device__ __forceinline__ void chain_xsolve_stream(const ChainArgs<T>& q, T* S, int i, int c,
+                                                    typename Mfma<T>::acc_t (&V)[8], const uint32_t* steps,
+                                                    const uint32_t* final_word, uint32_t E, int32_t* xstep) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   using CS = ChainStream<T>;
@@ -879,10 +895,6 @@ __device__ __forceinline__ void chain_diag_stream(const ChainArgs<T>& q, T* S, i
   T* bs = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + w * 16;  // wave-uniform; lane offset below
   asm volatile("" : "+s"(bs));
   const uint32_t boff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
-  const int pr = w & 3, i1 = pr, i2 = 7 - pr;
-  const int t0 = (w < 4) ? 0 : 5, nt = (w < 4) ? 5 : 4;
-#pragma unroll
-  for (int tt = 0; tt < 5; ++tt) Cf[tt] = acc_t{0, 0, 0, 0};
   // column block jn of L_cc -> registers (this wave's block (jn + w, jn); agent-scope loads: no acquire needed)
   T tr[4];
   auto issue_loads = [&](int jn) {
@@ -898,56 +910,95 @@ __device__ __forceinline__ void chain_diag_stream(const ChainArgs<T>& q, T* S, i
       }
     }
   };
-  // column blocks of L_cc known to be in memory (wave-uniform); a reader that starts late -- its tile's last update
-  // arrives when potf2(c) is almost done -- sees several at once and runs through them with the NEXT block's loads
-  // in flight under the current block's arithmetic
+  // column blocks of L_cc known to be in memory (wave-uniform); a reader that starts late sees several at once and
+  // runs through them with the NEXT block's loads in flight under the current block's arithmetic
   int known = steps == nullptr ? 8 : 0;
   bool have = false;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    T* Lc = S + (j & 1) * CS::LC;                 // blocks (j + s, j), s = 0 .. 7 - j; slot 0 = Linv_jj
-    T* Xc = S + 2 * CS::LC + (j & 1) * CS::XC;    // -X_j, [k][row]
-    if constexpr (SOLVE) {
-      if (!have) {
-        if (known <= j) {
-          if (j < 7) known = int(chain_wave_wait_ge(steps, E + uint32_t(j + 1), q.info) - E);
-          else { chain_wave_wait_ge(final_word, E + CHAIN_FINAL, q.info); known = 8; }
-          known = __builtin_amdgcn_readfirstlane(known);
-        }
-        issue_loads(j);
+    T* Lc = S + (j & 1) * CS::LC;  // blocks (j + s, j), s = 0 .. 7 - j; slot 0 = Linv_jj
+    if (!have) {
+      if (known <= j) {
+        if (j < 7) known = int(chain_wave_wait_ge(steps, E + uint32_t(j + 1), q.info) - E);
+        else { chain_wave_wait_ge(final_word, E + CHAIN_FINAL, q.info); known = 8; }
+        known = __builtin_amdgcn_readfirstlane(known);
       }
-      if (j + w < 8) {
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) Lc[w * 256 + qq * 64 + lane] = tr[qq];
-      }
-      chain_lds_barrier();
-      have = j < 7 && known > j + 1;
-      if (have) issue_loads(j + 1);
-      {  // X_j = R_j Linv_jj^T
-        acc_t y = acc_t{0, 0, 0, 0}, y2 = acc_t{0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const T d = Lc[M::drow(lane, s) * 16 + lrow];
-          if (s & 1) y2 = M::mma(d, V[j][s], y2);
-          else y = M::mma(d, V[j][s], y);
-        }
-        y += y2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st_agent(bs + int64_t(j * 16 + M::drow(0, r)) * ld + boff, T(y[r]));
-        V[j] = -y;
-      }
+      issue_loads(j);
     }
+    if (j + w < 8) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Xc[(r * 4 + lk) * CS::XC_LD + w * 16 + lrow] = V[j][r];
-    if constexpr (SOLVE) {
-#pragma unroll
-      for (int jb = j + 1; jb < 8; ++jb) {  // R_jb -= X_j L_jb,j^T
-        const T* Lb = Lc + (jb - j) * 256;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) V[jb] = M::mma(Lb[M::drow(lane, s) * 16 + lrow], V[j][s], V[jb]);
-      }
+      for (int qq = 0; qq < 4; ++qq) Lc[w * 256 + qq * 64 + lane] = tr[qq];
     }
+    if (j >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of X_{j-1}, stored a step ago
     chain_lds_barrier();
+    if (j >= 1 && threadIdx.x == 0) __hip_atomic_store(xstep, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    have = j < 7 && known > j + 1;
+    if (have) issue_loads(j + 1);
+    {  // X_j = R_j Linv_jj^T
+      acc_t y = acc_t{0, 0, 0, 0}, y2 = acc_t{0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const T d = Lc[M::drow(lane, s) * 16 + lrow];
+        if (s & 1) y2 = M::mma(d, V[j][s], y2);
+        else y = M::mma(d, V[j][s], y);
+      }
+      y += y2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st_agent(bs + int64_t(j * 16 + M::drow(0, r)) * ld + boff, T(y[r]));
+      V[j] = -y;
+    }
+#pragma unroll
+    for (int jb = j + 1; jb < 8; ++jb) {  // R_jb -= X_j L_jb,j^T
+      const T* Lb = Lc + (jb - j) * 256;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) V[jb] = M::mma(Lb[M::drow(lane, s) * 16 + lrow], V[j][s], V[jb]);
+    }
+  }
+}
+
+// diag(c'): Cf = the lower blocks of X X^T for X = tile (i, c) = (c', c'-1) (distributed as potf2_body.inc's fold: rows p
+// and 7 - p belong to waves p and p + 4), 16 columns at a time behind xsolve(c')'s counter (`xstep` == NULL: X is final),
+// slabs loaded straight into the exchange layout (agent-scope loads) and exchanged through LDS
+template <typename T>
+__device__ __forceinline__ void chain_fold_stream(const ChainArgs<T>& q, T* S, int i, int c,
+                                                  typename Mfma<T>::acc_t (&Cf)[5], const int32_t* xstep) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  using CS = ChainStream<T>;
+  using bits_t = typename AgentBits<T>::t;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lrow = lane & 15, lk = lane >> 4;
+  const int64_t ld = q.ld;
+  const T* bu = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + w * 16;  // wave-uniform; lane offset below
+  const uint32_t boff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
+  const int pr = w & 3, i1 = pr, i2 = 7 - pr;
+  const int t0 = (w < 4) ? 0 : 5, nt = (w < 4) ? 5 : 4;
+#pragma unroll
+  for (int tt = 0; tt < 5; ++tt) Cf[tt] = acc_t{0, 0, 0, 0};
+  T xr[4];  // element (row w * 16 + lrow, column jn * 16 + drow(lane, r))
+  auto issue_loads = [&](int jn) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bits_t u = __hip_atomic_load(reinterpret_cast<const bits_t*>(bu + int64_t(jn * 16 + M::drow(0, r)) * ld + boff),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_memcpy(&xr[r], &u, sizeof(T));
+    }
+  };
+  int known = xstep == nullptr ? 8 : 0;
+  bool have = false;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    T* Xc = S + (j & 1) * CS::XC;  // X_j, [k][row]
+    if (!have) {
+      if (known <= j) known = __builtin_amdgcn_readfirstlane(chain_wave_wait_count(xstep, j + 1, q.info));
+      issue_loads(j);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xc[(r * 4 + lk) * CS::XC_LD + w * 16 + lrow] = xr[r];
+    chain_lds_barrier();
+    have = j < 7 && known > j + 1;
+    if (have) issue_loads(j + 1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const T* row = &Xc[(ks * 4 + lk) * CS::XC_LD + lrow];
@@ -996,13 +1047,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       // (tile (k+2, k+1), the first of them, is taken by FOUR workgroups: chain_update_full<QUARTER>)
       const int crit = (a <= b && q.R - (a + 1) >= 1) ? 3 : 0;
       const int nu = (a <= b ? (b - a + 1) * q.R - (a + b) * (b - a + 1) / 2 - 1 : 0) + crit;
-      if (t >= nd + ns + nu) {
-        t -= nd + ns + nu;
+      if (t >= 2 * nd + ns + nu) {
+        t -= 2 * nd + ns + nu;
         continue;
       }
-      if (nd) {
-        if (t == 0) { kind = 1; tc = k + 1; break; }
-        --t;
+      if (nd) {  // xsolve(k+1) in front of diag(k+1): the diagonal task follows the solve of its tile
+        if (t == 0) { kind = 5; tc = k + 1; break; }
+        if (t == 1) { kind = 1; tc = k + 1; break; }
+        t -= 2;
       }
       if (t < ns) { kind = 0; ti = r0 + t; tc = k; break; }
       t -= ns;
@@ -1037,7 +1089,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   const uint32_t E = q.epoch32;
   const bool head_final = q.cb == 0;  // L_00 was factored in front of the launch
-  if (kind >= 2) {  // ---- update(i, c, k) ----
+  if (kind >= 2 && kind <= 4) {  // ---- update(i, c, k) ----
     const int i = ti, c = tc, k = tk;
     uint32_t* wt = q.flags + i * CHAIN_FLAG_LD + c;
     chain_wait<8>(q.flags + i * CHAIN_FLAG_LD + k, E + CHAIN_FINAL, q.flags + c * CHAIN_FLAG_LD + k, E + CHAIN_FINAL,
@@ -1083,34 +1135,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   int32_t* info = q.info;
   const int32_t pivot_base = q.pivot_base + c * TILE;
   uint32_t* frow = q.flags + c * CHAIN_FLAG_LD;
-  acc_t Vx[8];  // (+-) X_{c,c-1}: row w * 16 + lrow, column jb * 16 + drow(lane, r)
-  acc_t Cfx[5];  // the fold X_{c,c-1} X_{c,c-1}^T, lower blocks (chain_diag_stream)
-  if (c > q.cb) {
-    // tile (c, c-1) with its updates from columns cb .. c-2 of this launch (its round trip hides behind potf2(c-1))
+  if (kind == 5) {  // ---- xsolve(c): tile (c, c-1) solved column block by column block behind potf2(c-1) ----
+    acc_t Vx[8];  // the residual of tile (c, c-1): row w * 16 + lrow, column jb * 16 + drow(lane, r)
+    // the tile with its updates from columns cb .. c-2 of this launch (the last one is the four-way split update)
     if (c - 1 > q.cb) chain_wait<4>(frow + (c - 1), E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
     chain_load_tile<T>(q, c, c - 1, Vx);
     chain_stamp(st, 1);
     // L_{c-1,c-1} is factored inside this launch unless it is the panel's first block: follow it step by step
     const uint32_t* steps = c - 1 >= 1 ? q.flags + (c - 2) * CHAIN_FLAG_LD + (c - 1) : nullptr;
-    chain_diag_stream<T, true>(q, S, c, c - 1, Vx, Cfx, steps, q.flags + (c - 1) * CHAIN_FLAG_LD + (c - 1), E);
+    int32_t* xstep = q.ticket + CHAIN_XSTEP_OFF + c;
+    chain_xsolve_stream<T>(q, S, c, c - 1, Vx, steps, q.flags + (c - 1) * CHAIN_FLAG_LD + (c - 1), E, xstep);
     chain_stamp(st, 3);
-    // the updates behind column c-1 and the next solves need X NOW
+    // the updates behind column c-1, the next solves and diag(c)'s last fold step need X NOW
     chain_publish(frow + (c - 1), E + CHAIN_FINAL, q.ticket + CHAIN_COLCNT_OFF + (c - 1));
+    if (threadIdx.x == 0) __hip_atomic_store(xstep, 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     chain_stamp(st, 4);
-    // tile (c, c) with the updates from columns cb .. c-2 (the one from c-1 is the fold in Cfx)
-    if (c - 1 > q.cb) chain_wait<1>(frow + c, E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
-  } else {
-    using M = Mfma<T>;
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const T* Xp = A - int64_t(TILE) * ld;  // tile (c, c-1), final since the previous launch
-    const int xoff = M::drow(lane, 0) * int(ld) + (lane & 15);
-#pragma unroll
-    for (int jb = 0; jb < 8; ++jb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Vx[jb][r] = (Xp + int64_t(jb * 16 + M::drow(0, r)) * ld + w * 16)[xoff];
-    chain_diag_stream<T, false>(q, S, c, c - 1, Vx, Cfx, nullptr, nullptr, E);
-    __syncthreads();  // (every wave is done with the slabs in S)
+    return;
   }
+  acc_t Vx[8];   // (only named by the fold code potf2_body.inc skips: POTF2_CF_IN_REGS)
+  acc_t Cfx[5];  // the fold X_{c,c-1} X_{c,c-1}^T, lower blocks (chain_fold_stream)
+  chain_fold_stream<T>(q, S, c, c - 1, Cfx, c > q.cb ? q.ticket + CHAIN_XSTEP_OFF + c : nullptr);
+  chain_stamp(st, 3);
+  // tile (c, c) with the updates from columns cb .. c-2 (the one from c-1 is the fold in Cfx)
+  if (c - 1 > q.cb) chain_wait<1>(frow + c, E + uint32_t(c - 1), nullptr, 0, nullptr, 0, q.info);
+  else __syncthreads();  // (every wave is done with the slabs in S)
   chain_stamp(st, 5);
   {
     constexpr bool FOLD = true;
@@ -1903,7 +1951,7 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
   for (int64_t k = cb; k < ce; ++k) {  // the same closed form as the kernel's ticket decode
     const int64_t nd = k + 1 < ce ? 1 : 0, r0 = nd ? k + 2 : k + 1;
     const int64_t a = k + 1, b = nblk - 1;
-    tasks += nd + std::max<int64_t>(0, R - r0) + (a <= b ? (b - a + 1) * R - (a + b) * (b - a + 1) / 2 - 1 : 0) +
+    tasks += 2 * nd + std::max<int64_t>(0, R - r0) + (a <= b ? (b - a + 1) * R - (a + b) * (b - a + 1) / 2 - 1 : 0) +
              ((a <= b && R - (a + 1) >= 1) ? 3 : 0);
   }
   if (tasks == 0) {  // a one-block panel: potf2 in front was all of it; the pollers' event still marks this point
