@@ -1029,11 +1029,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   using acc_t = typename Mfma<T>::acc_t;
   if (threadIdx.x == 0) {
     // ticket -> task.  diag(cb) first in a continuation launch (a panel's very first block is factored in front of
-    // the launch); then per column k: diag(k+1) [if in range], solve(r0.., k) with r0 = k + 2 while diag(k+1) owns
-    // tile (k+1, k), update(i, c, k) for c = k+1 .. nblk-1 and i = c .. R-1 without (k+1, k+1, k) = diag(k+1)'s fold
+    // the launch); then per column k: xsolve(k+1), diag(k+1) [if in range], solve(r0.., k) with r0 = k + 2 while
+    // xsolve(k+1) owns tile (k+1, k), update(i, c, k) for c = k+1 .. nblk-1 and i = c .. R-1 without (k+1, k+1, k) =
+    // diag(k+1)'s fold -- the first of them, tile (k+2, k+1), as four quarter tasks
     int t = atomicAdd(q.ticket, 1);
     s_task[4] = t;
-    int kind = -1, ti = 0, tc = 0, tk = 0;  // kind: 0 solve, 1 diag, 2 update, 3 update of a diagonal tile
+    // kind: 0 solve, 1 diag, 2 update, 3 update of a diagonal tile, 4 a quarter of an update, 5 xsolve
+    int kind = -1, ti = 0, tc = 0, tk = 0;
     if (q.cb > 0) {
       if (t == 0) { kind = 1; tc = q.cb; }
       --t;
