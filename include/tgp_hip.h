@@ -34,7 +34,7 @@ extern "C" {
 
 /* bumped whenever an exported signature or option changes; the Python binding refuses another version
  * (round 2 -> 3: tgp_trace_factor gained nb_wide_rows, ~15 entry points added, "potf2_sync" removed;
- *  round 3 -> 4: tgp_chain_stamps, the resident-factor solves of the block-column driver -- tgp_dist_fwd_block,
+ *  round 3 -> 4: tgp_chain_stamps, tgp_chain_task, the resident-factor solves of the block-column driver -- tgp_dist_fwd_block,
  *  _bwd_block, _trmv_partial, _cross_cov, _colsumsq_owned, _gram_owned -- and tgp_dist_abort added) */
 #define TGP_ABI_VERSION 4
 
@@ -429,6 +429,14 @@ int tgp_trace_factor(int64_t n_pad, const char* options, int32_t fused, int64_t*
  * 100 MHz real-time counter (0 = phase not run), copied to `out` (at most cap_tasks tasks; *n_tasks = recorded).
  * Phases: scripts/chain_timeline.py. */
 int tgp_chain_stamps(tgp_ctx* ctx, int64_t* out, int64_t cap_tasks, int64_t* n_tasks);
+
+/* Test hook, host only (no device, no context): the persistent chain's ticket -> task map (csrc/chain_tasks.h -- the
+ * text the kernel decodes its ticket with and the launch is sized by) for a launch over block columns [cb, ce) of a
+ * panel with R row tiles and nblk block columns.  *n_tasks = tickets of the launch; ticket >= 0: out5 = {kind, row
+ * tile, block column, source column, part} with kind 0 solve | 1 diag | 2 update | 3 update of a diagonal tile |
+ * 4 a quarter of an update | 5 xsolve.  tests/test_chain_tasks.py checks on the CPU that every task of a launch
+ * exists exactly once and waits for EARLIER tickets only. */
+int tgp_chain_task(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t ticket, int32_t* out5, int64_t* n_tasks);
 
 #ifdef __cplusplus
 }

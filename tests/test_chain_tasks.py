@@ -1,0 +1,110 @@
+"""The persistent panel chain hands out ONE task per workgroup by a ticket counter, and a workgroup polls device flags
+for its inputs: that is deadlock-free without any co-residency guarantee only if every task waits for tasks with EARLIER
+tickets (a workgroup that holds ticket t is running or done once ticket t + 1 is taken).  This test enumerates every
+ticket of a launch through the library's own map (csrc/chain_tasks.h via tgp_chain_task: the text the kernel decodes
+its ticket with and launch_chain sizes the grid by) and checks, on the CPU,
+  * that the tasks of the launch are exactly the ones the factorisation needs, each once;
+  * that every wait of chain_kernel (csrc/chol.hip) is for an earlier ticket."""
+import ctypes as C
+
+import pytest
+
+from tinygp_amd import _ffi
+
+PARTS = 4  # CHAIN_CRIT_PARTS
+
+
+def tasks_of(R, nblk, cb, ce):
+    lib = _ffi.lib()
+    n = C.c_int64()
+    _ffi.check(lib.tgp_chain_task(R, nblk, cb, ce, -1, None, C.byref(n)), "tgp_chain_task")
+    out = (C.c_int32 * 5)()
+    tasks = []
+    for t in range(n.value):
+        _ffi.check(lib.tgp_chain_task(R, nblk, cb, ce, t, out, None), "tgp_chain_task")
+        tasks.append(tuple(out))
+    return tasks
+
+
+def expected(R, nblk, cb, ce):
+    """What a launch over block columns [cb, ce) has to do (kind, i, c, k, part)."""
+    want = []
+    if cb > 0:
+        want.append((1, 0, cb, 0, 0))  # diag(cb): tile (cb, cb-1) is final since the launch before
+    for k in range(cb, ce):
+        factored_here = k + 1 < ce
+        if factored_here:
+            want += [(5, 0, k + 1, 0, 0), (1, 0, k + 1, 0, 0)]
+        for i in range(k + 1, R):  # column k: tile (k+1, k) belongs to xsolve(k+1) when that exists
+            if not (factored_here and i == k + 1):
+                want.append((0, i, k, 0, 0))
+        for c in range(k + 1, nblk):  # right-looking: column k -> every tile right of it
+            for i in range(c, R):
+                if (i, c) == (k + 1, k + 1):
+                    continue  # the fold inside diag(k+1)
+                if i == c:
+                    want.append((3, i, c, k, 0))
+                elif (i, c) == (k + 2, k + 1):
+                    want += [(4, i, c, k, p) for p in range(PARTS)]
+                else:
+                    want.append((2, i, c, k, 0))
+    return want
+
+
+SHAPES = [(1, 1, 0, 1), (2, 1, 0, 1), (2, 2, 0, 2), (3, 2, 0, 2), (8, 8, 0, 8), (12, 8, 0, 8), (32, 32, 0, 32), (40, 8, 0, 5),
+          (40, 8, 5, 8), (9, 8, 3, 4), (64, 64, 0, 64), (70, 64, 60, 64), (128, 8, 0, 8), (16, 8, 7, 8)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"R{r}-nblk{n}-cols{a}to{b}" for r, n, a, b in SHAPES])
+def test_every_task_once_and_waits_only_for_earlier_tickets(shape):
+    R, nblk, cb, ce = shape
+    tasks = tasks_of(R, nblk, cb, ce)
+    assert sorted(tasks) == sorted(expected(R, nblk, cb, ce))
+    assert len(set(tasks)) == len(tasks)
+    at = {t: n for n, t in enumerate(tasks)}
+
+    def final_of_tile(i, c):
+        """ticket of the task that makes tile (i, c), i > c, final (None: final before the launch)"""
+        if c < cb:
+            return None
+        if i == c + 1 and (5, 0, i, 0, 0) in at:
+            return at[(5, 0, i, 0, 0)]
+        return at[(0, i, c, 0, 0)]
+
+    def factor_of(c):
+        """ticket of diag(c) (None: factored in front of the launch / by an earlier one)"""
+        return at.get((1, 0, c, 0, 0))
+
+    def updates_of(i, c, upto):
+        """tickets of the updates of tile (i, c) from columns cb .. upto-1 of this launch"""
+        out = []
+        for k in range(cb, upto):
+            if i == c:
+                out.append(at[(3, i, c, k, 0)])
+            elif (4, i, c, k, 0) in at:
+                out += [at[(4, i, c, k, p)] for p in range(PARTS)]
+            else:
+                out.append(at[(2, i, c, k, 0)])
+        return out
+
+    for task, me in at.items():
+        kind, i, c, k, part = task
+        deps = []
+        if kind == 0:  # solve(i, c): the tile with every update from this launch, L_cc
+            deps = updates_of(i, c, c) + [factor_of(c)]
+        elif kind == 5:  # xsolve(c): tile (c, c-1) with its updates, the progress of potf2(c-1)
+            deps = updates_of(c, c - 1, c - 1) + [factor_of(c - 1)]
+        elif kind == 1:  # diag(c): the solve of tile (c, c-1) (its fold), tile (c, c) with its updates
+            deps = ([at[(5, 0, c, 0, 0)]] if (5, 0, c, 0, 0) in at else []) + updates_of(c, c, c - 1)
+        else:  # update(i, c, k): both operands final, the tile carries every earlier update
+            deps = [final_of_tile(i, k), final_of_tile(c, k)] + updates_of(i, c, k)
+        late = [d for d in deps if d is not None and d >= me]
+        assert not late, (task, me, late)
+
+
+def test_chain_task_rejects_bad_shapes():
+    lib = _ffi.lib()
+    n = C.c_int64()
+    assert lib.tgp_chain_task(4, 8, 0, 8, -1, None, C.byref(n)) != 0   # more block columns than row tiles
+    assert lib.tgp_chain_task(8, 8, 3, 3, -1, None, C.byref(n)) != 0   # empty column range
+    assert lib.tgp_chain_task(8, 8, 0, 8, 10**6, (C.c_int32 * 5)(), None) != 0

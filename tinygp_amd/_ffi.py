@@ -100,6 +100,7 @@ SIGNATURES = {
     "tgp_solver_timings": [_vp, _pdbl, _int],
     "tgp_trace_factor": [_i64, C.c_char_p, _i32, _pi64, _i64, _pi64],
     "tgp_chain_stamps": [_vp, _pi64, _i64, _pi64],
+    "tgp_chain_task": [_i64, _i64, _i64, _i64, _i64, _pi32, _pi64],
     "tgp_dist_slot_elems": [_i64, _i64],
     "tgp_dist_create": [_vp, _int, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _pvp],
     "tgp_dist_destroy": [_vp],

@@ -6,6 +6,8 @@
 #include <string>
 
 #include "tgp_common.h"
+#define CHAIN_HD __host__ __device__
+#include "chain_tasks.h"
 
 namespace tgp {
 
@@ -1123,6 +1125,25 @@ int tgp_solver_timings(tgp_solver* s, double* ms, int n) {
   SOLVER_GUARD(s);
   TGP_ARG_CHECK(ms != nullptr && n >= 0, "bad argument");
   for (int i = 0; i < n && i < 8; ++i) ms[i] = s->ms[i];
+  return TGP_OK;
+}
+
+// the chain kernel's ticket -> task map on the host (chain_tasks.h): ticket < 0 -> *n_tasks only
+int tgp_chain_task(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t ticket, int32_t* out5, int64_t* n_tasks) {
+  if (!(R >= 1 && cb >= 0 && cb < ce && ce <= nblk && nblk <= 64 && nblk <= R && R <= (1 << 20))) {
+    tgp::set_error("tgp_chain_task: bad panel shape");
+    return TGP_E_ARG;
+  }
+  const int64_t n = chain_task_count((int)R, (int)nblk, (int)cb, (int)ce);
+  if (n_tasks) *n_tasks = n;
+  if (ticket >= 0) {
+    if (ticket >= n || out5 == nullptr) {
+      tgp::set_error("tgp_chain_task: ticket out of range");
+      return TGP_E_ARG;
+    }
+    const ChainTask t = chain_decode_ticket((int)ticket, (int)R, (int)nblk, (int)cb, (int)ce);
+    out5[0] = t.kind; out5[1] = t.i; out5[2] = t.c; out5[3] = t.k; out5[4] = t.part;
+  }
   return TGP_OK;
 }
 

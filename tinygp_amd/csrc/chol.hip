@@ -20,6 +20,8 @@
 #include <type_traits>
 
 #include "tgp_common.h"
+#define CHAIN_HD __host__ __device__
+#include "chain_tasks.h"
 
 namespace tgp {
 
@@ -1028,50 +1030,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   __shared__ int s_task[6];
   using acc_t = typename Mfma<T>::acc_t;
   if (threadIdx.x == 0) {
-    // ticket -> task.  diag(cb) first in a continuation launch (a panel's very first block is factored in front of
-    // the launch); then per column k: xsolve(k+1), diag(k+1) [if in range], solve(r0.., k) with r0 = k + 2 while
-    // xsolve(k+1) owns tile (k+1, k), update(i, c, k) for c = k+1 .. nblk-1 and i = c .. R-1 without (k+1, k+1, k) =
-    // diag(k+1)'s fold -- the first of them, tile (k+2, k+1), as four quarter tasks
-    int t = atomicAdd(q.ticket, 1);
+    // ticket -> task (chain_tasks.h: the same map sizes the launch on the host and is checked on the CPU)
+    const int t = atomicAdd(q.ticket, 1);
     s_task[4] = t;
-    // kind: 0 solve, 1 diag, 2 update, 3 update of a diagonal tile, 4 a quarter of an update, 5 xsolve
-    int kind = -1, ti = 0, tc = 0, tk = 0;
-    if (q.cb > 0) {
-      if (t == 0) { kind = 1; tc = q.cb; }
-      --t;
-    }
-    for (int k = q.cb; k < q.ce && kind < 0; ++k) {
-      // tasks of step k in closed form (chains of up to 64 block columns: no loop over the columns per step)
-      const int nd = k + 1 < q.ce ? 1 : 0;
-      const int r0 = nd ? k + 2 : k + 1;
-      const int ns = q.R - r0 > 0 ? q.R - r0 : 0;
-      const int a = k + 1, b = q.nblk - 1;  // updated columns a .. b: R - c tiles each, minus diag(k+1)'s fold
-      // (tile (k+2, k+1), the first of them, is taken by FOUR workgroups: chain_update_full<QUARTER>)
-      const int crit = (a <= b && q.R - (a + 1) >= 1) ? 3 : 0;
-      const int nu = (a <= b ? (b - a + 1) * q.R - (a + b) * (b - a + 1) / 2 - 1 : 0) + crit;
-      if (t >= 2 * nd + ns + nu) {
-        t -= 2 * nd + ns + nu;
-        continue;
-      }
-      if (nd) {  // xsolve(k+1) in front of diag(k+1): the diagonal task follows the solve of its tile
-        if (t == 0) { kind = 5; tc = k + 1; break; }
-        if (t == 1) { kind = 1; tc = k + 1; break; }
-        t -= 2;
-      }
-      if (t < ns) { kind = 0; ti = r0 + t; tc = k; break; }
-      t -= ns;
-      for (int c = a; c <= b; ++c) {
-        const int i0 = c == a ? c + 1 : c;
-        const int cnt = q.R - i0;
-        if (c == a && crit) {
-          if (t < 4) { ti = i0; tc = c; tk = k; kind = 4; s_task[5] = t; break; }
-          t -= 3;
-        }
-        if (t < cnt) { ti = i0 + t; tc = c; tk = k; kind = ti == c ? 3 : 2; break; }
-        t -= cnt;
-      }
-      break;
-    }
+    const ChainTask task = chain_decode_ticket(t, q.R, q.nblk, q.cb, q.ce);
+    const int kind = task.kind, ti = task.i, tc = task.c, tk = task.k;
+    s_task[5] = task.part;
     s_task[0] = kind; s_task[1] = ti; s_task[2] = tc; s_task[3] = tk;
   }
   __syncthreads();
@@ -1105,7 +1069,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0 &&
-          __hip_atomic_fetch_add(q.ticket + CHAIN_QCNT_OFF + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3)
+          __hip_atomic_fetch_add(q.ticket + CHAIN_QCNT_OFF + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+              CHAIN_CRIT_PARTS - 1)
         __hip_atomic_store(wt, E + uint32_t(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       chain_publish(wt, E + uint32_t(k + 1));
@@ -1949,13 +1914,7 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
     trace_push(ctx, 11, st, trace_off(ctx, A0), ld, R, cb, ce, nblk);
     return TGP_OK;
   }
-  int64_t tasks = cb > 0 ? 1 : 0;
-  for (int64_t k = cb; k < ce; ++k) {  // the same closed form as the kernel's ticket decode
-    const int64_t nd = k + 1 < ce ? 1 : 0, r0 = nd ? k + 2 : k + 1;
-    const int64_t a = k + 1, b = nblk - 1;
-    tasks += 2 * nd + std::max<int64_t>(0, R - r0) + (a <= b ? (b - a + 1) * R - (a + b) * (b - a + 1) / 2 - 1 : 0) +
-             ((a <= b && R - (a + 1) >= 1) ? 3 : 0);
-  }
+  const int64_t tasks = chain_task_count((int)R, (int)nblk, (int)cb, (int)ce);  // (chain_tasks.h)
   if (tasks == 0) {  // a one-block panel: potf2 in front was all of it; the pollers' event still marks this point
     if (counters_ready != nullptr) TGP_TRY(ev_record(ctx, counters_ready, st));
     return TGP_OK;
