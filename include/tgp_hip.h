@@ -434,7 +434,7 @@ int tgp_chain_stamps(tgp_ctx* ctx, int64_t* out, int64_t cap_tasks, int64_t* n_t
  * text the kernel decodes its ticket with and the launch is sized by) for a launch over block columns [cb, ce) of a
  * panel with R row tiles and nblk block columns.  *n_tasks = tickets of the launch; ticket >= 0: out5 = {kind, row
  * tile, block column, source column, part} with kind 0 solve | 1 diag | 2 update | 3 update of a diagonal tile |
- * 4 a quarter of an update | 5 xsolve.  tests/test_chain_tasks.py checks on the CPU that every task of a launch
+ * 4 a part (an eighth) of an update | 5 xsolve.  tests/test_chain_tasks.py checks on the CPU that every task of a launch
  * exists exactly once and waits for EARLIER tickets only. */
 int tgp_chain_task(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t ticket, int32_t* out5, int64_t* n_tasks);
 

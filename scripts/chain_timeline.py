@@ -57,7 +57,7 @@ for n in [int(a) for a in sys.argv[1:]] or [1024, 4096]:
               f"{s_[5]:7.1f} {s_[6]:8.1f} {s_[7]:9.1f} | {gap:12.1f} {s_[6] - s_[5]:14.1f}  {per:7.1f}")
         prev_pub = s_[7]
     for kind, name, ph in ((0, "solve", ("wait", "stage", "solve", "publish")), (2, "update", ("wait", "compute", "publish")),
-                           (4, "update of tile (k+2, k+1), a quarter per task", ("wait", "compute", "publish")),
+                           (4, "update of tile (k+2, k+1), one of CHAIN_CRIT_PARTS parts per task", ("wait", "compute", "publish")),
                            (3, "update (diagonal tile)", ("wait", "compute", "publish"))):
         sel = recs[recs[:, 0] == kind]
         if not len(sel):

@@ -8,10 +8,10 @@
 
 struct ChainTask {
   int kind;  // 0 solve(i, c) | 1 diag(c) | 2 update(i, c, k) | 3 update of the diagonal tile (c, c) from column k |
-             // 4 a quarter (`part`) of update(i, c, k) | 5 xsolve(c): the streamed solve of tile (c, c-1) | -1 none
+             // 4 one of CHAIN_CRIT_PARTS parts (`part`) of update(i, c, k) | 5 xsolve(c): the streamed solve of tile (c, c-1) | -1 none
   int i, c, k, part;
 };
-constexpr int CHAIN_CRIT_PARTS = 4;  // workgroups that share the update of tile (k+2, k+1) from column k
+constexpr int CHAIN_CRIT_PARTS = 8;  // workgroups that share the update of tile (k+2, k+1) from column k
 
 // tasks of step k (column k is made final, everything right of it receives its update) in closed form:
 //   xsolve(k+1), diag(k+1)             if block k+1 is factored by this launch (k + 1 < ce)

@@ -419,7 +419,7 @@ __device__ __forceinline__ void chain_stamp(long long* st, int k) {
 constexpr int CHAIN_FLAG_LD = 64;  // state word of tile (i, c) of the panel: flags[i * 64 + c] (chains of <= 64 block columns)
 constexpr uint32_t CHAIN_FINAL = 127;
 constexpr int CHAIN_COLCNT_OFF = 16;  // d_chain_ticket: [0] the ticket counter, [16 + c] final tiles of block column c,
-constexpr int CHAIN_QCNT_OFF = 96;    // [96 + k] finished quarters of the update of tile (k+2, k+1) from column k
+constexpr int CHAIN_QCNT_OFF = 96;    // [96 + k] finished parts of the update of tile (k+2, k+1) from column k
 constexpr int CHAIN_XSTEP_OFF = 160;  // [160 + c] column blocks of X_{c,c-1} complete in memory (0..8): xsolve(c) -> diag(c)
 constexpr int CHAIN_TICKET_WORDS = CHAIN_XSTEP_OFF + CHAIN_FLAG_LD;
 
@@ -500,11 +500,12 @@ __global__ __launch_bounds__(64) void chain_poll_kernel(const int32_t* __restric
 
 // update(i, c, k), i > c:  A_ic -= X_ik X_ck^T.  128 x 128 x 128 on the MFMAs, operands double-buffered through S
 // as in trsm_fold_body; the tile is read and written once, write-through.
-// QUARTER: rows 32 qr .. 32 qr + 31 of the tile only, every wave 16 of its 128 columns -- a quarter of the MFMA work per
-// wave.  The update of tile (k+2, k+1) from column k is the LAST thing the next diagonal task waits for (its solve of
-// that tile runs beside potf2(k+1) only if the tile is there in time): four workgroups take a quarter each.
-template <typename T, bool QUARTER>
-__device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, int i, int c, int k, int qr) {
+// PARTS = 4 / 8: rows 32 part .. + 31 / 16 part .. + 15 of the tile only, every wave 16 of its 128 columns -- a quarter /
+// an eighth of the MFMA work per wave.  The update of tile (k+2, k+1) from column k is the LAST thing xsolve(k+2) waits
+// for (it runs beside potf2(k+1) only if the tile is there in time): CHAIN_CRIT_PARTS workgroups share it.
+template <typename T, int PARTS>
+__device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, int i, int c, int k, int part) {
+  static_assert(PARTS == 1 || PARTS == 4 || PARTS == 8, "whole tile, row quarters or row eighths");
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   typedef T T2 __attribute__((ext_vector_type(2)));
@@ -516,17 +517,19 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
   static_assert(4 * FK * F_LD == 36 * 256, "the operand buffers are exactly potf2's tile image");
   T* sA = S;                  // [2][FK * F_LD]
   T* sB = S + 2 * FK * F_LD;  // [2][FK * F_LD]
-  const int wr = QUARTER ? qr : (w >> 1);              // wave tile: 32 rows x 64 columns (a quarter task: 32 x 16)
-  const int cbase = QUARTER ? w * 16 : (w & 1) * 64;   // its first column
-  constexpr int NA = QUARTER ? 1 : 4;                  // 16-column blocks per wave
+  // wave tile: 32 rows x 64 columns (a quarter task: 32 x 16, an eighth: 16 x 16)
+  const int rbase = PARTS == 1 ? (w >> 1) * 32 : (PARTS == 4 ? part * 32 : part * 16);  // its first row
+  const int cbase = PARTS == 1 ? (w & 1) * 64 : w * 16;                                 // its first column
+  constexpr int NA = PARTS == 1 ? 4 : 1;   // 16-column blocks per wave
+  constexpr int NBR = PARTS == 8 ? 1 : 2;  // 16-row blocks per wave
   // acc[a][b]: the 16 x 16 block (rows wr*32 + b*16.., columns wc*64 + a*16..) of the wave's 32 x 64 tile.  fp64: four
   // scalars per lane from the 4x4x4_4b instruction (entry t <-> row rot4(lane, t), column arow4(lane) of the block);
   // fp32: the 16x16x4 form's vector (entry r <-> row lrow, column drow(lane, r))
-  acc_t acc[NA][2];
+  acc_t acc[NA][NBR];
 #pragma unroll
   for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+    for (int b = 0; b < NBR; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
   const T* Xi = q.A0 + int64_t(k) * TILE * ld + int64_t(i) * TILE;
   const T* Xj = q.A0 + int64_t(k) * TILE * ld + int64_t(c) * TILE;
   T2 ra[2], rb[2];
@@ -558,14 +561,14 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
     if (kt + 1 < nkt) load_global(kt + 1);
     const T* pa = &sB[buf * FK * F_LD + lk * F_LD + cbase + lrow];  // MFMA A operand <- Xj rows (C column)
     if constexpr (M::FAST4) {
-      const T* pb = &sA[buf * FK * F_LD + lk * F_LD + wr * 32];  // MFMA B operand <- Xi rows (C row), rotated reads
+      const T* pb = &sA[buf * FK * F_LD + lk * F_LD + rbase];  // MFMA B operand <- Xi rows (C row), rotated reads
 #pragma unroll
       for (int ks = 0; ks < FK / 4; ++ks) {
         T aop[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NBR; ++b) {
           T bop[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) bop[t] = pb[ks * 4 * F_LD + b * 16 + rot[t]];
@@ -576,37 +579,37 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
         }
       }
     } else {
-      const T* pb = &sA[buf * FK * F_LD + lk * F_LD + wr * 32 + lrow];  // MFMA B operand <- Xi rows (C row)
+      const T* pb = &sA[buf * FK * F_LD + lk * F_LD + rbase + lrow];  // MFMA B operand <- Xi rows (C row)
 #pragma unroll
       for (int ks = 0; ks < FK / 4; ++ks) {
-        T aop[NA], bop[2];
+        T aop[NA], bop[NBR];
 #pragma unroll
         for (int a = 0; a < NA; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) bop[b] = pb[ks * 4 * F_LD + b * 16];
+        for (int b = 0; b < NBR; ++b) bop[b] = pb[ks * 4 * F_LD + b * 16];
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b] = M::mma(aop[a], bop[b], acc[a][b]);
+          for (int b = 0; b < NBR; ++b) acc[a][b] = M::mma(aop[a], bop[b], acc[a][b]);
       }
     }
     if (kt + 1 < nkt) store_lds(buf ^ 1);
     __syncthreads();
   }
-  T* Cu = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + int64_t(cbase) * ld + wr * 32;
+  T* Cu = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + int64_t(cbase) * ld + rbase;
   if constexpr (M::FAST4) {
     // C[wr*32 + b*16 + rot[t], wc*64 + a*16 + arow4(lane)] -= acc[a][b][t]
     const int64_t ccol = M::arow4(lane);
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-      T cc[2][4];
+      T cc[NBR][4];
       T* col = Cu + (int64_t(a * 16) + ccol) * ld;
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NBR; ++b)
 #pragma unroll
         for (int t = 0; t < 4; ++t) cc[b][t] = col[b * 16 + rot[t]];
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NBR; ++b)
 #pragma unroll
         for (int t = 0; t < 4; ++t) st_agent(col + b * 16 + rot[t], T(cc[b][t] - acc[a][b][t]));
       __builtin_amdgcn_sched_barrier(0);  // one pass of eight loads at a time (register budget: 128)
@@ -616,13 +619,13 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
     const uint32_t coff = uint32_t(M::drow(lane, 0) * int(ld) + lrow);
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-      T cc[2][4];
+      T cc[NBR][4];
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NBR; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cc[b][r] = (Cu + int64_t(a * 16 + M::drow(0, r)) * ld + b * 16)[coff];
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NBR; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           st_agent(Cu + int64_t(a * 16 + M::drow(0, r)) * ld + b * 16 + coff, T(cc[b][r] - acc[a][b][r]));
@@ -1061,11 +1064,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     chain_wait<8>(q.flags + i * CHAIN_FLAG_LD + k, E + CHAIN_FINAL, q.flags + c * CHAIN_FLAG_LD + k, E + CHAIN_FINAL,
                   k > q.cb ? wt : nullptr, E + uint32_t(k), q.info);
     chain_stamp(st, 1);  // operands final, the tile carries every earlier update
-    if (kind == 2) chain_update_full<T, false>(q, S, i, c, k, 0);
-    else if (kind == 4) chain_update_full<T, true>(q, S, i, c, k, __builtin_amdgcn_readfirstlane(s_task[5]));
+    if (kind == 2) chain_update_full<T, 1>(q, S, i, c, k, 0);
+    else if (kind == 4) chain_update_full<T, CHAIN_CRIT_PARTS>(q, S, i, c, k, __builtin_amdgcn_readfirstlane(s_task[5]));
     else chain_update_diag<T>(q, S, c, k);
     chain_stamp(st, 2);
-    if (kind == 4) {  // the last of the four quarters publishes the tile's new state
+    if (kind == 4) {  // the last of the parts to finish publishes the tile's new state
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0 &&
