@@ -288,3 +288,57 @@ def test_c_oracle_agrees(refc):
                                    work.ctypes.data_as(dp))
     want = float(o.GaussianProcess(_cases.synthetic.config_kernel(o, "expsq"), X, diag=0.01).log_probability(y))
     np.testing.assert_allclose(got, want, rtol=1e-10)
+
+
+def test_closed_form_kernel_derivatives_match_central_differences():
+    """oracle/kernel_derivs_np.py (the closed forms the device evaluates, stated independently) against central
+    differences of the oracle's own kernel matrices: every stationary leaf, both metrics, 1-D and 3-D inputs."""
+    import numpy as np
+
+    from oracle import kernel_derivs_np as kd
+    from oracle import tinygp_np as o
+
+    rng = np.random.default_rng(3)
+    leaves = {
+        "scale": [lambda s, m: o.Exp(s, distance=m), lambda s, m: o.ExpSquared(s, distance=m), lambda s, m: o.Matern32(s, distance=m),
+                  lambda s, m: o.Matern52(s, distance=m), lambda s, m: o.Cosine(s, distance=m),
+                  lambda s, m: o.ExpSineSquared(s, distance=m, gamma=0.7), lambda s, m: o.RationalQuadratic(s, distance=m, alpha=1.3)],
+    }
+    for d in (1, 3):
+        X1, X2 = rng.normal(size=(40, d)) * 1.5, rng.normal(size=(35, d)) * 1.5
+        X2[0] = X1[0]  # a zero distance
+        for metric in (o.L1Distance, o.L2Distance):
+            for make in leaves["scale"]:
+                s0, h = 0.9, 1e-6
+                want = (make(s0 + h, metric())(X1, X2) - make(s0 - h, metric())(X1, X2)) / (2 * h)
+                got = kd.dleaf(make(s0, metric()), X1, X2, "scale")
+                np.testing.assert_allclose(got, want, rtol=2e-7, atol=2e-8, err_msg=f"{type(make(s0, metric())).__name__} {metric.__name__} d={d}")
+            for name, make, p0 in (("gamma", lambda v, m: o.ExpSineSquared(0.9, distance=m, gamma=v), 0.7),
+                                   ("alpha", lambda v, m: o.RationalQuadratic(0.9, distance=m, alpha=v), 1.3)):
+                h = 1e-6
+                want = (make(p0 + h, metric())(X1, X2) - make(p0 - h, metric())(X1, X2)) / (2 * h)
+                got = kd.dleaf(make(p0, metric()), X1, X2, name)
+                np.testing.assert_allclose(got, want, rtol=2e-7, atol=2e-8, err_msg=f"{name} {metric.__name__} d={d}")
+
+
+def test_trace_identity_with_closed_form_derivatives_matches_the_gradient_oracle():
+    """d ll / d theta = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta) with the CLOSED-FORM dK/dtheta against oracle/grad_np.py
+    (the same identity with dK/dtheta by central differences): amplitude and scale of Matern-3/2 and ExpSquared."""
+    import numpy as np
+
+    from oracle import grad_np
+    from oracle import kernel_derivs_np as kd
+    from oracle import tinygp_np as o
+
+    rng = np.random.default_rng(8)
+    X = np.sort(rng.uniform(0, 10, size=(60, 1)), axis=0)
+    y = np.sin(X[:, 0]) + 0.1 * rng.normal(size=60)
+    diag = 0.05
+    for leaf in (o.Matern32, o.ExpSquared):
+        theta = np.array([1.7, 0.8])  # amplitude, scale
+        build = lambda t: t[0] * leaf(t[1])  # noqa: E731
+        _, g, _, alpha = grad_np.log_probability_and_grad(build, theta, X, diag, y)
+        K = build(theta)(X, X) + diag * np.eye(60)
+        G = np.outer(alpha, alpha) - np.linalg.inv(K)
+        closed = np.array([0.5 * np.sum(G * leaf(theta[1])(X, X)), 0.5 * np.sum(G * theta[0] * kd.dleaf(leaf(theta[1]), X, X))])
+        np.testing.assert_allclose(closed, g, rtol=1e-6, atol=1e-8)
