@@ -713,7 +713,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # Rehearsal of the N > 1 launch line on a box with ONE GPU (tests/test_gpu_bench_contract.py): every
+    # Rehearsal of the N > 1 launch line on a box with ONE GPU (tests/test_gpu_9_bench_contract.py): every
     # rank uses device 0 and the collectives go through gloo (RCCL refuses two ranks on one device).
     # The line it prints carries "rehearsal": true -- its numbers mean nothing.
     rehearsal = os.environ.get("TGP_BENCH_ONE_GPU", "0") == "1"

@@ -8,7 +8,7 @@ on >= 2 GPUs the block-column path runs with the **nccl** backend (= RCCL over x
 
 Every process group is created with a finite timeout and `TORCH_NCCL_ASYNC_ERROR_HANDLING=1`, every queue read and
 subprocess has its own timeout: a schedule bug on first contact FAILS the test instead of hanging the lease.  The same
-code path is rehearsed on one GPU with gloo in tests/test_gpu_multirank_one_gpu.py and tests/test_gpu_bench_contract.py."""
+code path is rehearsed on one GPU with gloo in tests/test_gpu_6_multirank_one_gpu.py and tests/test_gpu_9_bench_contract.py."""
 import datetime
 import json
 import os

@@ -74,7 +74,7 @@ def test_inputs_beyond_the_device_evaluator_take_the_host_route():
     rng = np.random.default_rng(5)
     a20, b20 = rng.normal(size=(11, 20)), rng.normal(size=(6, 20))
     # (with D <= 16 the sub-trees that fit would run on the device and only the combination on the host -- GPU
-    # suite, test_gpu_gp.py; here everything is beyond the limits, so no device is touched)
+    # suite, test_gpu_1_gp.py; here everything is beyond the limits, so no device is touched)
     for kk, kko in ((k, ko), (deep, deepo)):
         assert np.array_equal(kk(a20, b20), kko(a20, b20))
         assert np.array_equal(kk(a20), kko(a20))
@@ -283,3 +283,21 @@ def test_division_free_quotient_is_the_ieee_quotient(tmp_path):
     subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", str(src), "-o", str(exe), "-lm"], check=True)
     out = subprocess.run([str(exe), "20000000"], capture_output=True, text=True)
     assert out.returncode == 0 and "mismatches=0" in out.stdout, out.stdout + out.stderr
+
+
+def test_transform_gradient_is_only_attributed_to_a_transform_that_covers_every_leaf():
+    """Sum(Linear(1, k1), k2) lowers to ONE device pass (the coordinates coincide) but k2 never saw the transform: the
+    device's d ll / d log s_q runs over every leaf, so no transform gradient may be returned for such a tree."""
+    from tinygp_amd import transforms
+    from tinygp_amd.transforms import covering_transform
+
+    k1, k2 = kernels.ExpSquared(1.0), kernels.Matern32(2.0)
+    lin = transforms.Linear(np.ones(3), k1)
+    assert covering_transform(lin) is lin
+    assert covering_transform(2.0 * lin) is lin            # Product(Constant, Linear)
+    assert covering_transform(2.0 * lin + 0.5) is lin      # Constant-only siblings do not depend on the coordinates
+    assert covering_transform(lin + k2) is None            # k2 sees the raw coordinates
+    assert covering_transform(lin * k2) is None
+    assert covering_transform(k1 + k2) is None             # no transform at all
+    assert covering_transform(transforms.Linear(np.ones(3), lin)) is None  # nested: two parameters, one device result
+    assert covering_transform(lin + transforms.Linear(np.ones(3), k2)) is None

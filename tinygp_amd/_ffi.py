@@ -132,6 +132,74 @@ SIGNATURES = {
 ABI_VERSION = 4  # TGP_ABI_VERSION of include/tgp_hip.h
 
 
+def _mapped_hip_runtimes() -> list[str]:
+    """Distinct ``libamdhip64`` images mapped into this process (Linux: /proc/self/maps)."""
+    seen = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.split(None, 5)[-1].strip() if line.count("/") else ""
+                if "libamdhip64" in os.path.basename(path):
+                    real = os.path.realpath(path)
+                    if real not in seen:
+                        seen.append(real)
+    except OSError:  # pragma: no cover - not Linux
+        pass
+    return seen
+
+
+def _torch_hip_runtime() -> Path | None:
+    """PyTorch-ROCm wheels bundle their own HIP runtime under torch/lib; located WITHOUT importing torch."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return None
+    if spec is None or not spec.origin:
+        return None
+    cand = Path(spec.origin).resolve().parent / "lib" / "libamdhip64.so"
+    return cand if cand.exists() else None
+
+
+def share_hip_runtime() -> str | None:
+    """Make sure ONE HIP runtime serves this process, whoever comes first.
+
+    ``libtgp_hip.so`` needs ``libamdhip64.so.7`` (no RUNPATH); PyTorch-ROCm loads the copy bundled in its wheel through
+    ``$ORIGIN``.  Two copies mean two HSA runtimes, and the second one sees no device
+    (``tgp_ctx_create: no HIP device visible`` right after ``init_process_group``, GPUTEST_r04).  Loaded after torch
+    the SONAME already resolves to torch's copy; loaded BEFORE torch -- the single-GPU path, then
+    ``DistributedDirectSolver`` -- the system copy used to win and torch mapped a second one.  So: when no runtime is
+    mapped yet and a torch wheel with a bundled runtime is installed, that copy is loaded first (RTLD_GLOBAL, by the
+    very path torch will ask for: the loader then re-uses the image by device/inode).  ``TGP_HIP_RUNTIME=system`` keeps
+    the loader's default (ROCm's ld.so.conf entry), ``TGP_HIP_RUNTIME=/path/libamdhip64.so`` names one.
+    Returns the path preloaded, or None."""
+    if _mapped_hip_runtimes():
+        return None
+    choice = os.environ.get("TGP_HIP_RUNTIME", "auto")
+    if choice == "system":
+        return None
+    cand = _torch_hip_runtime() if choice in ("auto", "torch") else Path(choice)
+    if cand is None:
+        if choice == "torch":
+            raise TgpError("TGP_HIP_RUNTIME=torch, but no torch wheel with a bundled libamdhip64.so is installed")
+        return None
+    if not cand.exists():
+        raise TgpError(f"TGP_HIP_RUNTIME={choice}: no such file")
+    C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+    return str(cand)
+
+
+def assert_single_hip_runtime(where: str = "") -> None:
+    """Two HIP runtimes in one process = a dead device for whichever came second: say so instead of failing later."""
+    got = _mapped_hip_runtimes()
+    if len(got) > 1:
+        raise TgpError(
+            f"{where + ': ' if where else ''}two HIP runtimes are mapped into this process ({', '.join(got)}); the "
+            "second one cannot see the GPU. Import tinygp_amd (or call tinygp_amd._ffi.lib()) before anything that loads "
+            "ROCm's system libamdhip64, or set TGP_HIP_RUNTIME to the copy the rest of the process uses.")
+
+
 def load_library(path: Path | None = None) -> C.CDLL:
     """dlopen the library and attach signatures.  Needs no GPU (used by the ABI test)."""
     path = library_path() if path is None else Path(path)
@@ -141,7 +209,9 @@ def load_library(path: Path | None = None) -> C.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C tinygp_amd/csrc`). "
             "tinygp_amd has no CPU fallback."
         )
+    share_hip_runtime()
     lib_ = C.CDLL(str(path))
+    assert_single_hip_runtime(str(path))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib_, name)  # AttributeError = ABI drift, deliberately loud
         fn.argtypes = argtypes
@@ -191,6 +261,8 @@ class Ctx:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
         h = C.c_void_p()
+        lib()
+        assert_single_hip_runtime("tgp_ctx_create")
         check(lib().tgp_ctx_create(device, C.c_void_p(stream or 0), C.byref(h)), "tgp_ctx_create")
         self.handle = h
         # tuning overrides, e.g. TGP_HIP_OPTIONS="nb_outer=512,lookahead=0"

@@ -128,11 +128,17 @@ class HipBlockOps:
     def x_slice(self, k: int):
         return self.x[k * self.nb:(k + 1) * self.nb]
 
+    # Every allocation, fill and copy that feeds kernels of the handle is issued UNDER the handle's main stream: that
+    # stream is created non-blocking, so torch's current (legacy null) stream does not order against it -- a zero-fill
+    # could land behind the first kernel that writes the buffer, a copy in front of the solve that produces its source
+    # (advisor r4, high).  The caching allocator then also ties the blocks to the stream their kernels run on.
     def scalar(self, v: float):
-        return self.torch.tensor([v], dtype=self.torch.float64, device=self.device)
+        with self.stream(MAIN):
+            return self.torch.tensor([v], dtype=self.torch.float64, device=self.device)
 
     def empty_vec(self, m: int):
-        return self.torch.empty(m, dtype=self.x.dtype, device=self.device)
+        with self.stream(MAIN):
+            return self.torch.empty(m, dtype=self.x.dtype, device=self.device)
 
     # -- per-step calls (all asynchronous) ---------------------------------------------------
     def assemble(self, prog):
@@ -185,7 +191,8 @@ class HipBlockOps:
     # -- solves on the resident factor (buffers: device tensors, (npad,) or (npad, nrhs) row-major) ------------
     def rhs_zeros(self, nrhs: int):
         shape = (self.npad,) if nrhs == 1 else (self.npad, nrhs)
-        return self.torch.zeros(shape, dtype=self.x.dtype, device=self.device)
+        with self.stream(MAIN):
+            return self.torch.zeros(shape, dtype=self.x.dtype, device=self.device)
 
     def rhs_from_host(self, Y: np.ndarray, nrhs: int):
         """(n,) or (n, R) host array -> zero-padded device buffer of `nrhs` (1 or a multiple of 128) columns."""
@@ -194,7 +201,8 @@ class HipBlockOps:
             buf[: self.n] = Y.reshape(self.n)
         else:
             buf[: self.n, : Y.shape[1]] = Y
-        return self.torch.from_numpy(buf).to(self.device)
+        with self.stream(MAIN):
+            return self.torch.from_numpy(buf).to(self.device)
 
     def rhs_to_host(self, buf) -> np.ndarray:
         with self.stream(MAIN):  # behind the collective that produced it, on ITS stream
@@ -218,26 +226,30 @@ class HipBlockOps:
 
     def cross_cov(self, prog, Pt: np.ndarray, m_pad: int):
         kp, nops = _ffi.as_kprog(prog)
-        out = self.torch.empty((self.npad, m_pad), dtype=self.x.dtype, device=self.device)
+        with self.stream(MAIN):
+            out = self.torch.empty((self.npad, m_pad), dtype=self.x.dtype, device=self.device)
         _ffi.check(self.lib.tgp_dist_cross_cov(self.h, kp, nops, Pt.shape[0], _ffi.ptr(Pt), m_pad,
                                                C.c_void_p(out.data_ptr())), "tgp_dist_cross_cov")
         return out
 
     def colsumsq_owned(self, nrhs: int, x):
-        out = self.torch.empty(nrhs, dtype=self.x.dtype, device=self.device)
+        with self.stream(MAIN):
+            out = self.torch.empty(nrhs, dtype=self.x.dtype, device=self.device)
         _ffi.check(self.lib.tgp_dist_colsumsq_owned(self.h, nrhs, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr())),
                    "tgp_dist_colsumsq_owned")
         return out
 
     def gram_owned(self, nrhs: int, x):
-        out = self.torch.empty((nrhs, nrhs), dtype=self.x.dtype, device=self.device)
+        with self.stream(MAIN):
+            out = self.torch.empty((nrhs, nrhs), dtype=self.x.dtype, device=self.device)
         _ffi.check(self.lib.tgp_dist_gram_owned(self.h, nrhs, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr())),
                    "tgp_dist_gram_owned")
         return out
 
     def set_x(self, buf):
         """The handle's own replicated vector <- a solved vector (the backward substitution works in place there)."""
-        self.x.copy_(buf)
+        with self.stream(MAIN):
+            self.x.copy_(buf)
 
     def abort(self):
         if self.h is not None:

@@ -361,9 +361,10 @@ class DirectSolver(Solver):
         # an input transform with per-dimension scales (transforms.Linear / Cholesky, reference transforms.py:39-133;
         # kernels/stationary.py:41-43 sends users there for anisotropic length scales): the device also returns
         # d ll / d log s_q per dimension of the transformed coordinates, one extra pass over K^-1 each
-        from tinygp_amd.transforms import find_transforms
+        from tinygp_amd.transforms import covering_transform
 
-        tfs = find_transforms(self.kernel)
+        tf = covering_transform(self.kernel)  # None unless ONE transform wraps every coordinate-dependent leaf
+        tfs = [] if tf is None else [tf]
         glog = (C.c_double * self.d)() if len(tfs) == 1 else None
         _ffi.check(_ffi.lib().tgp_solver_grad(self._handle, _ffi.ptr(r), C.byref(out), gp_,
                                               _ffi.ptr(gnoise), _ffi.ptr(alpha), glog), "tgp_solver_grad")

@@ -67,7 +67,7 @@ def config_kernel(kernels_module, spec: str, amp: float = 1.5, scale: float = 2.
     if spec == "matern52":
         # Euclidean metric: with the reference's DEFAULT (L1) metric a Matern-5/2 of a 3-D
         # distance is not positive definite (LAPACK and the HIP path both stop at pivot 17
-        # on config 3's inputs; tests/test_gpu_gp.py pins that), so config 3 names L2.
+        # on config 3's inputs; tests/test_gpu_1_gp.py pins that), so config 3 names L2.
         return amp**2 * k.Matern52(scale, distance=k.L2Distance())
     if spec == "matern52_l1":
         return amp**2 * k.Matern52(scale)

@@ -62,6 +62,35 @@ def find_transforms(kernel) -> list:
     return out
 
 
+def covering_transform(kernel):
+    """The ONE input transform that every coordinate-dependent leaf of ``kernel`` sits under, or None.
+
+    The device differentiates with respect to the per-dimension log-scales of the coordinates it is given over EVERY
+    leaf of the kernel program (no per-leaf mask).  That is the transform's gradient only if no leaf saw the raw
+    coordinates: in ``Sum(Linear(s, k1), k2)`` -- which lowers to one device pass while ``s == 1`` -- k2's share would be
+    attributed to ``s`` (advisor r4).  Constant-only siblings are fine: they do not depend on the coordinates."""
+    from tinygp_amd.kernels.base import Constant
+
+    def walk(k):  # -> (transforms found, a coordinate-dependent leaf outside any transform?)
+        if isinstance(k, _PreTransform):
+            return [k], False
+        subs = [getattr(k, name, None) for name in ("kernel1", "kernel2")]
+        subs = [x for x in subs if x is not None]
+        if not subs:
+            return [], not isinstance(k, Constant)
+        found, bare = [], False
+        for x in subs:
+            f, b = walk(x)
+            found += f
+            bare = bare or b
+        return found, bare
+
+    found, bare = walk(kernel)
+    if len(found) != 1 or bare or find_transforms(found[0].kernel):
+        return None
+    return found[0]
+
+
 class Transform(_PreTransform):
     """Apply ``transform`` (one coordinate -> one coordinate) before ``kernel``
     (reference ``transforms.py:23-37``)."""
