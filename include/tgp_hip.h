@@ -48,6 +48,7 @@ extern "C" {
 #define TGP_E_HIP (-2)     /* HIP runtime error */
 #define TGP_E_NOMEM (-3)   /* device allocation failed */
 #define TGP_E_UNSUPPORTED (-4)
+#define TGP_E_TIMEOUT (-5) /* a device-side hand-off did not arrive within poll_timeout_ms (not a numerical failure) */
 
 /* all device matrices are padded to a multiple of TGP_TILE rows/cols */
 #define TGP_TILE 128

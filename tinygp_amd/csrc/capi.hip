@@ -151,6 +151,7 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipSetDevice(device));
   tgp_ctx* ctx = new tgp_ctx();
   ctx->device = device;
+  ctx->has_device = true;
   if (stream) {
     ctx->stream = static_cast<hipStream_t>(stream);
   } else {
@@ -159,6 +160,12 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   }
   int lo = 0, hi = 0;
   TGP_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  {
+    int can = 0;  // stream memory operations: the followers of a chain launch wait in the command processor
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) can = 0;
+    (void)hipGetLastError();
+    ctx->can_wait_value = can == 1;
+  }
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->panel_stream, hipStreamNonBlocking, hi));
   // (the solve stream is created on first use -- ensure_solve_stream: a FIFTH stream in use costs every
   // dependent launch of the panel chains, profiles/r02_m_stream_count.txt, and the default schedule
@@ -259,6 +266,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "chain_depth2")) return &ctx->chain_depth2;
   if (!strcmp(key, "chain_pre_wait")) return &ctx->chain_pre_wait;
   if (!strcmp(key, "chain_polls")) return &ctx->chain_polls;
+  if (!strcmp(key, "chain_fast_update")) return &ctx->chain_fast_update;
   if (!strcmp(key, "kmat_plain_div")) return &ctx->kmat_plain_div;
   if (!strcmp(key, "chain_reserve")) return &ctx->chain_reserve;
   if (!strcmp(key, "gate_split")) return &ctx->gate_split;
@@ -268,6 +276,8 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "nb_first")) return &ctx->nb_first;
   if (!strcmp(key, "split_tail")) return &ctx->split_tail;
   if (!strcmp(key, "gemm_role")) return &ctx->gemm_role;
+  if (!strcmp(key, "poll_timeout_ms")) return &ctx->poll_timeout_ms;
+  if (!strcmp(key, "timeout_retries")) return &ctx->timeout_retries;  // (read: passes repeated after a device-side timeout)
   return nullptr;
 }
 
@@ -279,6 +289,8 @@ static int set_option_checked(tgp_ctx* ctx, const char* key, int64_t value, int6
   if (slot == &ctx->sub_panel || slot == &ctx->nb_first)
     TGP_ARG_CHECK(value >= 0 && value % TILE == 0, "%s must be a multiple of %d (0: off)", key, TILE);
   if (old) *old = *slot;
+  // (the bound lives in a device global of the library: it holds for every context of the process on this device)
+  if (slot == &ctx->poll_timeout_ms && ctx->has_device) return set_poll_limit(ctx, value);
   *slot = value;
   return TGP_OK;
 }
@@ -590,7 +602,23 @@ static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void*
 // events go back to the pool, so that the next call starts from a clean state.
 static int factor_impl(tgp_solver* s, const tgp_kop* prog, int nops, const void* cov_host,
                        int32_t* info, int fused, const void* resid_host, double* logprob) {
-  const int st = factor_body(s, prog, nops, cov_host, info, fused, resid_host, logprob);
+  int st = factor_body(s, prog, nops, cov_host, info, fused, resid_host, logprob);
+  if (st == TGP_E_TIMEOUT && s->ctx->chain_kernel != 0) {
+    // A device-side hand-off of the persistent chain timed out: a starved launch (a chip shared with other processes,
+    // a tool that holds kernels back), not a numerical result.  The matrix was factored in place, so the pass is
+    // repeated from the assembly -- ONCE, on the launch-per-block path, which has no device-side waits at all.
+    tgp_ctx* ctx = s->ctx;
+    for (hipStream_t q : {ctx->asm_stream, ctx->panel_stream, ctx->update_stream, ctx->solve_stream, ctx->stream})
+      if (q) (void)hipStreamSynchronize(q);
+    (void)hipGetLastError();
+    ctx->asm_pending = false;
+    ctx->ev_used = 0;
+    ctx->timeout_retries++;
+    const int64_t keep = ctx->chain_kernel;
+    ctx->chain_kernel = 0;
+    st = factor_body(s, prog, nops, cov_host, info, fused, resid_host, logprob);
+    ctx->chain_kernel = keep;
+  }
   if (st < 0) {
     tgp_ctx* ctx = s->ctx;
     ctx->asm_pending = false;

@@ -167,6 +167,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // ---------------------------------------------------------------------------------------
 constexpr int32_t STEP_TIMEOUT = INT32_MIN;
 
+// Device-side polls are bounded in WALL-CLOCK time (s_memrealtime, 100 MHz whatever the shader clock does), not by a
+// spin count: a chain launch that shares the chip with other ranks, runs under a debugger / profiler or at a throttled
+// clock is slow, not lost (advisor r4).  a single wait may last g_poll_limit ticks (ctx option poll_timeout_ms, default
+// 4 s); the clock is read every 256 polls only.  A wait that does expire poisons `info` with STEP_TIMEOUT: the host
+// reports TGP_E_TIMEOUT (never "not positive definite"), and tgp_solver_factor* retries once on the launch-per-block path.
+__device__ long long g_poll_limit = 400000000LL;  // ticks of 10 ns (set_poll_limit)
+struct PollClock {
+  long long t0 = 0;
+  __device__ __forceinline__ bool expired(long spin) {
+    if ((spin & 255) != 255) return false;
+    const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+    if (t0 == 0) {
+      t0 = now;
+      return false;
+    }
+    return now - t0 > __hip_atomic_load(&g_poll_limit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
+__device__ __forceinline__ bool poisoned(const int32_t* info) {
+  return __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == STEP_TIMEOUT;
+}
+
 template <typename T, bool FOLD>
 __device__ __forceinline__ void trsm_fold_body(T* S, int it, const T* __restrict__ Ljj,
                                                int64_t ld, const T* __restrict__ dinv,
@@ -270,10 +292,11 @@ __device__ __forceinline__ void trsm_fold_body(T* S, int it, const T* __restrict
   if (wait_flag) {  // L_jj and its inverses come from workgroup 0 of this launch
     if (tid == 0) {
       uint32_t seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      long spin = 0;
-      for (; seen != epoch && spin < (1L << 21); ++spin) {
+      PollClock clk;
+      for (int spin = 0; seen != epoch; ++spin) {
         __builtin_amdgcn_s_sleep(2);
         seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (clk.expired(spin)) break;
       }
       if (seen != epoch) atomicExch(info, STEP_TIMEOUT);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -439,6 +462,7 @@ struct ChainArgs {
                        // is L_00 when cb == 0 (a panel's first block is factored by potf2_kernel in front)
   long long* stamps;   // measurement hook (ctx option chain_stamps): 16 words per task from this base, or NULL
   int32_t launch;
+  int32_t fast_update;  // fp64 whole-tile updates on the 4x4x4 MFMA form, LDS-direct operands (chain_update_fast)
 };
 
 // all threads; wave 0 polls up to three state words (lane l: word f[l] == v[l]; NULL: nothing to wait for),
@@ -452,13 +476,14 @@ __device__ __forceinline__ void chain_wait(const uint32_t* f0, uint32_t v0, cons
     const uint32_t want = lane == 0 ? v0 : (lane == 1 ? v1 : v2);
     bool ok = f == nullptr || __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
     int spin = 0;
+    PollClock clk;
     while (!__all(ok)) {
       __builtin_amdgcn_s_sleep(NAP);
       if (!ok) ok = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
-      ++spin;
       bool dead = false;
-      if ((spin & 255) == 0 && lane == 0)  // somebody timed out, or this wait has lasted a few tenths of a second
-        dead = spin >= (1 << 18) || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == STEP_TIMEOUT;
+      if ((spin & 255) == 255 && lane == 0)  // somebody timed out, or this wait has outlasted the wall-clock limit
+        dead = clk.expired(spin) || poisoned(info);
+      ++spin;
       if (__any(dead)) {
         if (lane == 0) atomicExch(info, STEP_TIMEOUT);
         break;
@@ -487,11 +512,11 @@ __device__ __forceinline__ void chain_publish(uint32_t* word, uint32_t value, in
 __global__ __launch_bounds__(64) void chain_poll_kernel(const int32_t* __restrict__ count, int32_t target,
                                                         int32_t* __restrict__ info) {
   if (threadIdx.x != 0) return;
+  PollClock clk;
   for (int spin = 0;; ++spin) {
     if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
     __builtin_amdgcn_s_sleep(16);
-    if ((spin & 255) == 255 &&
-        (spin >= (1 << 19) || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == STEP_TIMEOUT)) {
+    if ((spin & 255) == 255 && (clk.expired(spin) || poisoned(info))) {
       atomicExch(info, STEP_TIMEOUT);
       break;
     }
@@ -632,6 +657,113 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
       __builtin_amdgcn_sched_barrier(0);  // one pass of eight loads at a time (register budget: 128)
     }
   }
+}
+
+// update(i, c, k), i > c, whole tile, fp64 (round 5, ctx option chain_fast_update): the 4x4x4 MFMA form -- 73-76 TFLOP/s
+// instruction ceiling against 46-49 for 16x16x4, i.e. 16.7 instead of 107 cycles per 16 x 16 x 4 step and SIMD -- with
+// the operands staged global -> LDS DIRECTLY (global_load_lds_dwordx4, one k-tile ahead, as gemm.hip): no staging
+// registers, which is what made round 4's attempt spill under the 128-register cap.  The tile is read FIRST, into the
+// accumulators, beside the first operand transfer; the MFMA's NEG field turns the products into -X_ik X_ck^T, so the
+// accumulators end as the updated tile and the epilogue is 32 write-through stores per lane, nothing loaded.
+// Wave tile 32 rows x 64 columns: acc[a][b][t] <-> row wr*32 + b*16 + rot4(lane, t), column wc*64 + a*16 + arow4(lane).
+__device__ __forceinline__ void chain_update_fast(const ChainArgs<double>& q, double* S, int i, int c, int k) {
+  using M = Mfma<double>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wu >> 1, wc = wu & 1;
+  const int lk = lane >> 4, lrow = lane & 15;
+  constexpr int FK = 16, F_LD = 144;  // [k][128 rows], 144 mod 32 == 16: conflict-free ds_read_b64
+  const int64_t ld = q.ld;
+  const double* Xi = q.A0 + int64_t(k) * TILE * ld + int64_t(i) * TILE;  // rows of the tile   -> MFMA B operand
+  const double* Xj = q.A0 + int64_t(k) * TILE * ld + int64_t(c) * TILE;  // columns of the tile -> MFMA A operand
+  double* sA = S;                  // [2][FK * F_LD]  X_ik
+  double* sB = S + 2 * FK * F_LD;  // [2][FK * F_LD]  X_ck
+  const uint32_t lds_a = uint32_t(size_t((__attribute__((address_space(3))) double*)(sA))) + uint32_t(wu * F_LD * 8);
+  const uint32_t lds_b = uint32_t(size_t((__attribute__((address_space(3))) double*)(sB))) + uint32_t(wu * F_LD * 8);
+  const uint32_t lane16 = uint32_t(lane) * 16u;
+  // wave wu moves k-rows {wu, wu + 8} of both operands: one 1 KiB row per wave instruction, LDS address in M0
+  auto issue_tile = [&](int kt, int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double* ap = Xi + (int64_t(kt) * FK + wu + 8 * r) * ld;
+      const double* bp = Xj + (int64_t(kt) * FK + wu + 8 * r) * ld;
+      const uint32_t off = uint32_t((buf * FK + 8 * r) * F_LD * 8);
+      uint32_t keep;  // (m0 is a reserved register: saved and restored, not clobbered)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                   "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(lane16), "s"(ap), "s"(lds_a + off), "s"(bp), "s"(lds_b + off) : "memory");
+    }
+  };
+  int rot[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) rot[t] = M::rot4(lane, t);
+  // the tile: wave-uniform base + four loop-invariant 32-bit lane offsets
+  char* Cu = reinterpret_cast<char*>(q.A0 + (int64_t(c) * TILE + wc * 64) * ld + int64_t(i) * TILE + wr * 32);
+  uint32_t voff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) voff[t] = uint32_t((int64_t(M::arow4(lane)) * ld + rot[t]) * 8);
+  issue_tile(0, 0);
+  double acc[4][2][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const char* cb = Cu + (int64_t(a * 16) * ld + b * 16) * 8;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[a][b][t] = *reinterpret_cast<const double*>(cb + voff[t]);
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the tile's values are consumed HERE as far as the compiler can tell: else its own wait for these loads lands inside
+  // the k-loop as a vmcnt(0) behind the transfers each iteration has just issued (it cannot count the asm's loads)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(acc[a][b][t]));
+  __syncthreads();
+  constexpr int nkt = TILE / FK;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) issue_tile(kt + 1, buf ^ 1);
+    const double* pa = &sB[buf * FK * F_LD + lk * F_LD + wc * 64 + lrow];  // A operand <- X_ck rows (tile column)
+    const double* pb = &sA[buf * FK * F_LD + lk * F_LD + wr * 32];         // B operand <- X_ik rows (tile row), rotated
+#pragma unroll
+    for (int ks = 0; ks < FK / 4; ++ks) {
+      double aop[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) aop[a] = pa[ks * 4 * F_LD + a * 16];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        double bop[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bop[t] = pb[ks * 4 * F_LD + b * 16 + rot[t]];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[a][b][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aop[a], bop[t], acc[a][b][t], 0, 0, 1);  // NEG: -A B
+      }
+      // one k-step's operands at a time (24 registers): left to itself the scheduler reads two steps ahead, runs out
+      // of the 128 registers and reloads a spilled index behind the transfers it has just issued -- with a vmcnt(0)
+      // that waits for THEM.  The other wave of the SIMD covers the read latency.
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next k-tile has landed (the only wait of the transfers)
+    __syncthreads();
+  }
+  // write-through (sc1 = the agent-scope relaxed store st_agent emits) in the base + 32-bit-offset form: through the
+  // atomic builtin the compiler materialises a 64-bit address per store, hoists all 32 in front of the k-loop and
+  // spills them (42 registers)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const char* cb = Cu + (int64_t(a * 16) * ld + b * 16) * 8;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(voff[t]), "v"(acc[a][b][t]), "s"(cb) : "memory");
+    }
 }
 
 // update(c, c, k): the diagonal tile (c, c) -= X_ck X_ck^T, lower 16 x 16 blocks only (potf2's fold: block pairs
@@ -847,12 +979,12 @@ struct ChainStream {
 // wave-level wait until *word has reached `want` within the same epoch (bounded: a lost producer poisons info);
 // returns what it saw, so that a reader that is several steps behind polls ONCE
 __device__ __forceinline__ uint32_t chain_wave_wait_ge(const uint32_t* word, uint32_t want, int32_t* info) {
+  PollClock clk;
   for (int spin = 0;; ++spin) {
     const uint32_t v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (int32_t(v - want) >= 0 && int32_t(v - want) < 128) return v;
     __builtin_amdgcn_s_sleep(1);
-    if ((spin & 255) == 255 &&
-        (spin >= (1 << 18) || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == STEP_TIMEOUT)) {
+    if ((spin & 255) == 255 && (clk.expired(spin) || poisoned(info))) {
       if ((threadIdx.x & 63) == 0) atomicExch(info, STEP_TIMEOUT);
       return want;
     }
@@ -866,12 +998,12 @@ __device__ __forceinline__ void chain_lds_barrier() {
 
 // wave-level wait until the counter *p (zeroed per launch) has reached `want`; returns what it saw
 __device__ __forceinline__ int chain_wave_wait_count(const int32_t* p, int want, int32_t* info) {
+  PollClock clk;
   for (int spin = 0;; ++spin) {
     const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v >= want) return v;
     __builtin_amdgcn_s_sleep(1);
-    if ((spin & 255) == 255 &&
-        (spin >= (1 << 18) || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == STEP_TIMEOUT)) {
+    if ((spin & 255) == 255 && (clk.expired(spin) || poisoned(info))) {
       if ((threadIdx.x & 63) == 0) atomicExch(info, STEP_TIMEOUT);
       return want;
     }
@@ -1064,7 +1196,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     chain_wait<8>(q.flags + i * CHAIN_FLAG_LD + k, E + CHAIN_FINAL, q.flags + c * CHAIN_FLAG_LD + k, E + CHAIN_FINAL,
                   k > q.cb ? wt : nullptr, E + uint32_t(k), q.info);
     chain_stamp(st, 1);  // operands final, the tile carries every earlier update
-    if (kind == 2) chain_update_full<T, 1>(q, S, i, c, k, 0);
+    if (kind == 2) {
+      if constexpr (sizeof(T) == 8) {
+        if (q.fast_update) chain_update_fast(q, S, i, c, k);
+        else chain_update_full<T, 1>(q, S, i, c, k, 0);
+      } else {
+        chain_update_full<T, 1>(q, S, i, c, k, 0);
+      }
+    }
     else if (kind == 4) chain_update_full<T, CHAIN_CRIT_PARTS>(q, S, i, c, k, __builtin_amdgcn_readfirstlane(s_task[5]));
     else chain_update_diag<T>(q, S, c, k);
     chain_stamp(st, 2);
@@ -1552,7 +1691,8 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
   // wait for block c of the solution (bounded: a lost producer must end in a NaN, never in a hung GPU)
   auto wait_x = [&](int c, int slot) {
     if (tid < 128) {
-      for (long spin = 0; xb == Sent<T>::value && spin < (1L << 26); ++spin) {
+      PollClock xclk;
+      for (long spin = 0; xb == Sent<T>::value && !xclk.expired(spin); ++spin) {
         if (spin) __builtin_amdgcn_s_sleep(1);
         xb = load_x_bits<T>(x + int64_t(c) * 128 + tid);
       }
@@ -1605,7 +1745,8 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
       T pv = T(0);
       if (b >= 3) {  // the helper's tiles b-3, b-5, ...: handed over one hop ago as a rule
         bits_t pb = Sent<T>::value;
-        for (long spin = 0; pb == Sent<T>::value && spin < (1L << 26); ++spin) {
+        PollClock pclk;
+        for (long spin = 0; pb == Sent<T>::value && !pclk.expired(spin); ++spin) {
           if (spin) __builtin_amdgcn_s_sleep(1);
           pb = load_x_bits<T>(part + int64_t(b) * 128 + tid);
         }
@@ -1740,7 +1881,8 @@ __global__ __launch_bounds__(512) void trsv_bwd_stream_kernel(int nblk, const T*
     if (next == 2) load_w(nxt);
     const int slot = (c >> 1) & 1;
     if (tid < 128) {
-      for (long spin = 0; xb == Sent<T>::value && spin < (1L << 26); ++spin) {
+      PollClock xclk;
+      for (long spin = 0; xb == Sent<T>::value && !xclk.expired(spin); ++spin) {
         if (spin) __builtin_amdgcn_s_sleep(1);
         xb = load_x_bits<T>(x + int64_t(c) * 128 + tid);
       }
@@ -1783,7 +1925,8 @@ __global__ __launch_bounds__(512) void trsv_bwd_stream_kernel(int nblk, const T*
       T pv = T(0);
       if (b + 2 <= nblk - 1) {  // the helper's tiles b+2, b+4, ...
         bits_t pb = Sent<T>::value;
-        for (long spin = 0; pb == Sent<T>::value && spin < (1L << 26); ++spin) {
+        PollClock pclk;
+        for (long spin = 0; pb == Sent<T>::value && !pclk.expired(spin); ++spin) {
           if (spin) __builtin_amdgcn_s_sleep(1);
           pb = load_x_bits<T>(part + int64_t(b) * 128 + tid);
         }
@@ -1846,6 +1989,14 @@ __global__ __launch_bounds__(512) void trsv_bwd_stream_kernel(int nblk, const T*
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
+int set_poll_limit(tgp_ctx* ctx, int64_t ms) {
+  TGP_ARG_CHECK(ms >= 1 && ms <= 3600000, "poll_timeout_ms must be in [1, 3600000]");
+  const long long ticks = (long long)ms * 100000LL;  // s_memrealtime: 100 MHz
+  TGP_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_poll_limit), &ticks, sizeof(ticks)));
+  ctx->poll_timeout_ms = ms;
+  return TGP_OK;
+}
+
 template <typename T>
 int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_t* info,
                  int32_t pivot_base, const T* Xp, int64_t ldx) {
@@ -1932,6 +2083,7 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
   q.cb = (int32_t)cb; q.ce = (int32_t)ce;
   q.stamps = nullptr;
   q.launch = (int32_t)ctx->chain_launches++;
+  q.fast_update = (int32_t)ctx->chain_fast_update;
   if (ctx->chain_stamps != 0 && ctx->chain_stamp_base + tasks <= CHAIN_STAMP_TASKS) {
     if (ctx->d_chain_stamps == nullptr)
       TGP_HIP_TRY(hipMalloc((void**)&ctx->d_chain_stamps, size_t(CHAIN_STAMP_TASKS) * 16 * sizeof(long long)));
@@ -1960,8 +2112,17 @@ int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, 
     return TGP_OK;
   }
   const int32_t target = (int32_t)(R - c - ((c == 0 && first_external) ? 1 : 0));
-  hipLaunchKernelGGL(chain_poll_kernel, dim3(1), dim3(64), 0, st, ctx->d_chain_ticket + CHAIN_COLCNT_OFF + c, target,
-                     ctx->d_info);
+  int32_t* count = ctx->d_chain_ticket + CHAIN_COLCNT_OFF + c;
+  if (ctx->chain_polls == 1 && ctx->can_wait_value) {
+    // Round 5: the wait sits in the COMMAND PROCESSOR (hipStreamWaitValue32 on plain device memory: no wave, no
+    // compute unit, nothing a kernel-serialising tool could run in front of the chain launch it waits for).  Measured
+    // hand-off, producer's atomic -> first instruction behind the wait: 1.35 us against the poll kernel's 1.55
+    // (profiles/r05_a, scripts/probe_waitvalue.hip).  The counters are zeroed on the chain's stream in front of
+    // `counters_ready`, which this stream has waited for.  chain_polls = 2 keeps round 4's one-wave poll kernel.
+    TGP_HIP_TRY(hipStreamWaitValue32(st, count, (uint32_t)target, hipStreamWaitValueGte, 0xffffffffu));
+    return TGP_OK;
+  }
+  hipLaunchKernelGGL(chain_poll_kernel, dim3(1), dim3(64), 0, st, count, target, ctx->d_info);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -2454,8 +2615,8 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     }
   }
   if (info == STEP_TIMEOUT) {
-    set_error("potrf: a panel step's hand-off flag never arrived (device-side timeout)");
-    return TGP_E_HIP;
+    set_error("potrf: a device-side hand-off did not arrive within poll_timeout_ms (a lost or starved chain launch)");
+    return TGP_E_TIMEOUT;
   }
   if (info_host) *info_host = info;
   return info > 0 ? info : TGP_OK;

@@ -131,6 +131,7 @@ struct tgp_ctx {
   int64_t chain_kernel = 1;
   uint32_t* d_chain_flags = nullptr;  // CHAIN_MAX_ROW_TILES x 64 words, zero at allocation, never reset (epochs)
   int32_t* d_chain_ticket = nullptr;  // [0] ticket counter, [16 + c] final tiles of block column c: zeroed per launch
+  int64_t chain_fast_update = 1;      // fp64 whole-tile update tasks on the 4x4x4 MFMA form with LDS-direct staging (0: round 4's)
   int64_t chain_full_rows = 4096;     // with at most this many rows left the WHOLE rest is one chain launch (measured
                                       // at N = 16 384: 4096 26.6 ms, 6144 26.9, 8192 27.6; per-block chain 28.2)
   int64_t chain_depth2 = 1;           // gate + chain of the next panel on the priority stream, two panels ahead
@@ -138,7 +139,14 @@ struct tgp_ctx {
   // the next panel's first potf2 -- issued at once it fills every compute unit with three 48-KB workgroups, and the
   // one-workgroup potf2 (74 KB) on the chain pipeline waited 120-290 us for room (profiles/r04_c)
   int64_t kmat_plain_div = 0;    // tests: the assembly's quotients by the division instruction sequence (kmat.hip, UDiv)
-  int64_t chain_polls = 1;       // 0: forward steps / early shares behind the chain launch (kernel-serialising profilers)
+  // followers of a chain launch (forward-substitution steps, early shares) start while it runs, behind
+  // 1: a stream wait-value on the block column's counter (command processor; round 5 default), 2: round 4's one-wave
+  // poll kernel; 0: they wait for the whole launch
+  int64_t chain_polls = 1;
+  bool has_device = false;       // (false: the schedule tracer's context, tgp_trace_factor)
+  bool can_wait_value = false;   // hipDeviceAttributeCanUseStreamWaitValue (else chain_polls 1 falls back to the poll kernel)
+  int64_t poll_timeout_ms = 4000;  // wall-clock bound of every device-side wait (chol.hip, PollClock)
+  int64_t timeout_retries = 0;     // factorisations repeated on the launch-per-block path after a TGP_E_TIMEOUT
   int64_t chain_pre_wait = 0;  // (measured: no effect at N = 16 384, -3 % at N = 8 192 -- off)
   int64_t chain_lds_pad = 10240;      // dynamic LDS per chain workgroup that nobody uses: one chain workgroup per CU
   int64_t chain_stamps = 0;           // 1: every chain task records its phases' time stamps (tgp_chain_stamps)
@@ -292,6 +300,7 @@ template <typename T>
 int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int64_t pivot_base, int64_t R,
                  int64_t nblk, int64_t cb, int64_t ce, bool head_done, hipEvent_t counters_ready = nullptr);
 int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, int64_t R, int64_t c, bool first_external);
+int set_poll_limit(tgp_ctx* ctx, int64_t ms);
 template <typename T>
 int panel_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int64_t pivot_off,
                 int64_t j0, bool pend);
