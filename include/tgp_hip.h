@@ -35,8 +35,10 @@ extern "C" {
 /* bumped whenever an exported signature or option changes; the Python binding refuses another version
  * (round 2 -> 3: tgp_trace_factor gained nb_wide_rows, ~15 entry points added, "potf2_sync" removed;
  *  round 3 -> 4: tgp_chain_stamps, tgp_chain_task, the resident-factor solves of the block-column driver -- tgp_dist_fwd_block,
- *  _bwd_block, _trmv_partial, _cross_cov, _colsumsq_owned, _gram_owned -- and tgp_dist_abort added) */
-#define TGP_ABI_VERSION 4
+ *  _bwd_block, _trmv_partial, _cross_cov, _colsumsq_owned, _gram_owned -- and tgp_dist_abort added;
+ *  round 4 -> 5: tgp_comm_* (RCCL from the C ABI), tgp_stream_* transfers, TGP_E_TIMEOUT, options poll_timeout_ms /
+ *  chain_fast_update, chain_polls = 1 now means a stream wait-value) */
+#define TGP_ABI_VERSION 5
 
 /* element types: follows the dtype of the caller's arrays (gp.py:89) */
 #define TGP_F32 0
@@ -438,6 +440,39 @@ int tgp_chain_stamps(tgp_ctx* ctx, int64_t* out, int64_t cap_tasks, int64_t* n_t
  * 4 a part (an eighth) of an update | 5 xsolve.  tests/test_chain_tasks.py checks on the CPU that every task of a launch
  * exists exactly once and waits for EARLIER tickets only. */
 int tgp_chain_task(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t ticket, int32_t* out5, int64_t* n_tasks);
+
+/* ---- RCCL from the C ABI (round 5) -------------------------------------------------------------------------------
+ * The block-column driver's collectives -- north_star's "RCCL broadcast of the current panel and reduce of the solve
+ * RHS over xGMI" -- issued by the library itself on ITS streams, on plain device pointers: no torch.distributed process
+ * group between the panel chain and the wire.  The reference has no multi-device code; the Python side of the seam is
+ * tinygp_amd/comm.py (RcclComm) under tinygp_amd/distributed.py.
+ *
+ * A communicator is one rank of `world` (one process per GPU).  Rank 0 calls tgp_comm_unique_id and the CALLER hands the
+ * 128 bytes to every rank (TCP on MASTER_ADDR, a shared file, any launcher-side channel); every rank then calls
+ * tgp_comm_create (collective: it returns when all ranks have joined).  librccl is loaded on first use.
+ * Collectives are IN PLACE on `count` elements of `dtype` at the device pointer `buf`, enqueued on stream `which` of
+ * the context (0 main, 1 priority/panel) and asynchronous.  tgp_comm_record / _wait order the two streams against each
+ * other without a host block ("the panel broadcast on the priority stream has arrived" -> main stream). */
+#define TGP_COMM_ID_BYTES 128
+typedef struct tgp_comm tgp_comm;
+int tgp_comm_unique_id(void* id_out /* TGP_COMM_ID_BYTES */, int32_t* rccl_version_out /* or NULL */);
+int tgp_comm_create(tgp_ctx* ctx, int32_t world, int32_t rank, const void* id, tgp_comm** out);
+int tgp_comm_destroy(tgp_comm* c);
+int tgp_comm_info(tgp_comm* c, int32_t* world, int32_t* rank);
+int tgp_comm_broadcast(tgp_comm* c, int which, void* buf, int64_t count, int dtype, int32_t root);
+int tgp_comm_reduce(tgp_comm* c, int which, void* buf, int64_t count, int dtype, int32_t root); /* sum, to root */
+int tgp_comm_all_reduce(tgp_comm* c, int which, void* buf, int64_t count, int dtype, int32_t op); /* 0 sum 1 min 2 max */
+int tgp_comm_record(tgp_comm* c, int which, int64_t* ticket);
+int tgp_comm_wait(tgp_comm* c, int which, int64_t ticket);
+
+/* Transfers addressed to a stream of the context (0 main, 1 priority): the driver's host side owns plain device
+ * buffers (tgp_malloc) and must order its fills and copies against the kernels and collectives of THAT stream.
+ * h2d / d2h return when the host buffer may be reused / holds the data; d2d and memset are asynchronous. */
+int tgp_stream_h2d(tgp_ctx* ctx, int which, void* dst_dev, const void* src_host, int64_t bytes);
+int tgp_stream_d2h(tgp_ctx* ctx, int which, void* dst_host, const void* src_dev, int64_t bytes);
+int tgp_stream_d2d(tgp_ctx* ctx, int which, void* dst_dev, const void* src_dev, int64_t bytes);
+int tgp_stream_memset(tgp_ctx* ctx, int which, void* dst_dev, int byte, int64_t bytes);
+int tgp_stream_sync(tgp_ctx* ctx, int which);
 
 #ifdef __cplusplus
 }

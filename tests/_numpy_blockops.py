@@ -43,6 +43,9 @@ class NumpyBlockOps:
         end = rows * self.nb + self.nd if c == nch - 1 else (c + 1) * cw * rows
         return self.ring[k % 3][c * cw * rows: end]
 
+    def nbytes_of(self, buf):
+        return buf.numel() * buf.element_size()
+
     def x_slice(self, k):
         return self.x[k * self.nb:(k + 1) * self.nb]
 

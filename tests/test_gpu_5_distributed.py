@@ -1,7 +1,8 @@
 """The block-cyclic driver with the REAL per-rank operations (HipBlockOps: csrc/dist.hip through
-the C ABI, torch CUDA buffers for the ring slots, RCCL collectives ordered against the driver's
-streams) on the one GPU a test box has: world size 1, so every panel is 'broadcast' to itself
-and every collective still goes through RCCL.  Multi-rank schedule logic is covered on CPU
+the C ABI, plain device buffers of the library for the ring slots, RCCL collectives issued BY THE LIBRARY on the
+driver's streams -- csrc/comm.hip, tinygp_amd.comm.RcclComm) on the one GPU a test box has: world size 1, so every
+panel is 'broadcast' to itself and every collective still goes through RCCL.  The module's torch.distributed group
+carries ONE message per solver, the communicator id; `test_rccl_from_the_c_abi_without_torch*` run with no torch at all.  Multi-rank schedule logic is covered on CPU
 under gloo (tests/test_distributed_cpu.py); 8-GPU runs are the driver's."""
 import os
 
@@ -217,3 +218,74 @@ def test_config4_n131072_block_column_driver_full_size(pg, golden_dir):
     import torch
 
     torch.cuda.empty_cache()
+
+
+_NO_TORCH = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["TGP_ROOT"]); sys.path.insert(0, os.path.join(os.environ["TGP_ROOT"], "tests"))
+from tinygp_amd import _ffi, kernels, synthetic
+from tinygp_amd.comm import RcclComm
+from tinygp_amd.distributed import BlockCyclicCholesky, HipBlockOps
+n, nb = 5000, 512
+X, y = synthetic.make_inputs(n, 1)
+k = 1.5**2 * kernels.ExpSquared(2.5) + 0.3 * kernels.Matern32(1.2)
+ops = HipBlockOps(0)
+mode = os.environ["TGP_TEST_COMM"]
+if mode == "env":
+    comm = None                                    # the default: RANK / WORLD_SIZE / MASTER_* of the launcher, TCP
+elif mode == "file":
+    comm = RcclComm.from_file(ops.ctx, os.environ["TGP_TEST_ID_FILE"], 1, 0)
+s = BlockCyclicCholesky(k, X, np.full(n, 0.01), nb=nb, ops=ops, comm=comm)
+assert type(s.comm).__name__ == "RcclComm" and (s.comm.rank, s.comm.world) == (0, 1)
+ll = s.log_probability(y)
+xt = np.linspace(X[0], X[-1], 37)
+mean = s.condition_mean(y, xt)
+Y = np.random.default_rng(5).normal(size=(n, 3))
+fwd = s.solve_triangular(Y)
+bwd = s.solve_triangular(y, transpose=True)
+var = s.condition_colsumsq(xt)
+ll2 = s.resident_log_probability(2.0 * y)
+assert "torch" not in sys.modules, "torch was imported on the RCCL-from-the-C-ABI path"
+maps = open("/proc/self/maps").read()
+assert "librccl" in maps and len(_ffi._mapped_hip_runtimes()) == 1
+np.savez(os.environ["TGP_TEST_OUT"], ll=ll, mean=mean, fwd=fwd, bwd=bwd, var=var, ll2=ll2, info=s.info)
+s.ops.close()
+print("OK")
+"""
+
+
+@pytest.mark.parametrize("mode", ["env", "file"])
+def test_rccl_from_the_c_abi_without_torch(mode, tmp_path):
+    """the library issues ncclBroadcast / ncclReduce / ncclAllReduce itself; the communicator id comes
+    from the launcher's environment (TCP) or a file -- no torch in the process, ONE HIP runtime, results vs LAPACK."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    import scipy.linalg as sla
+
+    root = Path(__file__).resolve().parent.parent
+    out = tmp_path / "res.npz"
+    env = dict(os.environ, TGP_ROOT=str(root), TGP_TEST_COMM=mode, TGP_TEST_OUT=str(out), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", TGP_TEST_ID_FILE=str(tmp_path / "id"))
+    env.pop("PYTHONPATH", None)
+    r = subprocess.run([sys.executable, "-c", _NO_TORCH], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    got = np.load(out)
+    n = 5000
+    X, y = _cases.synthetic.make_inputs(n, 1)
+    ref = o.GaussianProcess(_k(o), X, diag=0.01)
+    L = ref.solver.scale_tril
+    assert int(got["info"]) == 0
+    np.testing.assert_allclose(got["ll"], float(ref.log_probability(y)), rtol=1e-8)
+    xt = np.linspace(X[0], X[-1], 37)
+    np.testing.assert_allclose(got["mean"], ref.predict(y, xt), rtol=5e-7, atol=5e-7)
+    Y = np.random.default_rng(5).normal(size=(n, 3))
+    np.testing.assert_allclose(got["fwd"], sla.solve_triangular(L, Y, lower=True), rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(got["bwd"], sla.solve_triangular(L, y, lower=True, trans=1), rtol=1e-7, atol=1e-7)
+    A = sla.solve_triangular(L, _k(o)(X, xt), lower=True)
+    np.testing.assert_allclose(got["var"], np.sum(A * A, axis=0), rtol=5e-7, atol=5e-7)
+    a = sla.solve_triangular(L, 2.0 * y, lower=True)
+    want2 = -0.5 * a @ a - np.sum(np.log(np.diag(L))) - 0.5 * n * np.log(2 * np.pi)
+    np.testing.assert_allclose(got["ll2"], want2, rtol=1e-8)

@@ -126,10 +126,24 @@ SIGNATURES = {
     "tgp_dist_colsumsq_owned": [_vp, _i64, _vp, _vp],
     "tgp_dist_gram_owned": [_vp, _i64, _vp, _vp],
     "tgp_dist_abort": [_vp],
+    "tgp_comm_unique_id": [_vp, _pi32],
+    "tgp_comm_create": [_vp, _i32, _i32, _vp, _pvp],
+    "tgp_comm_destroy": [_vp],
+    "tgp_comm_info": [_vp, _pi32, _pi32],
+    "tgp_comm_broadcast": [_vp, _int, _vp, _i64, _int, _i32],
+    "tgp_comm_reduce": [_vp, _int, _vp, _i64, _int, _i32],
+    "tgp_comm_all_reduce": [_vp, _int, _vp, _i64, _int, _i32],
+    "tgp_comm_record": [_vp, _int, _pi64],
+    "tgp_comm_wait": [_vp, _int, _i64],
+    "tgp_stream_h2d": [_vp, _int, _vp, _vp, _i64],
+    "tgp_stream_d2h": [_vp, _int, _vp, _vp, _i64],
+    "tgp_stream_d2d": [_vp, _int, _vp, _vp, _i64],
+    "tgp_stream_memset": [_vp, _int, _vp, _int, _i64],
+    "tgp_stream_sync": [_vp, _int],
 }
 
 
-ABI_VERSION = 4  # TGP_ABI_VERSION of include/tgp_hip.h
+ABI_VERSION = 5  # TGP_ABI_VERSION of include/tgp_hip.h
 
 
 def _mapped_hip_runtimes() -> list[str]:

@@ -166,6 +166,20 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
     (void)hipGetLastError();
     ctx->can_wait_value = can == 1;
   }
+  {
+    // A profiler that collects hardware counters (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION in the profiled
+    // process) runs kernels one at a time in an order of its own: followers that wait for a chain launch of ANOTHER
+    // stream -- by a poll kernel or by a stream wait-value -- can then be scheduled in front of it for good (measured:
+    // profiles/r05_b).  Under such a tool the followers go behind the whole launch (chain_polls = 0) unless the caller
+    // sets the option; TGP_SERIALIZED_KERNELS=1 says the same for tools this check does not know.
+    const char* a = getenv("ROCPROF_COUNTER_COLLECTION");
+    const char* b = getenv("TGP_SERIALIZED_KERNELS");
+    auto on = [](const char* v) { return v != nullptr && *v && strcmp(v, "0") != 0 && strcasecmp(v, "false") != 0; };
+    if (on(a) || on(b)) {
+      ctx->serializing_tool = true;
+      ctx->chain_polls = 0;
+    }
+  }
   TGP_HIP_TRY(hipStreamCreateWithPriority(&ctx->panel_stream, hipStreamNonBlocking, hi));
   // (the solve stream is created on first use -- ensure_solve_stream: a FIFTH stream in use costs every
   // dependent launch of the panel chains, profiles/r02_m_stream_count.txt, and the default schedule
@@ -180,6 +194,7 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_g2, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_h, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
   TGP_HIP_TRY(hipMalloc(&ctx->d_scal, 16 * sizeof(double)));
@@ -207,6 +222,8 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
     hipStreamDestroy(ctx->solve_stream);
   }
   if (ctx->ev_c) hipEventDestroy(ctx->ev_c);
+  if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+  if (ctx->rescue_stream) hipStreamDestroy(ctx->rescue_stream);
   if (ctx->update_stream) {
     hipStreamSynchronize(ctx->update_stream);
     hipStreamDestroy(ctx->update_stream);
@@ -276,6 +293,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "nb_first")) return &ctx->nb_first;
   if (!strcmp(key, "split_tail")) return &ctx->split_tail;
   if (!strcmp(key, "gemm_role")) return &ctx->gemm_role;
+  if (!strcmp(key, "host_join")) return &ctx->host_join;
   if (!strcmp(key, "poll_timeout_ms")) return &ctx->poll_timeout_ms;
   if (!strcmp(key, "timeout_retries")) return &ctx->timeout_retries;  // (read: passes repeated after a device-side timeout)
   return nullptr;

@@ -19,6 +19,8 @@
 #include <functional>
 #include <type_traits>
 
+#include <thread>
+
 #include "tgp_common.h"
 #define CHAIN_HD __host__ __device__
 #include "chain_tasks.h"
@@ -1997,6 +1999,41 @@ int set_poll_limit(tgp_ctx* ctx, int64_t ms) {
   return TGP_OK;
 }
 
+// A stream wait-value has no timeout of its own: if the chain launch it waits for never makes progress (a tool that holds
+// kernels back in an order of its own -- rocprofv3 --pmc hung exactly here, profiles/r05_b -- or a launch that was lost),
+// hipStreamSynchronize would block for ever.  So a factorisation that enqueued wait-values is joined with a DEADLINE: the
+// host polls an event (busy for the first 50 ms -- no latency added to evaluations up to N ~ 16 k --, then every 200 us);
+// past poll_timeout_ms + 3 x the time of N^3 / 3 flops at 20 TFLOP/s it releases every pending wait itself
+// (hipStreamWriteValue32 from a rescue stream: command-processor writes, no kernel), joins all streams and reports
+// TGP_E_TIMEOUT -- tgp_solver_factor* then repeats the pass on the launch-per-block path, which has no device-side waits.
+int join_bounded(tgp_ctx* ctx, hipStream_t st, int64_t n) {
+  TGP_TRY(ev_record(ctx, ctx->ev_join, st));
+  const auto t0 = std::chrono::steady_clock::now();
+  const double budget_ms = double(ctx->poll_timeout_ms) + 3.0 * (double(n) * double(n) * double(n) / 3.0) / 2e13 * 1e3;
+  for (long spin = 0;; ++spin) {
+    const hipError_t e = hipEventQuery(ctx->ev_join);
+    if (e == hipSuccess) return TGP_OK;
+    if (e != hipErrorNotReady) {
+      set_error("hipEventQuery failed: %s", hipGetErrorString(e));
+      return TGP_E_HIP;
+    }
+    (void)hipGetLastError();
+    if ((spin & 63) != 63) continue;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > budget_ms) break;
+    if (ms > 50.0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+  // rescue: satisfy every wait on the block columns' counters, then drain
+  if (ctx->rescue_stream == nullptr) TGP_HIP_TRY(hipStreamCreateWithFlags(&ctx->rescue_stream, hipStreamNonBlocking));
+  for (int c = 0; c < CHAIN_FLAG_LD; ++c)
+    (void)hipStreamWriteValue32(ctx->rescue_stream, ctx->d_chain_ticket + CHAIN_COLCNT_OFF + c, 0x7fffffffu, 0);
+  for (hipStream_t q : {ctx->rescue_stream, ctx->asm_stream, ctx->panel_stream, ctx->update_stream, ctx->solve_stream, ctx->stream})
+    if (q) (void)hipStreamSynchronize(q);
+  (void)hipGetLastError();
+  set_error("potrf: the followers of a chain launch were still waiting after %.0f ms (stream wait-values released by the host)", budget_ms);
+  return TGP_E_TIMEOUT;
+}
+
 template <typename T>
 int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_t* info,
                  int32_t pivot_base, const T* Xp, int64_t ldx) {
@@ -2114,6 +2151,7 @@ int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, 
   const int32_t target = (int32_t)(R - c - ((c == 0 && first_external) ? 1 : 0));
   int32_t* count = ctx->d_chain_ticket + CHAIN_COLCNT_OFF + c;
   if (ctx->chain_polls == 1 && ctx->can_wait_value) {
+    ctx->wait_values_inflight = true;  // the host joins this factorisation with a deadline (join_bounded)
     // Round 5: the wait sits in the COMMAND PROCESSOR (hipStreamWaitValue32 on plain device memory: no wave, no
     // compute unit, nothing a kernel-serialising tool could run in front of the chain launch it waits for).  Measured
     // hand-off, producer's atomic -> first instruction behind the wait: 1.35 us against the poll kernel's 1.55
@@ -2596,7 +2634,13 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   ctx->submitted = std::chrono::steady_clock::now();
   if (!ctx->trace) {
     TGP_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, S0));
-    TGP_HIP_TRY(hipStreamSynchronize(S0));
+    if (ctx->wait_values_inflight && ctx->host_join != 0) {
+      ctx->wait_values_inflight = false;
+      TGP_TRY(join_bounded(ctx, S0, n));
+    } else {
+      ctx->wait_values_inflight = false;
+      TGP_HIP_TRY(hipStreamSynchronize(S0));
+    }
   }
   if (prof_on) {
     ctx->prof_syrk_ms = 0;

@@ -131,7 +131,11 @@ struct tgp_ctx {
   int64_t chain_kernel = 1;
   uint32_t* d_chain_flags = nullptr;  // CHAIN_MAX_ROW_TILES x 64 words, zero at allocation, never reset (epochs)
   int32_t* d_chain_ticket = nullptr;  // [0] ticket counter, [16 + c] final tiles of block column c: zeroed per launch
-  int64_t chain_fast_update = 1;      // fp64 whole-tile update tasks on the 4x4x4 MFMA form with LDS-direct staging (0: round 4's)
+  // fp64 whole-tile update tasks on the 4x4x4 MFMA form with LDS-direct staging (chain_update_fast).  MEASURED, OFF
+  // (profiles/r05_b): no spill any more, but a task takes 22-25 us + 4-6 us publish against 20-21 + 1.7 for round 4's
+  // form -- the task is bound by its prologue (tile + first operands: one round trip), the per-k-step LDS latency under the
+  // 128-register cap and 32 scattered 8-byte write-through stores per lane, not by the MFMA form; c2 26.1 vs 25.5 ms
+  int64_t chain_fast_update = 0;
   int64_t chain_full_rows = 4096;     // with at most this many rows left the WHOLE rest is one chain launch (measured
                                       // at N = 16 384: 4096 26.6 ms, 6144 26.9, 8192 27.6; per-block chain 28.2)
   int64_t chain_depth2 = 1;           // gate + chain of the next panel on the priority stream, two panels ahead
@@ -143,6 +147,11 @@ struct tgp_ctx {
   // 1: a stream wait-value on the block column's counter (command processor; round 5 default), 2: round 4's one-wave
   // poll kernel; 0: they wait for the whole launch
   int64_t chain_polls = 1;
+  bool wait_values_inflight = false;  // this factorisation enqueued stream wait-values: join with a deadline (join_bounded)
+  int64_t host_join = 1;         // 0: plain hipStreamSynchronize even then (A/B of the polling join)
+  bool serializing_tool = false; // a counter-collecting profiler is attached (ROCPROF_COUNTER_COLLECTION): chain_polls defaults to 0
+  hipStream_t rescue_stream = nullptr;
+  hipEvent_t ev_join = nullptr;
   bool has_device = false;       // (false: the schedule tracer's context, tgp_trace_factor)
   bool can_wait_value = false;   // hipDeviceAttributeCanUseStreamWaitValue (else chain_polls 1 falls back to the poll kernel)
   int64_t poll_timeout_ms = 4000;  // wall-clock bound of every device-side wait (chol.hip, PollClock)
@@ -301,6 +310,7 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
                  int64_t nblk, int64_t cb, int64_t ce, bool head_done, hipEvent_t counters_ready = nullptr);
 int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, int64_t R, int64_t c, bool first_external);
 int set_poll_limit(tgp_ctx* ctx, int64_t ms);
+int join_bounded(tgp_ctx* ctx, hipStream_t st, int64_t n);
 template <typename T>
 int panel_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int64_t pivot_off,
                 int64_t j0, bool pend);

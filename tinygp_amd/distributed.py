@@ -8,9 +8,9 @@ The reference has no multi-device code at all; this is new design for MI355X + R
   "1-D block-column").  A rank holds its block columns side by side in one column-major device
   matrix (``csrc/dist.hip``);
 * step ``k``: the owner factors panel ``k`` with the single-GPU panel chain on its priority
-  stream and packs it into a ring slot; the slot is **broadcast** (``torch.distributed.broadcast``
-  = ``ncclBroadcast`` over xGMI); every rank updates its own block columns with ONE MFMA launch
-  over all of them;
+  stream and packs it into a ring slot; the slot is **broadcast** (``ncclBroadcast`` over xGMI, issued by the
+  library itself on that stream: ``csrc/comm.hip``, :class:`tinygp_amd.comm.RcclComm`); every rank updates its own
+  block columns with ONE MFMA launch over all of them;
 * look-ahead of depth 2 (round 3): the CHAIN PIPELINE -- arrival of panel ``k`` -> gate (panel ``k`` applied to
   block column ``k+1``) -> chain of panel ``k+1`` -> pack -> broadcast -- lives on the owner's priority stream
   and depends on the main stream only through the small *pre-update* that brought block column ``k+1`` up to
@@ -26,22 +26,21 @@ The reference has no multi-device code at all; this is new design for MI355X + R
   solved ``nb``-slice broadcast to all; then every rank evaluates ``K(X*, X_owned) alpha_owned``
   (fused, K* never formed) and ONE all-reduce of the (M,) vector finishes the job.
 
-One process per GPU.  The schedule below is written against a small per-rank operations
-interface: :class:`HipBlockOps` (the product: ``tgp_dist_*`` of ``libtgp_hip.so`` on device
-buffers owned by torch so that RCCL can send them) and, in ``tests/`` only, a NumPy stand-in
-that lets the same schedule run under ``gloo`` on CPUs.
+One process per GPU.  The schedule below is written against two small interfaces: the per-rank operations --
+:class:`HipBlockOps` (the product: ``tgp_dist_*`` of ``libtgp_hip.so`` on plain device buffers of the library) and, in
+``tests/`` only, a NumPy stand-in that lets the same schedule run under ``gloo`` on CPUs -- and the collectives
+(:mod:`tinygp_amd.comm`: RCCL from the C ABI; torch is not on the data path and not needed at all with
+``RcclComm.from_env`` / ``from_file``).
 
-Stream contract with RCCL (``torch.distributed`` makes a collective wait for the CURRENT
-stream at call time, and ``work.wait()`` makes the current stream wait for the collective):
-every rank issues the broadcast of a chunk under its PANEL stream -- the owner behind the pack of
-that chunk, a receiver behind the last readers of the slot (``slot_ready``); the owner of the NEXT
-panel waits for the arrival under its PANEL stream (gate + chain), everyone under the MAIN stream
-(forward step, updates).
+Stream contract: a collective is enqueued ON a stream of the library and is ordered like a kernel there; every rank
+issues the broadcast of a chunk on its PANEL stream -- the owner behind the pack of that chunk, a receiver behind the last
+readers of the slot (``slot_ready``); ``work.wait(stream)`` makes a stream wait for the broadcast (an event, no host
+block): the owner of the NEXT panel waits on its PANEL stream (gate + chain), everyone on the MAIN stream (forward step,
+updates).  Reductions of the resident-factor solves run on the MAIN stream, in order with the kernels around them.
 """
 
 from __future__ import annotations
 
-import contextlib
 import ctypes as C
 import math
 import os
@@ -55,90 +54,116 @@ __all__ = ["HipBlockOps", "BlockCyclicCholesky"]
 MAIN, PANEL = 0, 1
 
 
-class _Done:
-    """Stand-in for a collective's work handle when there is nobody to talk to: wait() orders the
-    current stream behind everything queued so far on the stream the data was produced on."""
+class DevBuf:
+    """A device buffer of the library (``tgp_malloc``) or a contiguous view into one: ``count`` elements of ``dtype`` at
+    ``ptr``, logically ``shape`` (row-major).  Owning buffers go back to their :class:`HipBlockOps`' pool when the last
+    reference dies; everything that touches them is ordered on the driver's MAIN stream, so re-use is stream-ordered."""
 
-    def __init__(self, ops, which):
-        self.ops = ops
-        self.ev = None
-        if hasattr(ops, "streams"):  # (the CPU stand-in of the tests is synchronous)
-            self.ev = ops.torch.cuda.Event()
-            self.ev.record(ops.streams[which])
+    __slots__ = ("ops", "ptr", "shape", "dtype", "code", "count", "_own", "_base")
 
-    def wait(self):
-        if self.ev is not None:
-            self.ops.torch.cuda.current_stream().wait_event(self.ev)
+    def __init__(self, ops, ptr, shape, dtype, own=False, base=None):
+        self.ops, self.ptr, self.shape, self.dtype = ops, int(ptr), tuple(shape), np.dtype(dtype)
+        self.code = _ffi.dtype_code(self.dtype)
+        self.count = int(np.prod(self.shape)) if self.shape else 1
+        self._own, self._base = own, base  # a view keeps its base alive
+
+    @property
+    def nbytes(self) -> int:
+        return self.count * self.dtype.itemsize
+
+    def rows(self, r0: int, r1: int) -> "DevBuf":
+        """Rows [r0, r1) of the leading axis (contiguous in a row-major buffer)."""
+        per = self.count // self.shape[0]
+        return DevBuf(self.ops, self.ptr + r0 * per * self.dtype.itemsize, (r1 - r0,) + self.shape[1:], self.dtype,
+                      base=self)
+
+    def flat(self, e0: int, e1: int) -> "DevBuf":
+        return DevBuf(self.ops, self.ptr + e0 * self.dtype.itemsize, (e1 - e0,), self.dtype, base=self)
+
+    def __del__(self):  # pragma: no cover
+        if self._own:
+            try:
+                self.ops._release(self.ptr, self.nbytes)
+            except Exception:
+                pass
 
 
 class HipBlockOps:
-    """One rank's device state: a ``tgp_dist`` handle + the torch tensors RCCL sends."""
+    """One rank's device state: a ``tgp_dist`` handle + the plain device buffers its collectives send."""
 
     def __init__(self, device: int):
-        import torch
-
-        self.torch = torch
-        self.device = torch.device("cuda", device)
-        torch.cuda.set_device(self.device)
         self.ctx = _ffi.Ctx(device=device)
         self.lib = _ffi.lib()
+        self.device = device
         self.h = None
+        self._pool = {}   # nbytes -> [ptr, ...]: released buffers (every use is ordered on the MAIN stream)
+        self._pool_bytes = 0
+
+    # -- buffers ---------------------------------------------------------------------------
+    POOL_LIMIT = 8 << 30
+
+    def _alloc(self, shape, dtype=None, zero=False) -> DevBuf:
+        dtype = self.dtype if dtype is None else np.dtype(dtype)
+        nbytes = max(int(np.prod(shape)) * dtype.itemsize, 8)
+        free = self._pool.get(nbytes)
+        if free:
+            ptr = free.pop()
+            self._pool_bytes -= nbytes
+        else:
+            ptr = self.ctx.malloc(nbytes)
+        buf = DevBuf(self, ptr, shape, dtype, own=True)
+        if zero:
+            _ffi.check(self.lib.tgp_stream_memset(self.ctx.handle, MAIN, C.c_void_p(ptr), 0, buf.nbytes),
+                       "tgp_stream_memset")
+        return buf
+
+    def _release(self, ptr: int, nbytes: int):
+        nbytes = max(nbytes, 8)
+        if self.ctx.handle is None:
+            return
+        if self._pool_bytes + nbytes > self.POOL_LIMIT:
+            self.ctx.free(ptr)  # (joins the main stream first)
+            return
+        self._pool.setdefault(nbytes, []).append(ptr)
+        self._pool_bytes += nbytes
 
     # -- set-up ------------------------------------------------------------------------
     def setup(self, P: np.ndarray, noise_diag: np.ndarray, nb: int, world: int, rank: int):
-        torch, lib = self.torch, self.lib
+        lib = self.lib
         n, d = P.shape
-        self.dtype = P.dtype
+        self.dtype = np.dtype(P.dtype)
         self.nb, self.n = nb, n
-        tdt = torch.float64 if P.dtype == np.float64 else torch.float32
         nslot = lib.tgp_dist_slot_elems(n, nb)
         self.nd = (nb // 128) * 2048
         self.npad = -(-n // nb) * nb
-        self.ring = [torch.empty(nslot, dtype=tdt, device=self.device) for _ in range(3)]
-        self.x = torch.zeros(self.npad, dtype=tdt, device=self.device)
-        torch.cuda.synchronize(self.device)
+        self.ring = [self._alloc((nslot,)) for _ in range(3)]
+        self.x = self._alloc((self.npad,), zero=True)
+        _ffi.check(lib.tgp_stream_sync(self.ctx.handle, MAIN), "tgp_stream_sync")
         h = C.c_void_p()
         _ffi.check(lib.tgp_dist_create(self.ctx.handle, _ffi.dtype_code(P.dtype), n, d, _ffi.ptr(P),
                                        _ffi.ptr(noise_diag), nb, world, rank,
-                                       C.c_void_p(self.ring[0].data_ptr()),
-                                       C.c_void_p(self.ring[1].data_ptr()),
-                                       C.c_void_p(self.ring[2].data_ptr()),
-                                       C.c_void_p(self.x.data_ptr()), C.byref(h)), "tgp_dist_create")
+                                       C.c_void_p(self.ring[0].ptr), C.c_void_p(self.ring[1].ptr),
+                                       C.c_void_p(self.ring[2].ptr), C.c_void_p(self.x.ptr), C.byref(h)), "tgp_dist_create")
         self.h = h
-        self.streams = []
-        for which in (MAIN, PANEL):
-            s = C.c_void_p()
-            _ffi.check(lib.tgp_dist_stream(h, which, C.byref(s)), "tgp_dist_stream")
-            self.streams.append(torch.cuda.ExternalStream(s.value, device=self.device))
-
-    def stream(self, which: int):
-        """Context manager: collectives issued inside order against that stream of the driver."""
-        return self.torch.cuda.stream(self.streams[which])
 
     def slot(self, k: int, rows: int):
         """The broadcast buffer of panel k: [rows x nb panel, ld = rows | dinv]."""
-        return self.ring[k % 3][: rows * self.nb + self.nd]
+        return self.ring[k % 3].flat(0, rows * self.nb + self.nd)
 
     def slot_chunk(self, k: int, rows: int, c: int, nch: int):
         """Column chunk c of nch of that buffer (contiguous); the last one carries the inverses."""
         cw = self.nb // nch
         end = rows * self.nb + self.nd if c == nch - 1 else (c + 1) * cw * rows
-        return self.ring[k % 3][c * cw * rows: end]
+        return self.ring[k % 3].flat(c * cw * rows, end)
+
+    def nbytes_of(self, buf) -> int:
+        return buf.nbytes
 
     def x_slice(self, k: int):
-        return self.x[k * self.nb:(k + 1) * self.nb]
-
-    # Every allocation, fill and copy that feeds kernels of the handle is issued UNDER the handle's main stream: that
-    # stream is created non-blocking, so torch's current (legacy null) stream does not order against it -- a zero-fill
-    # could land behind the first kernel that writes the buffer, a copy in front of the solve that produces its source
-    # (advisor r4, high).  The caching allocator then also ties the blocks to the stream their kernels run on.
-    def scalar(self, v: float):
-        with self.stream(MAIN):
-            return self.torch.tensor([v], dtype=self.torch.float64, device=self.device)
+        return self.x.rows(k * self.nb, (k + 1) * self.nb)
 
     def empty_vec(self, m: int):
-        with self.stream(MAIN):
-            return self.torch.empty(m, dtype=self.x.dtype, device=self.device)
+        return self._alloc((m,))
 
     # -- per-step calls (all asynchronous) ---------------------------------------------------
     def assemble(self, prog):
@@ -184,15 +209,13 @@ class HipBlockOps:
         kp, nops = _ffi.as_kprog(prog)
         out = self.empty_vec(Pt.shape[0])
         _ffi.check(self.lib.tgp_dist_cond_mean_partial(self.h, kp, nops, Pt.shape[0], _ffi.ptr(Pt),
-                                                       C.c_void_p(out.data_ptr())),
+                                                       C.c_void_p(out.ptr)),
                    "tgp_dist_cond_mean_partial")
         return out
 
     # -- solves on the resident factor (buffers: device tensors, (npad,) or (npad, nrhs) row-major) ------------
     def rhs_zeros(self, nrhs: int):
-        shape = (self.npad,) if nrhs == 1 else (self.npad, nrhs)
-        with self.stream(MAIN):
-            return self.torch.zeros(shape, dtype=self.x.dtype, device=self.device)
+        return self._alloc((self.npad,) if nrhs == 1 else (self.npad, nrhs), zero=True)
 
     def rhs_from_host(self, Y: np.ndarray, nrhs: int):
         """(n,) or (n, R) host array -> zero-padded device buffer of `nrhs` (1 or a multiple of 128) columns."""
@@ -201,55 +224,57 @@ class HipBlockOps:
             buf[: self.n] = Y.reshape(self.n)
         else:
             buf[: self.n, : Y.shape[1]] = Y
-        with self.stream(MAIN):
-            return self.torch.from_numpy(buf).to(self.device)
+        out = self._alloc(buf.shape)
+        _ffi.check(self.lib.tgp_stream_h2d(self.ctx.handle, MAIN, C.c_void_p(out.ptr), _ffi.ptr(buf), buf.nbytes),
+                   "tgp_stream_h2d")
+        return out
 
     def rhs_to_host(self, buf) -> np.ndarray:
-        with self.stream(MAIN):  # behind the collective that produced it, on ITS stream
-            return buf.cpu().numpy()
+        """Behind everything on the MAIN stream (the collective that produced the buffer included)."""
+        out = np.empty(buf.shape, dtype=buf.dtype)
+        _ffi.check(self.lib.tgp_stream_d2h(self.ctx.handle, MAIN, _ffi.ptr(out), C.c_void_p(buf.ptr), out.nbytes),
+                   "tgp_stream_d2h")
+        return out
 
     def rhs_block(self, buf, k: int):
-        return buf[k * self.nb:(k + 1) * self.nb]
+        return buf.rows(k * self.nb, (k + 1) * self.nb)
 
     def fwd_block(self, k: int, nrhs: int, y, acc, x):
-        _ffi.check(self.lib.tgp_dist_fwd_block(self.h, k, nrhs, C.c_void_p(y.data_ptr()), C.c_void_p(acc.data_ptr()),
-                                               C.c_void_p(x.data_ptr())), "tgp_dist_fwd_block")
+        _ffi.check(self.lib.tgp_dist_fwd_block(self.h, k, nrhs, C.c_void_p(y.ptr), C.c_void_p(acc.ptr),
+                                               C.c_void_p(x.ptr)), "tgp_dist_fwd_block")
 
     def bwd_block(self, k: int, x):
-        _ffi.check(self.lib.tgp_dist_bwd_block(self.h, k, C.c_void_p(x.data_ptr())), "tgp_dist_bwd_block")
+        _ffi.check(self.lib.tgp_dist_bwd_block(self.h, k, C.c_void_p(x.ptr)), "tgp_dist_bwd_block")
 
     def trmv_partial(self, y):
         out = self.rhs_zeros(1)
-        _ffi.check(self.lib.tgp_dist_trmv_partial(self.h, C.c_void_p(y.data_ptr()), C.c_void_p(out.data_ptr())),
+        _ffi.check(self.lib.tgp_dist_trmv_partial(self.h, C.c_void_p(y.ptr), C.c_void_p(out.ptr)),
                    "tgp_dist_trmv_partial")
         return out
 
     def cross_cov(self, prog, Pt: np.ndarray, m_pad: int):
         kp, nops = _ffi.as_kprog(prog)
-        with self.stream(MAIN):
-            out = self.torch.empty((self.npad, m_pad), dtype=self.x.dtype, device=self.device)
+        out = self._alloc((self.npad, m_pad))
         _ffi.check(self.lib.tgp_dist_cross_cov(self.h, kp, nops, Pt.shape[0], _ffi.ptr(Pt), m_pad,
-                                               C.c_void_p(out.data_ptr())), "tgp_dist_cross_cov")
+                                               C.c_void_p(out.ptr)), "tgp_dist_cross_cov")
         return out
 
     def colsumsq_owned(self, nrhs: int, x):
-        with self.stream(MAIN):
-            out = self.torch.empty(nrhs, dtype=self.x.dtype, device=self.device)
-        _ffi.check(self.lib.tgp_dist_colsumsq_owned(self.h, nrhs, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr())),
+        out = self._alloc((nrhs,))
+        _ffi.check(self.lib.tgp_dist_colsumsq_owned(self.h, nrhs, C.c_void_p(x.ptr), C.c_void_p(out.ptr)),
                    "tgp_dist_colsumsq_owned")
         return out
 
     def gram_owned(self, nrhs: int, x):
-        with self.stream(MAIN):
-            out = self.torch.empty((nrhs, nrhs), dtype=self.x.dtype, device=self.device)
-        _ffi.check(self.lib.tgp_dist_gram_owned(self.h, nrhs, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr())),
+        out = self._alloc((nrhs, nrhs))
+        _ffi.check(self.lib.tgp_dist_gram_owned(self.h, nrhs, C.c_void_p(x.ptr), C.c_void_p(out.ptr)),
                    "tgp_dist_gram_owned")
         return out
 
     def set_x(self, buf):
         """The handle's own replicated vector <- a solved vector (the backward substitution works in place there)."""
-        with self.stream(MAIN):
-            self.x.copy_(buf)
+        _ffi.check(self.lib.tgp_stream_d2d(self.ctx.handle, MAIN, C.c_void_p(self.x.ptr), C.c_void_p(buf.ptr),
+                                           self.x.nbytes), "tgp_stream_d2d")
 
     def abort(self):
         if self.h is not None:
@@ -262,8 +287,12 @@ class HipBlockOps:
 
     def close(self):
         if self.h is not None:
-            self.lib.tgp_dist_destroy(self.h)
+            self.lib.tgp_dist_destroy(self.h)  # (joins every stream of the context)
             self.h = None
+            for ptrs in self._pool.values():
+                for p in ptrs:
+                    self.ctx.free(p)
+            self._pool, self._pool_bytes = {}, 0
 
     def __del__(self):  # pragma: no cover
         try:
@@ -281,17 +310,23 @@ class BlockCyclicCholesky:
         noise_diag: (N,) noise variances (``noise.Diagonal``, reference noise.py:55-95).
         nb: block-column width (multiple of 128).
         ops: per-rank operations (default :class:`HipBlockOps` on ``LOCAL_RANK``).
-        group: ``torch.distributed`` process group (default: the world).
+        comm: the collectives (:mod:`tinygp_amd.comm`).  Default for the HIP operations: :class:`RcclComm` -- its
+            128-byte id exchanged through ``dist`` / an initialised ``torch.distributed`` when there is one (that ONE
+            message; a ``gloo`` group selects the host-staged test transport instead), else over TCP from the launcher's
+            ``RANK`` / ``WORLD_SIZE`` / ``MASTER_ADDR`` / ``MASTER_PORT`` with no torch at all.  Default for stand-in
+            operations: ``torch.distributed`` on their tensors.
+        group, dist: ``torch.distributed`` process group / module for the above (default: the world).
     """
 
-    def __init__(self, kernel, X, noise_diag, *, nb: int = 1024, ops=None, group=None, dist=None):
-        if dist is None:
-            import torch.distributed as dist
-        self.dist, self.group = dist, group
-        self.rank = dist.get_rank(group)
-        self.G = dist.get_world_size(group)
+    def __init__(self, kernel, X, noise_diag, *, nb: int = 1024, ops=None, group=None, dist=None, comm=None):
         if nb % 128 or nb <= 0:
             raise ValueError("nb must be a positive multiple of 128")
+        if ops is None:
+            ops = HipBlockOps(int(os.environ.get("LOCAL_RANK", "0")))
+        if comm is None:
+            comm = self._default_comm(ops, dist, group)
+        self.comm = comm
+        self.rank, self.G = comm.rank, comm.world
         X = np.asarray(X)
         P = np.ascontiguousarray(X[:, None] if X.ndim == 1 else X)
         self.dtype = np.dtype(np.float32 if P.dtype == np.float32 else np.float64)
@@ -302,8 +337,6 @@ class BlockCyclicCholesky:
         self.npad = self.nblk * nb
         self.kernel = kernel
         self.prog = kernel.program()
-        if ops is None:
-            ops = HipBlockOps(int(os.environ.get("LOCAL_RANK", "0")))
         self.ops = ops
         self.owned = [j for j in range(self.nblk) if j % self.G == self.rank]
         diag = np.ascontiguousarray(np.broadcast_to(noise_diag, (self.n,)), dtype=self.dtype)
@@ -325,8 +358,23 @@ class BlockCyclicCholesky:
     def owner(self, j: int) -> int:
         return j % self.G
 
-    def _src(self, r: int) -> int:
-        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+    @staticmethod
+    def _default_comm(ops, dist, group):
+        from tinygp_amd import comm as _comm
+
+        if not isinstance(ops, HipBlockOps):  # the CPU stand-in of the tests: torch tensors under gloo
+            return _comm.TorchComm(dist, group)
+        if dist is None:
+            import sys
+
+            td = sys.modules.get("torch.distributed")  # (never imported for this: a process without torch stays so)
+            if td is not None and td.is_available() and td.is_initialized():
+                dist = td
+        if dist is None:
+            return _comm.RcclComm.from_env(ops.ctx)
+        if str(dist.get_backend(group)).lower() == "gloo":
+            return _comm.HostStagedComm(ops.ctx, dist, group)
+        return _comm.RcclComm.from_torch(ops.ctx, dist, group)
 
     # -- the schedule -----------------------------------------------------------------------
     CHUNK_MIN_BYTES = 32 << 20  # a panel is sent in pieces once a piece is at least this big
@@ -358,17 +406,16 @@ class BlockCyclicCholesky:
         nch = self.chunks(k)
         if not own:
             self._guard(self.ops.slot_ready, k)
-            self.bytes_received += self.ops.slot(k, self.rows(k)).numel() * self.ops.slot(k, self.rows(k)).element_size()
+            self.bytes_received += self.ops.nbytes_of(self.ops.slot(k, self.rows(k)))
         works = []
         for c in range(nch):
             if own:
                 self._guard(self.ops.panel_chunk, k, c, nch)
             if self.G == 1 and not self.self_broadcast:
-                works.append(_Done(self.ops, PANEL))  # nobody to send to: only the stream dependency remains
+                works.append(self.comm.marker(PANEL))  # nobody to send to: only the stream dependency remains
                 continue
             buf = self.ops.slot_chunk(k, self.rows(k), c, nch)
-            with self.ops.stream(PANEL):
-                works.append(self.dist.broadcast(buf, src=self._src(self.owner(k)), group=self.group, async_op=True))
+            works.append(self.comm.broadcast(buf, self.owner(k), PANEL))  # on the PANEL stream, behind the pack
         return works
 
     def factor(self, resid=None, kernel=None) -> int:
@@ -391,15 +438,13 @@ class BlockCyclicCholesky:
             nxt = None
             if k + 1 < self.nblk:
                 if self.owner(k + 1) == self.rank:
-                    with ops.stream(PANEL):
-                        for w in works:
-                            w.wait()  # RCCL: a stream dependency, not a host block
+                    for w in works:
+                        w.wait(PANEL)  # a stream dependency, not a host block
                     self._guard(ops.lookahead, k)  # gate: panel k -> block column k+1
                 nxt = self._bcast_panel(k + 1)     # (owner: chain + pack per chunk, each right before its send)
             # -- main stream: forward step, then the updates; block column k+2 first on its owner
-            with ops.stream(MAIN):
-                for w in works:
-                    w.wait()
+            for w in works:
+                w.wait(MAIN)
             self._guard(ops.arrived, k)
             self._guard(ops.fwd_step, k)
             self._guard(ops.pre_update, k)
@@ -408,9 +453,7 @@ class BlockCyclicCholesky:
         out = self._guard(ops.end)
         info, self._sumsq, self._logdet = out if out is not None else (0, math.nan, math.nan)
         # agree on the first failing pivot (LAPACK convention), 0 if none; a rank-local error travels as -1
-        t = ops.scalar(-1.0 if self._err is not None else (float(info) if info else float(2**52)))
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
-        v = float(t.item())
+        v = self.comm.agree_min(-1.0 if self._err is not None else (float(info) if info else float(2**52)))
         if v < 0:
             # every rank: join the streams (broadcasts and kernels of the interrupted pass may still be in flight on
             # the ring slots and on x) and forget its markers before raising, so that a retry starts from a quiet
@@ -442,14 +485,12 @@ class BlockCyclicCholesky:
     def _reduce_to_owner(self, buf, k: int):
         if self.G == 1 and not self.self_broadcast:
             return
-        with self.ops.stream(MAIN):
-            self.dist.reduce(buf, dst=self._src(self.owner(k)), op=self.dist.ReduceOp.SUM, group=self.group)
+        self.comm.reduce(buf, self.owner(k), MAIN)
 
     def _all_reduce(self, buf):
         if self.G == 1 and not self.self_broadcast:
             return
-        with self.ops.stream(MAIN):
-            self.dist.all_reduce(buf, group=self.group)
+        self.comm.all_reduce(buf, MAIN)
 
     def _forward(self, y_dev, nrhs: int):
         """``L^-1 Y`` for device right-hand sides (``nrhs`` = 1 or a multiple of 128), fan-in: block by block the
@@ -485,8 +526,7 @@ class BlockCyclicCholesky:
                     for k in reversed(range(self.nblk)):
                         ops.bwd_block(k, x)
                         if not (self.G == 1 and not self.self_broadcast):
-                            with ops.stream(MAIN):
-                                self.dist.broadcast(ops.rhs_block(x, k), src=self._src(self.owner(k)), group=self.group)
+                            self.comm.broadcast(ops.rhs_block(x, k), self.owner(k), MAIN).wait(MAIN)
                 else:
                     x = self._forward(ops.rhs_from_host(col, 1), 1)
                     self._all_reduce(x)
@@ -584,10 +624,8 @@ class BlockCyclicCholesky:
                 ops.bwd_step(k)  # owner: x_k on the main stream (needs the slices below it: waited for underneath)
                 if self.G == 1 and not self.self_broadcast:
                     continue
-                with ops.stream(MAIN):  # asynchronous: issued behind bwd_step, the next step waits on the stream
-                    w = self.dist.broadcast(ops.x_slice(k), src=self._src(self.owner(k)), group=self.group,
-                                            async_op=True)
-                    w.wait()
+                # asynchronous: issued behind bwd_step on the main stream, the next step follows it there
+                self.comm.broadcast(ops.x_slice(k), self.owner(k), MAIN).wait(MAIN)
             self.have_alpha = True
         return self.ops.x
 
@@ -635,9 +673,8 @@ class BlockCyclicCholesky:
         Pt = self._test_points(X_test)
         prog = self.prog if kernel is None else kernel.program()
         part = self.ops.cond_mean_partial(prog, Pt)
-        with self.ops.stream(MAIN):  # the copy to the host must follow the all-reduce on ITS stream
-            self.dist.all_reduce(part, group=self.group)
-            out = part.cpu().numpy()
+        self.comm.all_reduce(part, MAIN)  # (no self_broadcast shortcut: the product's one collective per call)
+        out = self.ops.rhs_to_host(part)
         if self.info:
             out = np.full_like(out, np.nan)
         return out
