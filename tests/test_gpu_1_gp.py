@@ -412,6 +412,50 @@ def test_refactor_is_the_optimizer_step():
         np.testing.assert_allclose(gp.solver.log_probability(y), want, rtol=LL_RTOL)
 
 
+def test_a_timed_out_hand_off_is_released_and_the_pass_repeated_on_the_per_block_path():
+    """Followers of a chain launch wait in the command processor (stream wait-values): no timeout of their own.  The
+    host joins such a pass with a deadline; past it, it satisfies the pending waits itself, drains the streams and
+    reports TGP_E_TIMEOUT, and the solver repeats the pass ONCE on the launch-per-block path.  The test hook
+    `fault_inject = 1` lets the deadline pass while the device is still at work: the result must be the reference's,
+    the retry must be counted, and the next evaluation must run on the default path again."""
+    from tinygp_amd import _ffi
+
+    ctx = _ffi.default_ctx()
+    if ctx.get_option("chain_polls") != 1 or ctx.get_option("chain_kernel") != 1:
+        pytest.skip("the default schedule (stream wait-values behind the persistent chain) is switched off")
+    n = 4096
+    X, y = _cases.synthetic.make_inputs(n, 1)
+    k = 1.5**2 * kernels.ExpSquared(2.5)
+    want = float(o.GaussianProcess(1.5**2 * o.ExpSquared(2.5), X, diag=0.01).log_probability(y))
+    gp = GaussianProcess(k, X, diag=0.01)
+    before = ctx.get_option("timeout_retries")
+    ctx.set_option("fault_inject", 1)
+    try:
+        got = float(gp.log_probability(y))
+    finally:
+        ctx.set_option("fault_inject", 0)
+    np.testing.assert_allclose(got, want, rtol=LL_RTOL)
+    assert ctx.get_option("timeout_retries") == before + 1
+    assert ctx.get_option("chain_kernel") == 1
+    gp.solver.refactor(1.2**2 * kernels.ExpSquared(2.0))
+    want2 = float(o.GaussianProcess(1.2**2 * o.ExpSquared(2.0), X, diag=0.01).log_probability(y))
+    np.testing.assert_allclose(gp.solver.log_probability(y), want2, rtol=LL_RTOL)
+    assert ctx.get_option("timeout_retries") == before + 1
+
+
+def test_poll_timeout_option_round_trips_and_rejects_nonsense():
+    from tinygp_amd import _ffi
+
+    ctx = _ffi.default_ctx()
+    old = ctx.set_option("poll_timeout_ms", 2500)
+    try:
+        assert ctx.get_option("poll_timeout_ms") == 2500
+        with pytest.raises(ValueError):
+            ctx.set_option("poll_timeout_ms", 0)
+    finally:
+        ctx.set_option("poll_timeout_ms", old)
+
+
 # ---- BASELINE.json configs -----------------------------------------------------------------
 def test_config1_n1024(golden_dir):
     g = np.load(golden_dir / "configs.npz")

@@ -294,6 +294,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "split_tail")) return &ctx->split_tail;
   if (!strcmp(key, "gemm_role")) return &ctx->gemm_role;
   if (!strcmp(key, "host_join")) return &ctx->host_join;
+  if (!strcmp(key, "fault_inject")) return &ctx->fault_inject;
   if (!strcmp(key, "poll_timeout_ms")) return &ctx->poll_timeout_ms;
   if (!strcmp(key, "timeout_retries")) return &ctx->timeout_retries;  // (read: passes repeated after a device-side timeout)
   return nullptr;

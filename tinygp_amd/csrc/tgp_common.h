@@ -148,6 +148,7 @@ struct tgp_ctx {
   // poll kernel; 0: they wait for the whole launch
   int64_t chain_polls = 1;
   bool wait_values_inflight = false;  // this factorisation enqueued stream wait-values: join with a deadline (join_bounded)
+  int64_t fault_inject = 0;      // TEST hook. 1: the next bounded join expires at once (exercises rescue + retry), then clears
   int64_t host_join = 1;         // 0: plain hipStreamSynchronize even then (A/B of the polling join)
   bool serializing_tool = false; // a counter-collecting profiler is attached (ROCPROF_COUNTER_COLLECTION): chain_polls defaults to 0
   hipStream_t rescue_stream = nullptr;
