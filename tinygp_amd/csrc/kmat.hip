@@ -476,6 +476,88 @@ __global__ __launch_bounds__(256) void kgrad_kernel(KProg kp, int which_op, int 
   if (threadIdx.x == 0) partial[tile_id] = red[0];
 }
 
+// The same sum for a CHUNK OF COLUMNS of K^-1 held as rows (round 5: the gradient on the block-column path).  `Kc` is
+// (n_pad, R) ROW-major -- K^-1[i, c0 + r] at i * R + r, the layout of the distributed solves' right-hand sides --, and
+// only row tiles inside block rows THIS RANK owns contribute (block row b = row / nb belongs to rank b mod G): the ranks'
+// partial sums add up to the lower triangle of the chunk.  Tile (tr, tc): rows tr * 128 .., columns c0 + tc * 128 ...
+template <typename T>
+__global__ __launch_bounds__(256) void kgrad_cols_kernel(KProg kp, int which_op, int which_param, int64_t n, int d,
+                                                         const T* __restrict__ X, const T* __restrict__ alpha,
+                                                         const T* __restrict__ Kc, int64_t R, int64_t c0, int64_t nb,
+                                                         int G, int rank, double* __restrict__ partial) {
+  const int tr = blockIdx.x, tc = blockIdx.y;
+  const int tile_id = tr * gridDim.y + tc;
+  const int64_t r0 = int64_t(tr) * KT, cc0 = c0 + int64_t(tc) * KT;
+  const bool mine = int((r0 / nb) % G) == rank;
+  if (!mine || r0 + KT <= cc0 || cc0 >= n || r0 >= n) {  // not this rank's rows, or strictly above the diagonal
+    if (threadIdx.x == 0) partial[tile_id] = 0.0;
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* s1 = reinterpret_cast<T*>(smem);  // [KT][d]
+  T* s2 = s1 + KT * d;                 // [KT][d]
+  __shared__ double red[256];
+  for (int t = threadIdx.x; t < KT * d; t += 256) {
+    const int64_t gi = r0 + t / d, gj = cc0 + t / d;
+    s1[t] = (gi < n) ? X[gi * d + t % d] : T(0);
+    s2[t] = (gj < n) ? X[gj * d + t % d] : T(0);
+  }
+  __syncthreads();
+  const int il = threadIdx.x & (KT - 1), g = threadIdx.x >> 7;
+  const int64_t gi = r0 + il;
+  const T ai = (gi < n) ? alpha[gi] : T(0);
+  double acc = 0.0;
+  if (gi < n) {
+    for (int c = 0; c < KT / 2; ++c) {
+      const int jl = g * (KT / 2) + c;
+      const int64_t gj = cc0 + jl;
+      if (gj >= n || gj > gi) continue;
+      T r1 = 0, r2 = 0, dxd = 0;
+      for (int t = 0; t < d; ++t) {
+        const T dx = s1[il * d + t] - s2[jl * d + t];
+        r1 += fabs(dx);
+        r2 += dx * dx;
+        if (t == -1 - which_op) dxd = dx;
+      }
+      const T dk = which_op >= 0 ? eval_kprog_deriv<T>(kp, which_op, which_param, r1, r2)
+                                 : eval_kprog_deriv_dim<T>(kp, r1, r2, r1 > T(0) ? fabs(dxd) / r1 : T(0),
+                                                           r2 > T(0) ? dxd * dxd / r2 : T(0));
+      const T gij = ai * alpha[gj] - Kc[gi * R + (gj - c0)];
+      acc += double(gij) * double(dk) * (gi == gj ? 0.5 : 1.0);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[tile_id] = red[0];
+}
+
+// *out += sum(partial) (one workgroup, fixed tree: deterministic)
+__global__ __launch_bounds__(1024) void add_partials_kernel(int64_t count, const double* __restrict__ partial,
+                                                            double* __restrict__ out) {
+  __shared__ double red[1024];
+  double acc = 0;
+  for (int64_t i = threadIdx.x; i < count; i += 1024) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = 512; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out += red[0];
+}
+
+// diag[c0 + r] = Kc[c0 + r, r] for the chunk's columns (K^-1_jj: the noise gradient's second term)
+template <typename T>
+__global__ __launch_bounds__(256) void kcols_diag_kernel(int64_t n, const T* __restrict__ Kc, int64_t R, int64_t c0,
+                                                         T* __restrict__ diag) {
+  const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (r < R && c0 + r < n) diag[c0 + r] = Kc[(c0 + r) * R + r];
+}
+
 __global__ __launch_bounds__(1024) void sum_partials_kernel(int64_t count, const double* __restrict__ partial,
                                                             double* __restrict__ out) {
   __shared__ double red[1024];
@@ -921,6 +1003,32 @@ int launch_kgrad(tgp_ctx* ctx, const KProg& kp, int which_op, int which_param, i
   return TGP_OK;
 }
 
+// out_accum[0] += this rank's share of  sum_{i >= j, j in chunk} w_ij (alpha_i alpha_j - Kinv_ij) dK_ij / dtheta  over the
+// chunk of R columns from c0 (Kc: (n_pad, R) row-major); diag_out (or NULL) receives the chunk's K^-1_jj
+template <typename T>
+int launch_kgrad_cols(tgp_ctx* ctx, const KProg& kp, int which_op, int which_param, int64_t n, int d, const T* X,
+                      const T* alpha, const T* Kc, int64_t R, int64_t c0, int64_t nb, int G, int rank,
+                      double* out_accum) {
+  const int64_t tr = (n + KT - 1) / KT, tc = (std::min<int64_t>(R, n - c0) + KT - 1) / KT;
+  TGP_ARG_CHECK(tr <= 65535 && tc >= 1 && tc <= 65535 && c0 % KT == 0, "kgrad_cols: bad chunk");
+  TGP_TRY(ensure_work(ctx, size_t(tr) * tc * sizeof(double)));
+  double* partial = static_cast<double*>(ctx->d_work);
+  const size_t shmem = 2 * size_t(KT) * d * sizeof(T);
+  hipLaunchKernelGGL((kgrad_cols_kernel<T>), dim3((unsigned)tr, (unsigned)tc), dim3(256), shmem, ctx->stream, kp,
+                     which_op, which_param, n, d, X, alpha, Kc, R, c0, nb, G, rank, partial);
+  hipLaunchKernelGGL(add_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream, tr * tc, partial, out_accum);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
+template <typename T>
+int launch_kcols_diag(tgp_ctx* ctx, int64_t n, const T* Kc, int64_t R, int64_t c0, T* diag) {
+  hipLaunchKernelGGL((kcols_diag_kernel<T>), dim3((unsigned)((R + 255) / 256)), dim3(256), 0, ctx->stream, n, Kc, R, c0,
+                     diag);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
 // Gradient sums of a "leaf" / "amp * leaf" program in one pass: out_dev[0] = d/d(constant) (only
 // meaningful when the program has one), out_dev[1] = d/d(scale).  Returns 1 when the program is
 // of that shape (*leaf / *konst = their positions, -1: none), 0 when the caller must use launch_kgrad.
@@ -966,6 +1074,9 @@ int launch_noise_grad(tgp_ctx* ctx, int64_t n, const T* alpha, const T* Kinv, in
 }
 
 #define TGP_INST(T)                                                                               \
+  template int launch_kgrad_cols<T>(tgp_ctx*, const KProg&, int, int, int64_t, int, const T*, const T*, const T*,   \
+                                    int64_t, int64_t, int64_t, int, int, double*);                                  \
+  template int launch_kcols_diag<T>(tgp_ctx*, int64_t, const T*, int64_t, int64_t, T*);                            \
   template int launch_kgrad<T>(tgp_ctx*, const KProg&, int, int, int64_t, int, const T*, const T*, \
                                const T*, int64_t, double*);                                       \
   template int launch_noise_grad<T>(tgp_ctx*, int64_t, const T*, const T*, int64_t, T*);          \

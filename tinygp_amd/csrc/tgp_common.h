@@ -372,6 +372,12 @@ int launch_add_diag(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, const T* diag);
 // gradient of the log-probability (row 8f-1): partial[pass][block] sums of
 //   w_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta over the lower triangle, w = 1/2 on the diagonal
 template <typename T>
+int launch_kgrad_cols(tgp_ctx* ctx, const KProg& kp, int which_op, int which_param, int64_t n, int d, const T* X,
+                      const T* alpha, const T* Kc, int64_t R, int64_t c0, int64_t nb, int G, int rank,
+                      double* out_accum);
+template <typename T>
+int launch_kcols_diag(tgp_ctx* ctx, int64_t n, const T* Kc, int64_t R, int64_t c0, T* diag);
+template <typename T>
 int launch_kgrad(tgp_ctx* ctx, const KProg& kp, int which_op, int which_param, int64_t n, int d,
                  const T* X, const T* alpha, const T* Kinv, int64_t ld, double* out_dev);
 template <typename T>
