@@ -37,7 +37,8 @@ extern "C" {
  *  round 3 -> 4: tgp_chain_stamps, tgp_chain_task, the resident-factor solves of the block-column driver -- tgp_dist_fwd_block,
  *  _bwd_block, _trmv_partial, _cross_cov, _colsumsq_owned, _gram_owned -- and tgp_dist_abort added;
  *  round 4 -> 5: tgp_comm_* (RCCL from the C ABI), tgp_stream_* transfers, TGP_E_TIMEOUT, options poll_timeout_ms /
- *  chain_fast_update, chain_polls = 1 now means a stream wait-value) */
+ *  chain_fast_update, chain_polls = 1 now means a stream wait-value; tgp_dist_bwd_*_multi, tgp_dist_identity_cols,
+ *  tgp_dist_grad_* -- multi-RHS backward solve and gradient on the block-column path) */
 #define TGP_ABI_VERSION 5
 
 /* element types: follows the dtype of the caller's arrays (gp.py:89) */
@@ -394,6 +395,30 @@ int tgp_dist_gram_owned(tgp_dist* h, int64_t nrhs, const void* x_dev, void* out_
 /* after a rank-local failure: joins every stream and forgets the interrupted pass's markers (a retry starts from a
  * quiet device) */
 int tgp_dist_abort(tgp_dist* h);
+
+/* Round 5.  Backward substitution with MANY right-hand sides on the resident distributed factor (reference
+ * solvers/direct.py:66-68, trans=1, y (N, R)): right-looking, block k from the last to the first --
+ *   tgp_dist_bwd_block_multi   owner(k): X_k = L_kk^-T Y_k in place;  the caller broadcasts X_k (ONE nb x R message);
+ *   tgp_dist_bwd_update_multi  every rank: Y_i -= L[k, i]^T X_k for its OWN block columns i in [stop_block, k).
+ * Buffers as tgp_dist_fwd_block: (n_pad, nrhs) ROW-major device memory, nrhs a multiple of 128.
+ * tgp_dist_identity_cols fills such a buffer with columns c0 .. c0 + nrhs - 1 of the identity. */
+int tgp_dist_bwd_block_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev);
+int tgp_dist_bwd_update_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev, int64_t stop_block);
+int tgp_dist_identity_cols(tgp_dist* h, int64_t c0, int64_t nrhs, void* out_dev);
+
+/* Gradient of log_probability on the block-column path -- what jax.value_and_grad of reference gp.py:126-138 gives a caller
+ * at any size: d ll / d theta = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta) with alpha = K^-1 r in the handle's replicated
+ * vector.  K^-1 is visited a chunk of columns at a time (the caller solves L L^T Z = E_chunk on the resident factor; the
+ * chunk arrives replicated, (n_pad, nrhs) row-major): every rank adds the lower-triangle terms of ITS block rows.
+ *   _begin(prog)                        zero the accumulators (the kernel program whose parameters are differentiated)
+ *   _chunk(c0, nrhs, kcols_dev, dims)   += this rank's share for columns c0 .. (dims != 0: also d / d log-scale of each
+ *                                       input dimension, as tgp_solver_grad's grad_logscale); keeps diag(K^-1) of the chunk
+ *   _end(out, logscale|NULL, diag|NULL) this rank's PARTIAL sums: out[2 i + q] = parameter q of op i (2 nops doubles),
+ *                                       grad_logscale[d]; kinv_diag_host (n entries of the solver's dtype, identical on
+ *                                       every rank).  The caller all-reduces out / grad_logscale over the ranks. */
+int tgp_dist_grad_begin(tgp_dist* h, const tgp_kop* prog, int nops);
+int tgp_dist_grad_chunk(tgp_dist* h, int64_t c0, int64_t nrhs, const void* kcols_dev, int32_t with_logscale);
+int tgp_dist_grad_end(tgp_dist* h, double* grad_params, double* grad_logscale, void* kinv_diag_host);
 /* inspection: local block column l (rows from its diagonal block down, ld = rows) to the host */
 int tgp_dist_get_column(tgp_dist* h, int64_t l, void* out_host);
 

@@ -232,6 +232,86 @@ class NumpyBlockOps:
             xn[k * nb:(k + 1) * nb] = sla.solve_triangular(C[k * nb:(k + 1) * nb], xk, lower=True, trans=1,
                                                            check_finite=False)
 
+    def bwd_block_multi(self, k, nrhs, x):
+        self.calls.append(("bwd_block_multi", k))
+        if k % self.G != self.rank:
+            return
+        nb = self.nb
+        Lkk = np.tril(self._col(k // self.G)[k * nb:(k + 1) * nb])
+        xv = x.numpy()
+        xv[k * nb:(k + 1) * nb] = sla.solve_triangular(Lkk, xv[k * nb:(k + 1) * nb], lower=True, trans=1,
+                                                       check_finite=False)
+
+    def bwd_update_multi(self, k, nrhs, x, stop):
+        self.calls.append(("bwd_update_multi", k, stop))
+        nb = self.nb
+        xv = x.numpy()
+        xk = xv[k * nb:(k + 1) * nb]
+        for l in range(self.nloc):
+            i = l * self.G + self.rank
+            if stop <= i < k:
+                xv[i * nb:(i + 1) * nb] -= self._col(l)[k * nb:(k + 1) * nb].T @ xk
+
+    def rhs_identity(self, c0, nrhs):
+        buf = self.rhs_zeros(nrhs)
+        v = buf.numpy()
+        for r in range(nrhs):
+            if c0 + r < self.npad:
+                v[c0 + r, r] = 1.0
+        return buf
+
+    # gradient accumulators: the device kernel's sums restated with central differences of the program's matrix
+    def grad_begin(self, prog):
+        self._gprog = [tuple(p) for p in prog]
+        self._gacc = np.zeros(2 * len(prog) + self.d)
+        self._kdiag = np.zeros(self.n, dtype=self.dtype)
+
+    def _dK(self, which, q, rows, cols):
+        """d K[rows, cols] / d (parameter q of op `which`) -- or, which < 0, d / d log-scale of input dimension -1 - which --
+        by central differences of the oracle's evaluation of the program."""
+        P = self.P.astype(np.float64)
+        if which >= 0:
+            op, metric, p0, p1 = self._gprog[which]
+            base = p0 if q == 0 else p1
+            h = 1e-6 * max(1.0, abs(base))
+
+            def at(v):
+                prog = list(self._gprog)
+                prog[which] = (op, metric, v, p1) if q == 0 else (op, metric, p0, v)
+                return ref_prog.eval_matrix(prog, P[rows], P[cols])
+            return (at(base + h) - at(base - h)) / (2 * h)
+        dim, h = -1 - which, 1e-6
+
+        def at_s(ls):
+            S = np.ones(self.d)
+            S[dim] = np.exp(ls)
+            return ref_prog.eval_matrix(self._gprog, P[rows] * S, P[cols] * S)
+        return (at_s(h) - at_s(-h)) / (2 * h)
+
+    def grad_chunk(self, c0, nrhs, kcols, with_logscale):
+        self.calls.append(("grad_chunk", c0))
+        Kc = kcols.numpy().astype(np.float64)
+        alpha = self.xn.astype(np.float64)
+        cols = np.arange(c0, min(c0 + nrhs, self.n))
+        rows = np.array([i for i in range(self.n) if (i // self.nb) % self.G == self.rank and i >= c0], dtype=int)
+        self._kdiag[cols] = Kc[cols, cols - c0]
+        if not len(rows) or not len(cols):
+            return
+        Gm = np.outer(alpha[rows], alpha[cols]) - Kc[rows][:, cols - c0]
+        W = np.where(rows[:, None] > cols[None, :], 1.0, np.where(rows[:, None] == cols[None, :], 0.5, 0.0))
+        for i, (op, _m, _p0, _p1) in enumerate(self._gprog):
+            if op >= 16:
+                continue
+            for q in range(2 if op in (6, 7) else 1):
+                self._gacc[2 * i + q] += np.sum(W * Gm * self._dK(i, q, rows, cols))
+        if with_logscale:
+            for dim in range(self.d):
+                self._gacc[2 * len(self._gprog) + dim] += np.sum(W * Gm * self._dK(-1 - dim, 0, rows, cols))
+
+    def grad_end(self, d):
+        part = np.concatenate([self._gacc[: 2 * len(self._gprog)], self._gacc[2 * len(self._gprog): 2 * len(self._gprog) + d]])
+        return torch.from_numpy(part.copy()), self._kdiag.copy()
+
     def trmv_partial(self, y):
         out = self.rhs_zeros(1)
         for l in range(self.nloc):

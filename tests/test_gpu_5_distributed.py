@@ -165,8 +165,65 @@ def test_resident_solves_on_the_hip_path(pg):
     np.testing.assert_allclose(a, np.linalg.solve(K, 2.0 * y - 0.5), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(s.resident_log_probability(3.0 * y + 1.0),
                                float(o.GaussianProcess(_k(o), X, diag=0.01).log_probability(3.0 * y + 1.0)), rtol=1e-8)
+    # round 5: ONE blocked pass for (N, R) with transpose=True (right-looking: trsm per block + one nb x R broadcast)
+    Y2 = np.random.default_rng(4).normal(size=(n, 200))  # 200 -> padded to 256 right-hand sides
+    calls_b = []
+    real_b = s.ops.bwd_block_multi
+    s.ops.bwd_block_multi = lambda k, r, x: (calls_b.append((k, r)), real_b(k, r, x))[1]
+    got = s.solve_triangular(Y2, transpose=True)
+    np.testing.assert_allclose(got, sla.solve_triangular(L, Y2, lower=True, trans=1), rtol=1e-7, atol=1e-7)
+    assert calls_b == [(k, 256) for k in reversed(range(s.nblk))]  # nblk block steps for ALL right-hand sides
     assert calls["panel"] == factored  # not one panel was factored again
     s.ops.close()
+
+
+@pytest.mark.parametrize("n,nb,chunk", [(2000, 256, 512), (3000, 512, 384), (1500, 128, 2048)])
+def test_gradient_on_the_block_column_path_hip(pg, n, nb, chunk):
+    """Value-and-gradient through the REAL per-rank operations at world size 1 (RCCL self-collectives): the chunked K^-1
+    solves (fan-in forward of identity columns, right-looking multi-RHS backward: csrc/dist.hip), the column-chunk
+    contraction kernel (kgrad_cols_kernel) and the all-reduce -- against the gradient oracle (trace identity in NumPy),
+    at the single-GPU gradient's tolerances (tests/test_gpu_2_grad.py)."""
+    from oracle import grad_np
+    from tinygp_amd import kernels
+    from tinygp_amd.distributed import BlockCyclicCholesky
+
+    rng = np.random.default_rng(11)
+    X = np.sort(rng.uniform(0, 8 * n / 300, n))
+    y = np.sin(X) + 0.1 * rng.normal(size=n)
+    diag = rng.uniform(0.05, 0.15, n)
+    theta0 = np.array([1.3**2, 1.7, 0.4, 0.9])
+    build = lambda m, t: t[0] * m.ExpSquared(t[1]) + t[2] * m.Matern32(t[3])  # noqa: E731
+    s = BlockCyclicCholesky(build(kernels, theta0), X, diag, nb=nb, dist=pg)
+    s.GRAD_CHUNK = chunk
+    ll, g = s.log_probability_and_grad(y)
+    want_ll, want_g, want_noise, want_alpha = grad_np.log_probability_and_grad(lambda t: build(o, t), theta0, X, diag, y)
+    np.testing.assert_allclose(ll, want_ll, rtol=1e-8)
+    flat = np.array(g["kernel"])  # 2 per op of the postfix program: [const | expsq.scale | mul | const | m32.scale | mul | add]
+    prog = build(kernels, theta0).program()
+    got = [flat[2 * i] for i, op in enumerate(prog) if op[0] < 16]
+    scale = np.abs(want_g).max()
+    np.testing.assert_allclose(got, want_g, rtol=2e-6, atol=2e-6 * scale)
+    np.testing.assert_allclose(g["noise_diag"], want_noise, rtol=1e-6, atol=1e-6 * np.abs(want_noise).max())
+    np.testing.assert_allclose(g["mean"], want_alpha, rtol=1e-7, atol=1e-7 * np.abs(want_alpha).max())
+    s.ops.close()
+
+
+def test_gradient_block_column_vs_single_gpu_n16384(pg):
+    """VERDICT r4 item 8's done-criterion: world-size-1 RCCL at N = 16 384 against the single-GPU tgp_solver_grad."""
+    from tinygp_amd import GaussianProcess, kernels
+    from tinygp_amd.solvers import DistributedDirectSolver
+
+    X, y, c = _cases.data_config("c2")
+    k = _cases.synthetic.config_kernel(kernels, c["kernel"])
+    ll1, g1 = GaussianProcess(k, X, diag=c["diag"]).log_probability_and_grad(y)
+    gp = GaussianProcess(k, X, diag=c["diag"], solver=DistributedDirectSolver, nb=1024, dist=pg)
+    ll2, g2 = gp.log_probability_and_grad(y)
+    np.testing.assert_allclose(ll2, ll1, rtol=1e-10)
+    scale = np.abs(np.array(g1["kernel"])).max()
+    np.testing.assert_allclose(g2["kernel"], g1["kernel"], rtol=1e-6, atol=1e-6 * scale)
+    np.testing.assert_allclose(g2["noise_diag"], g1["noise_diag"], rtol=1e-5, atol=1e-6 * np.abs(g1["noise_diag"]).max())
+    np.testing.assert_allclose(g2["mean"], g1["mean"], rtol=1e-6, atol=1e-7 * np.abs(g1["mean"]).max())
+    gp.solver.close()
 
 
 def test_distributed_solver_behind_the_solver_seam(pg):

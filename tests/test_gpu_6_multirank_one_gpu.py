@@ -45,6 +45,12 @@ def _worker(rank, world, port, n, nb, dtype_name, m_test, q):
         # solves on the RESIDENT factor with peers: fan-in forward solve (one reduce per block column), the (M,) all-reduce
         Y = np.random.default_rng(3).normal(size=(n, 3)).astype(dt)
         res = (s.solve_triangular(Y), s.solve_triangular(y.astype(dt), transpose=True), s.condition_colsumsq(xt.astype(dt)))
+        # round 5 with peers: ONE blocked pass for (N, R) transposed; value-and-gradient (chunked K^-1 solves: every rank
+        # contracts its own block rows, one all-reduce)
+        bwdR = s.solve_triangular(Y, transpose=True)
+        s.GRAD_CHUNK = 512
+        gll, grad = s.log_probability_and_grad(y.astype(dt))
+        res = res + (bwdR, gll, np.array(grad["kernel"]), grad["noise_diag"])
         ll2 = s.log_probability(y.astype(dt), kernel=1.1 * _k(kernels))  # the optimiser's next step
         # this rank's block columns of the factor (lower part), for the LAPACK comparison
         cols = [(j, s.ops.column(l, s.rows(j))) for l, j in enumerate(s.owned)]
@@ -84,6 +90,11 @@ def test_block_column_driver_with_peers_on_one_gpu(world, n, nb, dtype_name, rto
     xt = np.linspace(X[0], X[-1], m_test)
     want_mean = gp.predict(y, xt)
     want2 = float(o.GaussianProcess(1.1 * _k(o), X, diag=diag).log_probability(y))
+    from oracle import grad_np
+
+    # _k = 1.5^2 ExpSquared(2.5) + 0.3 Matern32(1.2): program [const, expsq, mul, const, m32, mul, add]
+    want_grad = grad_np.log_probability_and_grad(lambda t: t[0] * o.ExpSquared(t[1]) + t[2] * o.Matern32(t[3]),
+                                                 np.array([1.5**2, 2.5, 0.3, 1.2]), X, diag, y) if dtype_name == "float64" else None
     out = _run(world, n, nb, dtype_name, m_test)
     tol = dict(rtol=5e-7, atol=5e-7) if dtype_name == "float64" else dict(rtol=5e-4, atol=5e-4)
     L = gp.solver.scale_tril
@@ -101,6 +112,13 @@ def test_block_column_driver_with_peers_on_one_gpu(world, n, nb, dtype_name, rto
         np.testing.assert_allclose(res[1], sla.solve_triangular(L, y, lower=True, trans=1), rtol=rtol * 10,
                                    atol=1e-7 if dtype_name == "float64" else 5e-2)
         np.testing.assert_allclose(res[2], np.sum(Aw * Aw, axis=0), **tol)
+        np.testing.assert_allclose(res[3], sla.solve_triangular(L, Y, lower=True, trans=1), rtol=rtol * 10,
+                                   atol=1e-7 if dtype_name == "float64" else 5e-2)
+        np.testing.assert_allclose(res[4], want, rtol=rtol)
+        if dtype_name == "float64":
+            np.testing.assert_allclose([res[5][2 * i] for i in (0, 1, 3, 4)], want_grad[1], rtol=2e-6,
+                                       atol=2e-6 * np.abs(want_grad[1]).max())
+            np.testing.assert_allclose(res[6], want_grad[2], rtol=1e-6, atol=1e-6 * np.abs(want_grad[2]).max())
         np.testing.assert_allclose(ll, want, rtol=rtol)
         np.testing.assert_allclose(ll2, want2, rtol=rtol)
         np.testing.assert_allclose(mean, want_mean, **tol)

@@ -126,6 +126,12 @@ SIGNATURES = {
     "tgp_dist_colsumsq_owned": [_vp, _i64, _vp, _vp],
     "tgp_dist_gram_owned": [_vp, _i64, _vp, _vp],
     "tgp_dist_abort": [_vp],
+    "tgp_dist_bwd_block_multi": [_vp, _i64, _i64, _vp],
+    "tgp_dist_bwd_update_multi": [_vp, _i64, _i64, _vp, _i64],
+    "tgp_dist_identity_cols": [_vp, _i64, _i64, _vp],
+    "tgp_dist_grad_begin": [_vp, _pkop, _int],
+    "tgp_dist_grad_chunk": [_vp, _i64, _i64, _vp, _i32],
+    "tgp_dist_grad_end": [_vp, _pdbl, _pdbl, _vp],
     "tgp_comm_unique_id": [_vp, _pi32],
     "tgp_comm_create": [_vp, _i32, _i32, _vp, _pvp],
     "tgp_comm_destroy": [_vp],

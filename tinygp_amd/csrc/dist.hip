@@ -52,6 +52,10 @@ struct tgp_dist {
   void* Xown = nullptr;    // coordinates of the owned columns, compacted (cond-mean partial)
   void* aown = nullptr;    // alpha at the owned columns, compacted
   double* d_logdet = nullptr;  // per-panel sum log L_ii (nblk) + [nblk] = sum of squares
+  void* bwd_ws = nullptr;      // multi-RHS backward solve: transposed blocks of a block row | M = P L_kk^T P | its 16 x 16
+  size_t bwd_ws_bytes = 0;     //   inverses | the reversed right-hand sides (grown on demand)
+  double* d_grad = nullptr;    // gradient accumulators (2 * TGP_KPROG_MAX + TGP_MAX_DIM doubles) of tgp_dist_grad_*
+  void* kinv_diag = nullptr;   // diag(K^-1) collected chunk by chunk (n_pad entries)
   int64_t n_own = 0;
   bool solving = false, asm_pending = false;
   bool asm_deferred = false;  // owned block columns l >= 1 are still to be assembled (tgp_dist_first_panel)
@@ -144,6 +148,58 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(int64_t chunks, int64
   double s = accumulate ? double(out[r]) : 0.0;
   for (int64_t c = 0; c < chunks; ++c) s += partial[c * R + r];
   out[r] = T(s);
+}
+
+// dst (cols x rows, leading dimension ldd) = src (rows x cols, leading dimension lds)^T, both column-major: 32 x 32
+// tiles through LDS (padded: conflict-free), coalesced on both sides
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(int64_t rows, int64_t cols, const T* __restrict__ src, int64_t lds,
+                                                        T* __restrict__ dst, int64_t ldd) {
+  __shared__ T tile[32][33];
+  const int64_t r0 = int64_t(blockIdx.x) * 32, c0 = int64_t(blockIdx.y) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int q = ty; q < 32; q += 8)
+    if (r0 + tx < rows && c0 + q < cols) tile[q][tx] = src[(c0 + q) * lds + r0 + tx];
+  __syncthreads();
+  for (int q = ty; q < 32; q += 8)
+    if (c0 + tx < cols && r0 + q < rows) dst[(r0 + q) * ldd + c0 + tx] = tile[tx][q];
+}
+
+// M = P L^T P for a lower-triangular nb x nb block L (P: the reversal permutation): M[i][j] = L[nb-1-j][nb-1-i] is
+// LOWER triangular again, and B L^-1 = ((B P) M^-T) P -- the right solve WITHOUT transposition on the kernels that
+// exist for the one with it (trsm_right_lt).  Entries above the diagonal are written as zeros.
+template <typename T>
+__global__ __launch_bounds__(256) void reverse_transpose_kernel(int64_t nb, const T* __restrict__ L, int64_t ld,
+                                                                T* __restrict__ M) {
+  __shared__ T tile[32][33];
+  const int64_t i0 = int64_t(blockIdx.x) * 32, j0 = int64_t(blockIdx.y) * 32;  // tile of M: rows i0.., columns j0..
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  // M[i][j] = L[nb-1-j][nb-1-i]: read L rows (nb-1-j0-31 .. nb-1-j0) x columns (nb-1-i0-31 .. nb-1-i0), rows contiguous
+  const int64_t lr0 = nb - 32 - j0, lc0 = nb - 32 - i0;
+  for (int q = ty; q < 32; q += 8) tile[q][tx] = L[(lc0 + q) * ld + lr0 + tx];  // tile[c][r] = L[lr0 + r][lc0 + c]
+  __syncthreads();
+  for (int q = ty; q < 32; q += 8) {
+    const int64_t i = i0 + tx, j = j0 + q;  // M[i][j] = L[nb-1-j][nb-1-i] = tile[nb-1-i - lc0][nb-1-j - lr0]
+    M[j * nb + i] = (i >= j) ? tile[31 - tx][31 - q] : T(0);
+  }
+}
+
+// dst[:, j] = src[:, nb - 1 - j] for an (R x nb) column-major pair with leading dimension R (R contiguous entries per column)
+template <typename T>
+__global__ __launch_bounds__(256) void reverse_cols_kernel(int64_t R, int64_t nb, const T* __restrict__ src,
+                                                           T* __restrict__ dst) {
+  const int64_t j = blockIdx.y;
+  for (int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x; r < R; r += int64_t(gridDim.x) * 256)
+    dst[j * R + r] = src[(nb - 1 - j) * R + r];
+}
+
+// (n_pad, R) row-major right-hand sides = the identity's columns c0 .. c0 + R - 1 (rows >= n_pad never exist)
+template <typename T>
+__global__ __launch_bounds__(256) void identity_cols_kernel(int64_t npad, int64_t R, int64_t c0, T* __restrict__ out) {
+  const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= npad * R) return;
+  const int64_t i = idx / R, r = idx - i * R;
+  out[idx] = (i == c0 + r) ? T(1) : T(0);
 }
 
 template <typename T>
@@ -308,7 +364,8 @@ int tgp_dist_destroy(tgp_dist* h) {
                           h->ctx->solve_stream, h->ctx->stream})
       if (q) hipStreamSynchronize(q);
   }
-  void* bufs[] = {h->X, h->diag, h->A, h->dinv, h->Xown, h->aown, (void*)h->d_logdet};
+  void* bufs[] = {h->X, h->diag, h->A, h->dinv, h->Xown, h->aown, (void*)h->d_logdet, h->bwd_ws, (void*)h->d_grad,
+                  h->kinv_diag};
   for (void* b : bufs)
     if (b) hipFree(b);
   if (h->ev_arrived) hipEventDestroy(h->ev_arrived);
@@ -661,6 +718,175 @@ int tgp_dist_fwd_block(tgp_dist* h, int64_t k, int64_t nrhs, const void* y_dev, 
                                 (T*)acc_dev + (k + 1) * nb * nrhs, nrhs, 0, 0, 1));
     return TGP_OK;
   });
+}
+
+// ---- backward substitution with MANY right-hand sides on the resident factor (round 5; reference solvers/direct.py:66-68:
+// solve_triangular(L, y, lower=True, trans=1) with y (N, R)) --------------------------------------------------------------
+// Right-looking ("fan-out"): block k from the last to the first --
+//   owner(k):  X_k = L_kk^-T Y_k                                    (tgp_dist_bwd_block_multi; Y_k carries every update)
+//   the caller broadcasts X_k (ONE nb x R message per block column)
+//   everyone:  Y_i -= L[k, i]^T X_k  for its OWN block columns i < k  (tgp_dist_bwd_update_multi)
+// -- a rank only ever touches the blocks of L it owns (block row k of its own columns) and the right-hand-side blocks it
+// owns: no reduction, and every product has the short dimension (nb) as its k-range, so it fills the chip.  (The
+// row-oriented form of the single right-hand side -- x_k from a dot product over all rows below -- would be R x nb
+// outputs with a k-range of up to N: a handful of workgroups.)
+// Buffers as in tgp_dist_fwd_block: (n_pad, R) ROW-major, R a multiple of 128 -- read column-major that is X^T (R x
+// n_pad, leading dimension R), the MFMA kernels' operand layout.  Both products need the TRANSPOSE of a block of L as
+// gemm_nt's second operand; blocks are transposed into a scratch buffer first (nb^2 entries each: noise beside the product).
+static int bwd_scratch(tgp_dist* h, size_t bytes) {
+  if (h->bwd_ws_bytes >= bytes) return TGP_OK;
+  if (h->bwd_ws) {
+    TGP_HIP_TRY(hipStreamSynchronize(h->ctx->stream));
+    TGP_HIP_TRY(hipFree(h->bwd_ws));
+    h->bwd_ws = nullptr;
+    h->bwd_ws_bytes = 0;
+  }
+  TGP_HIP_TRY(hipMalloc(&h->bwd_ws, bytes));
+  h->bwd_ws_bytes = bytes;
+  return TGP_OK;
+}
+
+int tgp_dist_bwd_block_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk && x_dev != nullptr && nrhs > 0 && nrhs % TILE == 0,
+                "bwd_block_multi: bad argument (nrhs must be a multiple of %d)", TILE);
+  if (owner_of(h, k) != h->rank) return TGP_OK;
+  tgp_ctx* ctx = h->ctx;
+  const int64_t nb = h->nb, nd = (nb / TILE) * 2048;
+  const size_t es = esz(h->dtype);
+  // scratch: [M nb x nb | dinv(M) | reversed right-hand sides nrhs x nb]
+  TGP_TRY(bwd_scratch(h, (size_t(nb) * nb + size_t(nd) + size_t(nrhs) * nb) * es));
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int64_t l = k / h->G, ld = h->npad;
+    const T* Lkk = (const T*)h->A + l * nb * ld + k * nb;
+    T* M = (T*)h->bwd_ws;
+    T* dM = M + nb * nb;
+    T* Br = dM + nd;
+    T* Xk = (T*)x_dev + k * nb * nrhs;
+    hipLaunchKernelGGL((reverse_transpose_kernel<T>), dim3((unsigned)(nb / 32), (unsigned)(nb / 32)), dim3(256), 0,
+                       ctx->stream, nb, Lkk, ld, M);
+    TGP_HIP_TRY(hipGetLastError());
+    TGP_TRY(compute_dinv<T>(ctx, nb, M, nb, dM));
+    unsigned gx = (unsigned)((nrhs + 255) / 256);
+    hipLaunchKernelGGL((reverse_cols_kernel<T>), dim3(gx, (unsigned)nb), dim3(256), 0, ctx->stream, nrhs, nb, (const T*)Xk, Br);
+    TGP_HIP_TRY(hipGetLastError());
+    TGP_TRY(trsm_right_lt<T>(ctx, nrhs, nb, M, nb, dM, Br, nrhs));  // Br <- (Y_k^T P) M^-T = Y_k^T L_kk^-1 P
+    hipLaunchKernelGGL((reverse_cols_kernel<T>), dim3(gx, (unsigned)nb), dim3(256), 0, ctx->stream, nrhs, nb, (const T*)Br, Xk);
+    TGP_HIP_TRY(hipGetLastError());
+    return TGP_OK;
+  });
+}
+
+int tgp_dist_bwd_update_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev, int64_t stop_block) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk && x_dev != nullptr && nrhs > 0 && nrhs % TILE == 0 && stop_block >= 0,
+                "bwd_update_multi: bad argument");
+  tgp_ctx* ctx = h->ctx;
+  const int64_t nb = h->nb;
+  // owned block columns i in [stop_block, k): local indices l with l * G + rank in that range
+  int64_t l_begin = (stop_block - h->rank + h->G - 1) / h->G;
+  if (l_begin < 0) l_begin = 0;
+  int64_t l_end = (k - h->rank + h->G - 1) / h->G;  // first l with l * G + rank >= k
+  if (l_end > h->nloc) l_end = h->nloc;
+  if (l_end <= l_begin) return TGP_OK;
+  const int64_t cnt = l_end - l_begin;
+  TGP_TRY(bwd_scratch(h, std::max<size_t>(h->bwd_ws_bytes, size_t(cnt) * nb * nb * esz(h->dtype))));
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int64_t ld = h->npad;
+    const T* Xk = (const T*)x_dev + k * nb * nrhs;
+    T* Tt = (T*)h->bwd_ws;
+    // block row k of the owned columns l_begin .. l_end - 1: side by side in A_loc, one transpose launch:
+    // src (nb rows x cnt*nb columns, ld) -> dst (cnt*nb x nb, leading dimension cnt*nb): block q's transpose is rows
+    // q*nb .. of dst, i.e. T_q[c][m] at m * (cnt*nb) + q*nb + c
+    const T* src = (const T*)h->A + l_begin * nb * ld + k * nb;
+    hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)(nb / 32), (unsigned)(cnt * nb / 32)), dim3(256), 0, ctx->stream,
+                       nb, cnt * nb, src, ld, Tt, cnt * nb);
+    TGP_HIP_TRY(hipGetLastError());
+    for (int64_t q = 0; q < cnt; ++q) {
+      const int64_t i = (l_begin + q) * h->G + h->rank;
+      // Y_i^T (nrhs x nb) -= X_k^T (nrhs x nb) . L[k, i]  =  A B^T with B = L[k, i]^T (nb x nb, leading dimension cnt*nb)
+      TGP_TRY(launch_gemm_nt<T>(ctx, ctx->stream, nrhs, nb, nb, Xk, nrhs, Tt + q * nb, cnt * nb,
+                                (T*)x_dev + i * nb * nrhs, nrhs, 0, 0, 1));
+    }
+    return TGP_OK;
+  });
+}
+
+// (n_pad, nrhs) row-major device buffer <- columns c0 .. c0 + nrhs - 1 of the identity (the right-hand sides behind
+// K^-1[:, c0 : c0 + nrhs] = L^-T L^-1 E: the gradient on the block-column path)
+int tgp_dist_identity_cols(tgp_dist* h, int64_t c0, int64_t nrhs, void* out_dev) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(c0 >= 0 && nrhs > 0 && out_dev != nullptr, "identity_cols: bad argument");
+  const int64_t cnt = h->npad * nrhs;
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((identity_cols_kernel<T>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->ctx->stream, h->npad,
+                       nrhs, c0, (T*)out_dev);
+    TGP_HIP_TRY(hipGetLastError());
+    return TGP_OK;
+  });
+}
+
+// ---- gradient of log_probability on the block-column path (SURVEY 8f-1 x 8e; what jax.value_and_grad of reference
+// gp.py:126-138 gives a caller at any size) ------------------------------------------------------------------------------
+//   d ll / d theta = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta),  alpha = K^-1 r replicated in the handle's vector x.
+// K^-1 is never held as a whole: the caller solves for it a CHUNK of columns at a time on the resident factor (fan-in
+// forward from the chunk's first block, fan-out backward down to it: tinygp_amd/distributed.py), the chunk ends up
+// replicated as (n_pad, R) row-major, and every rank adds the lower-triangle terms of ITS block rows to its accumulators:
+//   tgp_dist_grad_begin(prog)                       zero the accumulators
+//   tgp_dist_grad_chunk(c0, nrhs, Kcols)            += this rank's share for columns c0 .. c0 + nrhs - 1; diag(K^-1) kept
+//   tgp_dist_grad_end(out, grad_logscale, kinv_diag) this rank's partial sums (the caller all-reduces 2 nops + d doubles)
+// grad layout as tgp_solver_grad: out[2 i + q] = parameter q of op i; grad_logscale[q] per input dimension (or NULL).
+int tgp_dist_grad_begin(tgp_dist* h, const tgp_kop* prog, int nops) {
+  DIST_GUARD(h);
+  TGP_TRY(make_kprog(prog, nops, &h->kp));
+  const size_t cnt = size_t(2 * TGP_KPROG_MAX + TGP_MAX_DIM);
+  if (!h->d_grad) TGP_HIP_TRY(hipMalloc((void**)&h->d_grad, cnt * sizeof(double)));
+  if (!h->kinv_diag) TGP_HIP_TRY(hipMalloc(&h->kinv_diag, size_t(h->npad) * esz(h->dtype)));
+  TGP_HIP_TRY(hipMemsetAsync(h->d_grad, 0, cnt * sizeof(double), h->ctx->stream));
+  TGP_HIP_TRY(hipMemsetAsync(h->kinv_diag, 0, size_t(h->npad) * esz(h->dtype), h->ctx->stream));
+  return TGP_OK;
+}
+
+int tgp_dist_grad_chunk(tgp_dist* h, int64_t c0, int64_t nrhs, const void* kcols_dev, int32_t with_logscale) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(h->d_grad != nullptr, "grad_chunk: call tgp_dist_grad_begin first");
+  TGP_ARG_CHECK(c0 >= 0 && c0 % TILE == 0 && nrhs > 0 && nrhs % TILE == 0 && kcols_dev != nullptr, "grad_chunk: bad argument");
+  tgp_ctx* ctx = h->ctx;
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const T* alpha = (const T*)h->x;
+    const T* Kc = (const T*)kcols_dev;
+    for (int i = 0; i < h->kp.n; ++i) {
+      const int op = h->kp.op[i];
+      if (op >= TGP_K_ADD) continue;
+      const int nparam = (op == TGP_K_ESS || op == TGP_K_RQ) ? 2 : 1;
+      for (int q = 0; q < nparam; ++q)
+        TGP_TRY(launch_kgrad_cols<T>(ctx, h->kp, i, q, h->n, h->d, (const T*)h->X, alpha, Kc, nrhs, c0, h->nb, h->G,
+                                     h->rank, h->d_grad + 2 * i + q));
+    }
+    for (int q = 0; q < (with_logscale ? h->d : 0); ++q)
+      TGP_TRY(launch_kgrad_cols<T>(ctx, h->kp, -1 - q, 0, h->n, h->d, (const T*)h->X, alpha, Kc, nrhs, c0, h->nb, h->G,
+                                   h->rank, h->d_grad + 2 * TGP_KPROG_MAX + q));
+    return launch_kcols_diag<T>(ctx, h->n, Kc, nrhs, c0, (T*)h->kinv_diag);
+  });
+}
+
+int tgp_dist_grad_end(tgp_dist* h, double* grad_params, double* grad_logscale, void* kinv_diag_host) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(h->d_grad != nullptr && grad_params != nullptr, "grad_end: bad argument");
+  tgp_ctx* ctx = h->ctx;
+  std::vector<double> g(size_t(2 * TGP_KPROG_MAX + TGP_MAX_DIM), 0.0);
+  TGP_HIP_TRY(hipMemcpyAsync(g.data(), h->d_grad, g.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (kinv_diag_host)
+    TGP_HIP_TRY(hipMemcpyAsync(kinv_diag_host, h->kinv_diag, size_t(h->n) * esz(h->dtype), hipMemcpyDeviceToHost, ctx->stream));
+  TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 2 * h->kp.n; ++i) grad_params[i] = g[size_t(i)];
+  if (grad_logscale)
+    for (int q = 0; q < h->d; ++q) grad_logscale[q] = g[size_t(2 * TGP_KPROG_MAX + q)];
+  return TGP_OK;
 }
 
 // out = sum over the OWNED block columns of L[:, k] y_k  (this rank's share of dot_triangular, reference

@@ -140,6 +140,28 @@ class DistributedDirectSolver(Solver):
             v = self._bc.resident_log_probability(resid)
         return self.dtype.type(v if math.isfinite(v) else -np.inf)
 
+    def log_probability_and_grad(self, resid):
+        """``(log_probability, grads)`` on the block-column path -- what ``jax.value_and_grad`` of reference
+        ``gp.py:126-138`` gives at any size; same dictionary as :meth:`DirectSolver.log_probability_and_grad`
+        (``grads["kernel"]`` follows ``kernel.parameters()``).  A fresh factorisation pass with the solver's kernel,
+        then the chunked ``K^-1`` solves of :meth:`BlockCyclicCholesky.log_probability_and_grad`; identical on every rank."""
+        from tinygp_amd.transforms import covering_transform
+
+        tf = covering_transform(self.kernel)
+        ll, g = self._bc.log_probability_and_grad(resid, with_logscale=tf is not None)
+        slots: list = []
+        self.kernel._slots(slots)
+        flat = g["kernel"]
+        kgrad = [flat[2 * i + q] for i, pair in enumerate(slots) for q in (0, 1) if pair[q] is not None]
+        tgrad = None
+        if tf is not None and g["logscale"] is not None and math.isfinite(ll):
+            try:
+                tgrad = tf._logscale_gradient(np.asarray(g["logscale"]))
+            except NotImplementedError:
+                tgrad = None
+        return self.dtype.type(ll if math.isfinite(ll) else -np.inf), {
+            "kernel": kgrad, "noise_diag": g["noise_diag"], "mean": g["mean"], "transform": tgrad}
+
     def alpha(self, resid):
         """``(K^-1 r, log_probability)`` (reference ``gp.py:330-334``)."""
         ll = self.log_probability(resid)
