@@ -470,7 +470,10 @@ def run_distributed(args, spec, rank, local_rank, world, torch, tdist, replicas_
             "dtype": "f64" if dt == np.float64 else "f32", "data": "synthetic",
             "config": {"workload": workload_text(spec) + "; ONE matrix, 1-D block-cyclic block columns, "
                                    "RCCL panel broadcast over xGMI, replicated forward solve",
-                       "n": n, "nb": nb, "parallelism": f"block-cyclic columns x{world}"},
+                       "n": n, "nb": nb, "parallelism": f"block-cyclic columns x{world}",
+                       # who issues the collectives: RcclComm = ncclBroadcast / ncclReduce by libtgp_hip.so itself on its
+                       # own streams (csrc/comm.hip); HostStagedComm = the one-GPU rehearsal's test transport
+                       "collectives": type(solver.comm).__name__},
             "aggregate_cholesky_tflops": (n**3 / 3.0) / per_eval / 1e12,
             # whole-evaluation rate of rank 0's share of the trailing updates against one GPU's peak:
             # a lower bound of the update kernel's own rate (chains, broadcasts and the tail included)

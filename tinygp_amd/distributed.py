@@ -616,6 +616,7 @@ class BlockCyclicCholesky:
             raise ValueError("X_test must have the same number of input dimensions as X")
         return Pt
 
+    GRAM_BYTES_LIMIT = 96 << 30  # device bytes condition_gram may ask for (a third of an MI355X's 288 GB)
     RHS_CHUNK = 2048  # test points per forward solve of the conditional variance (bounds the (n_pad, chunk) buffers)
 
     def condition_colsumsq(self, X_test, kernel=None) -> np.ndarray:
@@ -647,6 +648,15 @@ class BlockCyclicCholesky:
         prog = self.prog if kernel is None else kernel.program()
         m = Pt.shape[0]
         mp = -(-m // 128) * 128
+        # the full (M, M) product needs every column of A at once: three (n_pad, m_pad) buffers + the (m_pad, m_pad) result
+        # per rank (advisor r4).  Bounded and said so, instead of an out-of-memory deep inside a solve; the variance alone
+        # (condition_colsumsq) is chunked and has no such bound.
+        need = (3 * self.npad * mp + mp * mp) * self.dtype.itemsize
+        if need > self.GRAM_BYTES_LIMIT:
+            raise MemoryError(
+                f"condition covariance at {m} test points needs {need / 2**30:.1f} GiB of device buffers per rank "
+                f"(N = {self.n}); ask for the variance (condition_colsumsq / predict(return_var=True)), use fewer test "
+                f"points per call, or raise BlockCyclicCholesky.GRAM_BYTES_LIMIT")
         a = self._forward(self.ops.cross_cov(prog, Pt, mp), mp)
         g = self.ops.gram_owned(mp, a)
         self._all_reduce(g)
