@@ -402,6 +402,15 @@ int tgp_dist_abort(tgp_dist* h);
  *   tgp_dist_bwd_update_multi  every rank: Y_i -= L[k, i]^T X_k for its OWN block columns i in [stop_block, k).
  * Buffers as tgp_dist_fwd_block: (n_pad, nrhs) ROW-major device memory, nrhs a multiple of 128.
  * tgp_dist_identity_cols fills such a buffer with columns c0 .. c0 + nrhs - 1 of the identity. */
+/* Forward substitution with many right-hand sides, LEFT-looking fan-in (the form that scales over the ranks; the
+ * right-looking tgp_dist_fwd_block is the better one at world size 1): step k --
+ *   tgp_dist_fwd_partial      every rank: acc_k -= X[its columns in [first_block, k)] L[k, those columns]^T  (one product);
+ *   the caller reduces acc_k to owner(k);
+ *   tgp_dist_fwd_solve_left   owner(k): x_k = L_kk^-1 (y_k + acc_k) into x (global rows) AND xloc (its own solved blocks
+ *                             side by side: (nloc * nb, nrhs) row-major, local column l at rows l * nb ..). */
+int tgp_dist_fwd_partial(tgp_dist* h, int64_t k, int64_t nrhs, const void* xloc_dev, void* acc_dev, int64_t first_block);
+int tgp_dist_fwd_solve_left(tgp_dist* h, int64_t k, int64_t nrhs, const void* y_dev, const void* acc_dev, void* x_dev,
+                            void* xloc_dev);
 int tgp_dist_bwd_block_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev);
 int tgp_dist_bwd_update_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev, int64_t stop_block);
 int tgp_dist_identity_cols(tgp_dist* h, int64_t c0, int64_t nrhs, void* out_dev);

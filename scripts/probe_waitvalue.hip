@@ -1,5 +1,6 @@
-// Can a STREAM wait for a device-side counter without a spinning kernel?  hipStreamWaitValue32 puts the wait into the
-// command processor (no wave, no compute unit, nothing a kernel-serialising tool could dead-lock).  Measured here:
+// Can a STREAM wait for a device-side counter without a spinning kernel of OURS?  hipStreamWaitValue32 -- which turned out
+// to be a one-wave wait kernel of the runtime (__amd_rocclr_streamOpsWait in a kernel trace, profiles/r05_e), not a
+// command-processor packet: as fast as our poll kernel, but without a timeout.  Measured here:
 //   * is it supported, on signal memory (hipMallocSignalMemory, 8 bytes) and on plain hipMalloc memory;
 //   * the hand-off latency producer-kernel atomic -> first instruction of the kernel queued behind the wait,
 //     next to the one-wave poll kernel the chain's followers use today (chain_poll_kernel);

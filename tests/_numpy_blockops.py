@@ -232,6 +232,32 @@ class NumpyBlockOps:
             xn[k * nb:(k + 1) * nb] = sla.solve_triangular(C[k * nb:(k + 1) * nb], xk, lower=True, trans=1,
                                                            check_finite=False)
 
+    def xloc_zeros(self, nrhs):
+        tdt = torch.float64 if self.dtype == np.float64 else torch.float32
+        return torch.zeros((max(self.nloc, 1) * self.nb, nrhs), dtype=tdt)
+
+    def fwd_partial(self, k, nrhs, xloc, acc, first):
+        self.calls.append(("fwd_partial", k))
+        nb = self.nb
+        cols = [l for l in range(self.nloc) if first <= l * self.G + self.rank < k]
+        if not cols:
+            return
+        a = acc.numpy()
+        xl = xloc.numpy()
+        for l in cols:  # (one product on the device; block by block here)
+            a[k * nb:(k + 1) * nb] -= self._col(l)[k * nb:(k + 1) * nb] @ xl[l * nb:(l + 1) * nb]
+
+    def fwd_solve_left(self, k, nrhs, y, acc, x, xloc):
+        self.calls.append(("fwd_block", k))  # (counted like the right-looking step: one reduce per block column)
+        if k % self.G != self.rank:
+            return
+        nb, l = self.nb, k // self.G
+        sl = slice(k * nb, (k + 1) * nb)
+        Lkk = np.tril(self._col(l)[sl])
+        xk = sla.solve_triangular(Lkk, y.numpy()[sl] + acc.numpy()[sl], lower=True, check_finite=False)
+        x.numpy()[sl] = xk
+        xloc.numpy()[l * nb:(l + 1) * nb] = xk
+
     def bwd_block_multi(self, k, nrhs, x):
         self.calls.append(("bwd_block_multi", k))
         if k % self.G != self.rank:

@@ -230,10 +230,10 @@ def test_potrf_block_sizes_agree(nb_outer):
                                   dict(chain_lds_pad=0), dict(nb_outer=512, first_split=3, chain_full_rows=2048),
                                   dict(nb_first=256, chain_full_rows=1024), dict(first_split=0, chain_reserve=0),
                                   # round 5: update tasks on the 4x4x4 MFMA form with LDS-direct operands (measured, not the default); the
-                                  # followers of a chain launch behind the one-wave poll kernel / behind the whole launch
-                                  # (default: a stream wait-value in the command processor)
-                                  dict(chain_fast_update=1), dict(chain_polls=2), dict(chain_polls=0),
-                                  dict(chain_fast_update=1, chain_polls=2, chain_full_rows=0)])
+                                  # followers of a chain launch behind a stream wait-value / behind the whole launch
+                                  # (default: the wall-clock-bounded one-wave poll kernel)
+                                  dict(chain_fast_update=1), dict(chain_polls=3), dict(chain_polls=0),
+                                  dict(chain_fast_update=1, chain_polls=3, chain_full_rows=0)])
 def test_panel_chain_variants_agree(n, opts):
     """The schedules of the panel chain -- the default persistent chain (chain_kernel: tile tasks behind a ticket
     counter, the whole rest of the matrix in one launch once few rows are left), one fused launch per 128-column

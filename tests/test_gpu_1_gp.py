@@ -413,7 +413,8 @@ def test_refactor_is_the_optimizer_step():
 
 
 def test_a_timed_out_hand_off_is_released_and_the_pass_repeated_on_the_per_block_path():
-    """Followers of a chain launch wait in the command processor (stream wait-values): no timeout of their own.  The
+    """With `chain_polls = 3` the followers of a chain launch wait behind hipStreamWaitValue32 -- the runtime's own wait
+    kernel, which has no timeout (the default poll kernel is bounded on the device by wall clock).  The
     host joins such a pass with a deadline; past it, it satisfies the pending waits itself, drains the streams and
     reports TGP_E_TIMEOUT, and the solver repeats the pass ONCE on the launch-per-block path.  The test hook
     `fault_inject = 1` lets the deadline pass while the device is still at work: the result must be the reference's,
@@ -421,8 +422,9 @@ def test_a_timed_out_hand_off_is_released_and_the_pass_repeated_on_the_per_block
     from tinygp_amd import _ffi
 
     ctx = _ffi.default_ctx()
-    if ctx.get_option("chain_polls") != 1 or ctx.get_option("chain_kernel") != 1:
-        pytest.skip("the default schedule (stream wait-values behind the persistent chain) is switched off")
+    if ctx.get_option("chain_kernel") != 1:
+        pytest.skip("the persistent chain is switched off")
+    keep_polls = ctx.set_option("chain_polls", 3)  # followers behind stream wait-values: the mode that needs the host deadline
     n = 4096
     X, y = _cases.synthetic.make_inputs(n, 1)
     k = 1.5**2 * kernels.ExpSquared(2.5)
@@ -434,6 +436,7 @@ def test_a_timed_out_hand_off_is_released_and_the_pass_repeated_on_the_per_block
         got = float(gp.log_probability(y))
     finally:
         ctx.set_option("fault_inject", 0)
+        ctx.set_option("chain_polls", keep_polls)
     np.testing.assert_allclose(got, want, rtol=LL_RTOL)
     assert ctx.get_option("timeout_retries") == before + 1
     assert ctx.get_option("chain_kernel") == 1

@@ -173,6 +173,15 @@ def test_resident_solves_on_the_hip_path(pg):
     got = s.solve_triangular(Y2, transpose=True)
     np.testing.assert_allclose(got, sla.solve_triangular(L, Y2, lower=True, trans=1), rtol=1e-7, atol=1e-7)
     assert calls_b == [(k, 256) for k in reversed(range(s.nblk))]  # nblk block steps for ALL right-hand sides
+    # the LEFT-looking fan-in forward solve (the default with peers; forced here at world size 1): every rank's share of a
+    # block row in ONE product over the blocks it solved itself (split-k tail of gemm_nt), reduce, owner solves
+    s.FORWARD = "left"
+    np.testing.assert_allclose(s.solve_triangular(Y2), sla.solve_triangular(L, Y2, lower=True), rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(s.condition_colsumsq(xt), np.sum(A * A, axis=0), rtol=5e-7, atol=5e-7)
+    np.testing.assert_allclose(s.condition_gram(xt), A.T @ A, rtol=5e-7, atol=5e-7)
+    left1 = s.solve_triangular(Y2)
+    assert np.array_equal(left1, s.solve_triangular(Y2))  # split-k partials combined in slice order: bit-reproducible
+    s.FORWARD = "auto"
     assert calls["panel"] == factored  # not one panel was factored again
     s.ops.close()
 
@@ -195,6 +204,8 @@ def test_gradient_on_the_block_column_path_hip(pg, n, nb, chunk):
     build = lambda m, t: t[0] * m.ExpSquared(t[1]) + t[2] * m.Matern32(t[3])  # noqa: E731
     s = BlockCyclicCholesky(build(kernels, theta0), X, diag, nb=nb, dist=pg)
     s.GRAD_CHUNK = chunk
+    if n == 3000:
+        s.FORWARD = "left"  # (the forward solve the ranks use among peers)
     ll, g = s.log_probability_and_grad(y)
     want_ll, want_g, want_noise, want_alpha = grad_np.log_probability_and_grad(lambda t: build(o, t), theta0, X, diag, y)
     np.testing.assert_allclose(ll, want_ll, rtol=1e-8)

@@ -126,6 +126,8 @@ SIGNATURES = {
     "tgp_dist_colsumsq_owned": [_vp, _i64, _vp, _vp],
     "tgp_dist_gram_owned": [_vp, _i64, _vp, _vp],
     "tgp_dist_abort": [_vp],
+    "tgp_dist_fwd_partial": [_vp, _i64, _i64, _vp, _vp, _i64],
+    "tgp_dist_fwd_solve_left": [_vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "tgp_dist_bwd_block_multi": [_vp, _i64, _i64, _vp],
     "tgp_dist_bwd_update_multi": [_vp, _i64, _i64, _vp, _i64],
     "tgp_dist_identity_cols": [_vp, _i64, _i64, _vp],

@@ -161,7 +161,7 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   int lo = 0, hi = 0;
   TGP_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   {
-    int can = 0;  // stream memory operations: the followers of a chain launch wait in the command processor
+    int can = 0;  // stream memory operations (chain_polls = 3: followers behind hipStreamWaitValue32)
     if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) can = 0;
     (void)hipGetLastError();
     ctx->can_wait_value = can == 1;

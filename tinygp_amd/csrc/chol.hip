@@ -2154,13 +2154,14 @@ int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, 
   }
   const int32_t target = (int32_t)(R - c - ((c == 0 && first_external) ? 1 : 0));
   int32_t* count = ctx->d_chain_ticket + CHAIN_COLCNT_OFF + c;
-  if (ctx->chain_polls == 1 && ctx->can_wait_value) {
-    ctx->wait_values_inflight = true;  // the host joins this factorisation with a deadline (join_bounded)
-    // Round 5: the wait sits in the COMMAND PROCESSOR (hipStreamWaitValue32 on plain device memory: no wave, no
-    // compute unit, nothing a kernel-serialising tool could run in front of the chain launch it waits for).  Measured
-    // hand-off, producer's atomic -> first instruction behind the wait: 1.35 us against the poll kernel's 1.55
-    // (profiles/r05_a, scripts/probe_waitvalue.hip).  The counters are zeroed on the chain's stream in front of
-    // `counters_ready`, which this stream has waited for.  chain_polls = 2 keeps round 4's one-wave poll kernel.
+  if (ctx->chain_polls == 3 && ctx->can_wait_value) {
+    // Round 5, MEASURED, not the default: hipStreamWaitValue32 on the counter instead of our own poll kernel.  It works on
+    // plain device memory and its hand-off is as fast (1.35 us against 1.55, scripts/probe_waitvalue.hip; c2 25.56 vs
+    // 25.53 ms) -- but it is NOT a command-processor wait: the runtime launches a one-wave wait kernel of its own
+    // (__amd_rocclr_streamOpsWait in the kernel trace, 1 664 per 13 evaluations: profiles/r05_e), which spins like ours
+    // and, unlike ours, has no timeout -- under rocprofv3 --pmc it hung for good (profiles/r05_b).  A factorisation that
+    // enqueues these is therefore joined by the host with a deadline (join_bounded).
+    ctx->wait_values_inflight = true;
     TGP_HIP_TRY(hipStreamWaitValue32(st, count, (uint32_t)target, hipStreamWaitValueGte, 0xffffffffu));
     return TGP_OK;
   }

@@ -889,6 +889,66 @@ int tgp_dist_grad_end(tgp_dist* h, double* grad_params, double* grad_logscale, v
   return TGP_OK;
 }
 
+// ---- forward substitution, LEFT-looking fan-in (round 5): the form that SCALES over the ranks ---------------------------
+// tgp_dist_fwd_block above is right-looking: the owner of block column k alone turns x_k into updates of every row below --
+// (N - k nb) x R x nb flops on ONE rank per step while the others wait for the next reduce.  Fine at world size 1 (big
+// products, full chip), serial across ranks.  Left-looking, step k:
+//   every rank:  acc_k -= X[its columns in [first, k)] . L[k, those columns]^T    (tgp_dist_fwd_partial: ONE product per rank,
+//                k-range = its share of the columns left of k -- balanced to within one block over the ranks)
+//   the caller reduces acc_k to owner(k)   (the same ONE nb x R message per block column)
+//   owner(k):    x_k = L_kk^-1 (y_k + acc_k), kept twice: in x (global rows) and in xloc, the rank's OWN solved blocks side
+//                by side (local column l at rows l nb ..) -- the contiguous operand of the next steps' products
+// Only owner(k)'s next product depends on x_k; every other rank's does not: the ranks run ahead of the reduce chain.
+// The product has a small output (R x nb) and a long k-range: fp64 uses the split-k tail of gemm_nt (partial tiles combined
+// in slice order: deterministic).  Buffers: y, acc, x (n_pad, R) row-major, xloc (nloc nb, R) row-major.
+int tgp_dist_fwd_partial(tgp_dist* h, int64_t k, int64_t nrhs, const void* xloc_dev, void* acc_dev, int64_t first_block) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk && xloc_dev && acc_dev && nrhs > 0 && nrhs % TILE == 0 && first_block >= 0,
+                "fwd_partial: bad argument");
+  tgp_ctx* ctx = h->ctx;
+  const int64_t nb = h->nb;
+  int64_t l_begin = (first_block - h->rank + h->G - 1) / h->G;
+  if (l_begin < 0) l_begin = 0;
+  int64_t l_end = (k - h->rank + h->G - 1) / h->G;  // local columns with global index < k
+  if (l_end > h->nloc) l_end = h->nloc;
+  if (l_end <= l_begin) return TGP_OK;
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int64_t ld = h->npad;
+    const T* A = (const T*)xloc_dev + l_begin * nb * nrhs;            // X^T[:, local columns l_begin ..]: (nrhs x K), ld nrhs
+    const T* B = (const T*)h->A + l_begin * nb * ld + k * nb;         // L[block row k, local columns l_begin ..]: (nb x K), ld
+    T* C = (T*)acc_dev + k * nb * nrhs;                               // acc_k^T (nrhs x nb), ld nrhs
+    const int64_t keep = ctx->split_tail;
+    ctx->split_tail = 1;  // few output tiles, long k-range: the split-k tail fills the chip (fp64)
+    const int st = launch_gemm_nt<T>(ctx, ctx->stream, nrhs, nb, (l_end - l_begin) * nb, A, nrhs, B, ld, C, nrhs, 0, 0, 0);
+    ctx->split_tail = keep;
+    return st;
+  });
+}
+
+int tgp_dist_fwd_solve_left(tgp_dist* h, int64_t k, int64_t nrhs, const void* y_dev, const void* acc_dev, void* x_dev,
+                            void* xloc_dev) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk && y_dev && acc_dev && x_dev && xloc_dev && nrhs > 0 && nrhs % TILE == 0,
+                "fwd_solve_left: bad argument");
+  if (owner_of(h, k) != h->rank) return TGP_OK;
+  tgp_ctx* ctx = h->ctx;
+  return ddispatch(h->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const int64_t l = k / h->G, nb = h->nb, ld = h->npad;
+    const T* Lkk = (const T*)h->A + l * nb * ld + k * nb;
+    const T* dk = (const T*)h->dinv + (k * nb / TILE) * 2048;
+    const int64_t cnt = nb * nrhs, off = k * nb * nrhs;
+    T* xk = (T*)x_dev + off;
+    hipLaunchKernelGGL((add_into_kernel<T>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, cnt,
+                       (const T*)y_dev + off, (const T*)acc_dev + off, xk);
+    TGP_HIP_TRY(hipGetLastError());
+    TGP_TRY(trsm_right_lt<T>(ctx, nrhs, nb, Lkk, ld, dk, xk, nrhs));
+    TGP_HIP_TRY(hipMemcpyAsync((T*)xloc_dev + l * nb * nrhs, xk, size_t(cnt) * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    return TGP_OK;
+  });
+}
+
 // out = sum over the OWNED block columns of L[:, k] y_k  (this rank's share of dot_triangular, reference
 // solvers/direct.py:72-73; the caller all-reduces).  Vectors of n_pad entries on the device.
 int tgp_dist_trmv_partial(tgp_dist* h, const void* y_dev, void* out_dev) {

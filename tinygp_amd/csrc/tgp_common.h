@@ -144,8 +144,9 @@ struct tgp_ctx {
   // one-workgroup potf2 (74 KB) on the chain pipeline waited 120-290 us for room (profiles/r04_c)
   int64_t kmat_plain_div = 0;    // tests: the assembly's quotients by the division instruction sequence (kmat.hip, UDiv)
   // followers of a chain launch (forward-substitution steps, early shares) start while it runs, behind
-  // 1: a stream wait-value on the block column's counter (command processor; round 5 default), 2: round 4's one-wave
-  // poll kernel; 0: they wait for the whole launch
+  // 1: a one-wave poll kernel on the block column's counter, bounded by wall clock (default); 3: hipStreamWaitValue32 on
+  // it (the runtime's own one-wave wait kernel: as fast, no timeout -- measured, not the default); 0: they wait for the
+  // whole launch (the default under a counter-collecting profiler, which runs kernels one at a time in its own order)
   int64_t chain_polls = 1;
   bool wait_values_inflight = false;  // this factorisation enqueued stream wait-values: join with a deadline (join_bounded)
   int64_t fault_inject = 0;      // TEST hook. 1: the next bounded join expires at once (exercises rescue + retry), then clears

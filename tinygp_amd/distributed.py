@@ -136,6 +136,7 @@ class HipBlockOps:
         nslot = lib.tgp_dist_slot_elems(n, nb)
         self.nd = (nb // 128) * 2048
         self.npad = -(-n // nb) * nb
+        self.nloc = len(range(rank, self.npad // nb, world))
         self.ring = [self._alloc((nslot,)) for _ in range(3)]
         self.x = self._alloc((self.npad,), zero=True)
         _ffi.check(lib.tgp_stream_sync(self.ctx.handle, MAIN), "tgp_stream_sync")
@@ -245,6 +246,18 @@ class HipBlockOps:
 
     def bwd_block(self, k: int, x):
         _ffi.check(self.lib.tgp_dist_bwd_block(self.h, k, C.c_void_p(x.ptr)), "tgp_dist_bwd_block")
+
+    def xloc_zeros(self, nrhs: int):
+        """This rank's solved blocks side by side (local column l at rows l * nb ..): the left-looking forward solve's operand."""
+        return self._alloc((max(self.nloc, 1) * self.nb, nrhs), zero=True)
+
+    def fwd_partial(self, k: int, nrhs: int, xloc, acc, first: int):
+        _ffi.check(self.lib.tgp_dist_fwd_partial(self.h, k, nrhs, C.c_void_p(xloc.ptr), C.c_void_p(acc.ptr), first),
+                   "tgp_dist_fwd_partial")
+
+    def fwd_solve_left(self, k: int, nrhs: int, y, acc, x, xloc):
+        _ffi.check(self.lib.tgp_dist_fwd_solve_left(self.h, k, nrhs, C.c_void_p(y.ptr), C.c_void_p(acc.ptr),
+                                                    C.c_void_p(x.ptr), C.c_void_p(xloc.ptr)), "tgp_dist_fwd_solve_left")
 
     def bwd_block_multi(self, k: int, nrhs: int, x):
         _ffi.check(self.lib.tgp_dist_bwd_block_multi(self.h, k, nrhs, C.c_void_p(x.ptr)), "tgp_dist_bwd_block_multi")
@@ -532,10 +545,27 @@ class BlockCyclicCholesky:
         needs.  Returns the solved buffer, zero outside the OWNED blocks (``_all_reduce`` replicates it)."""
         ops = self.ops
         acc, x = ops.rhs_zeros(nrhs), ops.rhs_zeros(nrhs)
+        if nrhs > 1 and self._forward_left():
+            # LEFT-looking (round 5): every rank forms its share of block row k's sum from the blocks it has solved itself --
+            # the work of a step is spread over the ranks, and only the owner's next product waits for the reduce chain
+            xloc = ops.xloc_zeros(nrhs)
+            for k in range(first, self.nblk):
+                ops.fwd_partial(k, nrhs, xloc, acc, first)
+                self._reduce_to_owner(ops.rhs_block(acc, k), k)
+                ops.fwd_solve_left(k, nrhs, y_dev, acc, x, xloc)
+            return x
         for k in range(first, self.nblk):  # (`first`: right-hand sides that are zero above that block -- identity columns)
             self._reduce_to_owner(ops.rhs_block(acc, k), k)
             ops.fwd_block(k, nrhs, y_dev, acc, x)
         return x
+
+    FORWARD = os.environ.get("TGP_DIST_FORWARD", "auto")  # "left" | "right" | "auto" (left with peers, right alone)
+
+    def _forward_left(self) -> bool:
+        """Right-looking: the owner of block column k alone updates every row below (big products: the better form on ONE
+        GPU, serial across ranks).  Left-looking: balanced over the ranks (small outputs, long k-ranges: split-k)."""
+        mode = self.FORWARD
+        return mode == "left" or (mode == "auto" and self.G > 1)
 
     def _backward(self, x, nrhs: int, stop: int = 0):
         """``L^-T Y`` in place for ``nrhs`` (a multiple of 128) right-hand sides, right-looking: block ``k`` from the last
