@@ -398,9 +398,11 @@ int tgp_dist_abort(tgp_dist* h);
 
 /* Round 5.  Backward substitution with MANY right-hand sides on the resident distributed factor (reference
  * solvers/direct.py:66-68, trans=1, y (N, R)): right-looking, block k from the last to the first --
- *   tgp_dist_bwd_block_multi   owner(k): X_k = L_kk^-T Y_k in place;  the caller broadcasts X_k (ONE nb x R message);
- *   tgp_dist_bwd_update_multi  every rank: Y_i -= L[k, i]^T X_k for its OWN block columns i in [stop_block, k).
- * Buffers as tgp_dist_fwd_block: (n_pad, nrhs) ROW-major device memory, nrhs a multiple of 128.
+ *   tgp_dist_bwd_block_multi   owner(k): X_k = L_kk^-T Y_k into block k of x;  the caller broadcasts it (ONE nb x R message);
+ *   tgp_dist_bwd_update_multi  every rank: Y_i -= L[k, i]^T X_k for its OWN block columns i in [stop_block, k) -- ONE product.
+ * x: (n_pad, nrhs) ROW-major device memory, nrhs a multiple of 128 (as tgp_dist_fwd_block); yloc: the rank's OWN blocks of the
+ * right-hand sides side by side, (nloc * nb, nrhs) row-major -- what tgp_dist_fwd_solve_left leaves in xloc, or
+ * tgp_dist_gather_owned of a global buffer (world size 1: the two layouts coincide, pass x itself).
  * tgp_dist_identity_cols fills such a buffer with columns c0 .. c0 + nrhs - 1 of the identity. */
 /* Forward substitution with many right-hand sides, LEFT-looking fan-in (the form that scales over the ranks; the
  * right-looking tgp_dist_fwd_block is the better one at world size 1): step k --
@@ -411,8 +413,9 @@ int tgp_dist_abort(tgp_dist* h);
 int tgp_dist_fwd_partial(tgp_dist* h, int64_t k, int64_t nrhs, const void* xloc_dev, void* acc_dev, int64_t first_block);
 int tgp_dist_fwd_solve_left(tgp_dist* h, int64_t k, int64_t nrhs, const void* y_dev, const void* acc_dev, void* x_dev,
                             void* xloc_dev);
-int tgp_dist_bwd_block_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev);
-int tgp_dist_bwd_update_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev, int64_t stop_block);
+int tgp_dist_bwd_block_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev, const void* yloc_dev);
+int tgp_dist_bwd_update_multi(tgp_dist* h, int64_t k, int64_t nrhs, const void* x_dev, void* yloc_dev, int64_t stop_block);
+int tgp_dist_gather_owned(tgp_dist* h, int64_t nrhs, const void* x_dev, void* yloc_dev);
 int tgp_dist_identity_cols(tgp_dist* h, int64_t c0, int64_t nrhs, void* out_dev);
 
 /* Gradient of log_probability on the block-column path -- what jax.value_and_grad of reference gp.py:126-138 gives a caller

@@ -258,25 +258,32 @@ class NumpyBlockOps:
         x.numpy()[sl] = xk
         xloc.numpy()[l * nb:(l + 1) * nb] = xk
 
-    def bwd_block_multi(self, k, nrhs, x):
+    def gather_owned(self, x, nrhs, world):
+        nb = self.nb
+        yloc = self.xloc_zeros(nrhs)
+        for l in range(self.nloc):
+            i = l * self.G + self.rank
+            yloc.numpy()[l * nb:(l + 1) * nb] = x.numpy()[i * nb:(i + 1) * nb]
+        return yloc
+
+    def bwd_block_multi(self, k, nrhs, x, yloc):
         self.calls.append(("bwd_block_multi", k))
         if k % self.G != self.rank:
             return
-        nb = self.nb
-        Lkk = np.tril(self._col(k // self.G)[k * nb:(k + 1) * nb])
-        xv = x.numpy()
-        xv[k * nb:(k + 1) * nb] = sla.solve_triangular(Lkk, xv[k * nb:(k + 1) * nb], lower=True, trans=1,
-                                                       check_finite=False)
+        nb, l = self.nb, k // self.G
+        Lkk = np.tril(self._col(l)[k * nb:(k + 1) * nb])
+        x.numpy()[k * nb:(k + 1) * nb] = sla.solve_triangular(Lkk, yloc.numpy()[l * nb:(l + 1) * nb], lower=True, trans=1,
+                                                              check_finite=False)
 
-    def bwd_update_multi(self, k, nrhs, x, stop):
+    def bwd_update_multi(self, k, nrhs, x, yloc, stop):
         self.calls.append(("bwd_update_multi", k, stop))
         nb = self.nb
-        xv = x.numpy()
-        xk = xv[k * nb:(k + 1) * nb]
+        xk = x.numpy()[k * nb:(k + 1) * nb]
+        yl = yloc.numpy()
         for l in range(self.nloc):
             i = l * self.G + self.rank
             if stop <= i < k:
-                xv[i * nb:(i + 1) * nb] -= self._col(l)[k * nb:(k + 1) * nb].T @ xk
+                yl[l * nb:(l + 1) * nb] -= self._col(l)[k * nb:(k + 1) * nb].T @ xk
 
     def rhs_identity(self, c0, nrhs):
         buf = self.rhs_zeros(nrhs)

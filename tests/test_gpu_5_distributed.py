@@ -169,7 +169,7 @@ def test_resident_solves_on_the_hip_path(pg):
     Y2 = np.random.default_rng(4).normal(size=(n, 200))  # 200 -> padded to 256 right-hand sides
     calls_b = []
     real_b = s.ops.bwd_block_multi
-    s.ops.bwd_block_multi = lambda k, r, x: (calls_b.append((k, r)), real_b(k, r, x))[1]
+    s.ops.bwd_block_multi = lambda k, r, x, yl: (calls_b.append((k, r)), real_b(k, r, x, yl))[1]
     got = s.solve_triangular(Y2, transpose=True)
     np.testing.assert_allclose(got, sla.solve_triangular(L, Y2, lower=True, trans=1), rtol=1e-7, atol=1e-7)
     assert calls_b == [(k, 256) for k in reversed(range(s.nblk))]  # nblk block steps for ALL right-hand sides

@@ -128,8 +128,9 @@ SIGNATURES = {
     "tgp_dist_abort": [_vp],
     "tgp_dist_fwd_partial": [_vp, _i64, _i64, _vp, _vp, _i64],
     "tgp_dist_fwd_solve_left": [_vp, _i64, _i64, _vp, _vp, _vp, _vp],
-    "tgp_dist_bwd_block_multi": [_vp, _i64, _i64, _vp],
-    "tgp_dist_bwd_update_multi": [_vp, _i64, _i64, _vp, _i64],
+    "tgp_dist_bwd_block_multi": [_vp, _i64, _i64, _vp, _vp],
+    "tgp_dist_bwd_update_multi": [_vp, _i64, _i64, _vp, _vp, _i64],
+    "tgp_dist_gather_owned": [_vp, _i64, _vp, _vp],
     "tgp_dist_identity_cols": [_vp, _i64, _i64, _vp],
     "tgp_dist_grad_begin": [_vp, _pkop, _int],
     "tgp_dist_grad_chunk": [_vp, _i64, _i64, _vp, _i32],

@@ -725,7 +725,9 @@ int tgp_dist_fwd_block(tgp_dist* h, int64_t k, int64_t nrhs, const void* y_dev, 
 // Right-looking ("fan-out"): block k from the last to the first --
 //   owner(k):  X_k = L_kk^-T Y_k                                    (tgp_dist_bwd_block_multi; Y_k carries every update)
 //   the caller broadcasts X_k (ONE nb x R message per block column)
-//   everyone:  Y_i -= L[k, i]^T X_k  for its OWN block columns i < k  (tgp_dist_bwd_update_multi)
+//   everyone:  Y_i -= L[k, i]^T X_k  for its OWN block columns i < k  (tgp_dist_bwd_update_multi: ONE product -- the rank's
+//              right-hand-side blocks live side by side in `yloc`, (nloc nb, R) row-major, local column l at rows l nb ..;
+//              the left-looking forward solve's xloc IS that layout, tgp_dist_gather_owned makes it from a global buffer)
 // -- a rank only ever touches the blocks of L it owns (block row k of its own columns) and the right-hand-side blocks it
 // owns: no reduction, and every product has the short dimension (nb) as its k-range, so it fills the chip.  (The
 // row-oriented form of the single right-hand side -- x_k from a dot product over all rows below -- would be R x nb
@@ -746,11 +748,17 @@ static int bwd_scratch(tgp_dist* h, size_t bytes) {
   return TGP_OK;
 }
 
-int tgp_dist_bwd_block_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev) {
+int tgp_dist_bwd_block_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev, const void* yloc_dev) {
   DIST_GUARD(h);
-  TGP_ARG_CHECK(k >= 0 && k < h->nblk && x_dev != nullptr && nrhs > 0 && nrhs % TILE == 0,
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk && x_dev != nullptr && yloc_dev != nullptr && nrhs > 0 && nrhs % TILE == 0,
                 "bwd_block_multi: bad argument (nrhs must be a multiple of %d)", TILE);
   if (owner_of(h, k) != h->rank) return TGP_OK;
+  {  // Y_k with every update applied lives in yloc (this rank's blocks side by side): into its place in x, solved there
+    const size_t es_ = esz(h->dtype), bytes = size_t(h->nb) * nrhs * es_;
+    const char* src = (const char*)yloc_dev + size_t(k / h->G) * bytes;
+    char* dst = (char*)x_dev + size_t(k) * bytes;
+    if (src != dst) TGP_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->ctx->stream));
+  }
   tgp_ctx* ctx = h->ctx;
   const int64_t nb = h->nb, nd = (nb / TILE) * 2048;
   const size_t es = esz(h->dtype);
@@ -778,10 +786,10 @@ int tgp_dist_bwd_block_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev) 
   });
 }
 
-int tgp_dist_bwd_update_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev, int64_t stop_block) {
+int tgp_dist_bwd_update_multi(tgp_dist* h, int64_t k, int64_t nrhs, const void* x_dev, void* yloc_dev, int64_t stop_block) {
   DIST_GUARD(h);
-  TGP_ARG_CHECK(k >= 0 && k < h->nblk && x_dev != nullptr && nrhs > 0 && nrhs % TILE == 0 && stop_block >= 0,
-                "bwd_update_multi: bad argument");
+  TGP_ARG_CHECK(k >= 0 && k < h->nblk && x_dev != nullptr && yloc_dev != nullptr && nrhs > 0 && nrhs % TILE == 0 &&
+                    stop_block >= 0, "bwd_update_multi: bad argument");
   tgp_ctx* ctx = h->ctx;
   const int64_t nb = h->nb;
   // owned block columns i in [stop_block, k): local indices l with l * G + rank in that range
@@ -797,21 +805,32 @@ int tgp_dist_bwd_update_multi(tgp_dist* h, int64_t k, int64_t nrhs, void* x_dev,
     const int64_t ld = h->npad;
     const T* Xk = (const T*)x_dev + k * nb * nrhs;
     T* Tt = (T*)h->bwd_ws;
-    // block row k of the owned columns l_begin .. l_end - 1: side by side in A_loc, one transpose launch:
-    // src (nb rows x cnt*nb columns, ld) -> dst (cnt*nb x nb, leading dimension cnt*nb): block q's transpose is rows
-    // q*nb .. of dst, i.e. T_q[c][m] at m * (cnt*nb) + q*nb + c
+    // block row k of the owned columns l_begin .. l_end - 1 (side by side in A_loc) -> its transpose (cnt*nb x nb, leading
+    // dimension cnt*nb): gemm_nt's second operand B[c][m] = L[k nb + m, column c of those] at m * (cnt*nb) + c
     const T* src = (const T*)h->A + l_begin * nb * ld + k * nb;
     hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)(nb / 32), (unsigned)(cnt * nb / 32)), dim3(256), 0, ctx->stream,
                        nb, cnt * nb, src, ld, Tt, cnt * nb);
     TGP_HIP_TRY(hipGetLastError());
-    for (int64_t q = 0; q < cnt; ++q) {
-      const int64_t i = (l_begin + q) * h->G + h->rank;
-      // Y_i^T (nrhs x nb) -= X_k^T (nrhs x nb) . L[k, i]  =  A B^T with B = L[k, i]^T (nb x nb, leading dimension cnt*nb)
-      TGP_TRY(launch_gemm_nt<T>(ctx, ctx->stream, nrhs, nb, nb, Xk, nrhs, Tt + q * nb, cnt * nb,
-                                (T*)x_dev + i * nb * nrhs, nrhs, 0, 0, 1));
-    }
-    return TGP_OK;
+    // ONE product for all of them: the rank's right-hand-side blocks are CONTIGUOUS in yloc (local column l at rows l nb ..),
+    //   Yloc^T[:, l_begin nb .. l_end nb) (nrhs x cnt*nb) -= X_k^T (nrhs x nb) . L[k, those columns]
+    // (with the blocks where the global layout has them this was cnt small launches of nrhs/128 x nb/128 tiles each, one
+    // k-loop deep: N = 65 536, 64 right-hand sides: 2 080 launches, 336 ms -- profiles/r05_f)
+    return launch_gemm_nt<T>(ctx, ctx->stream, nrhs, cnt * nb, nb, Xk, nrhs, Tt, cnt * nb,
+                             (T*)yloc_dev + l_begin * nb * nrhs, nrhs, 0, 0, 1);
   });
+}
+
+// yloc (nloc nb, nrhs) <- this rank's blocks of x (n_pad, nrhs), side by side (world size 1: the same layout -- pass x itself)
+int tgp_dist_gather_owned(tgp_dist* h, int64_t nrhs, const void* x_dev, void* yloc_dev) {
+  DIST_GUARD(h);
+  TGP_ARG_CHECK(x_dev && yloc_dev && nrhs > 0, "gather_owned: bad argument");
+  const size_t bytes = size_t(h->nb) * nrhs * esz(h->dtype);
+  for (int64_t l = 0; l < h->nloc; ++l) {
+    const char* src = (const char*)x_dev + size_t(l * h->G + h->rank) * bytes;
+    char* dst = (char*)yloc_dev + size_t(l) * bytes;
+    if (src != dst) TGP_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->ctx->stream));
+  }
+  return TGP_OK;
 }
 
 // (n_pad, nrhs) row-major device buffer <- columns c0 .. c0 + nrhs - 1 of the identity (the right-hand sides behind
