@@ -59,7 +59,14 @@ def _worker(rank, world, port, n, nb, q):
         fwd = s.solve_triangular(y)
         csq = s.condition_colsumsq(xt)
         ll_new = s.resident_log_probability(3.0 * y + 1.0)
-        q.put((rank, float(ll), s.info, mean, s.bytes_received, fwd, csq, float(ll_new)))
+        # round 5: ONE blocked pass for (N, R) transposed, value-and-gradient (left-looking forward + right-looking backward
+        # solves of K^-1's column chunks among peers), collectives issued by the library (RcclComm; torch carried the id)
+        Y = np.random.default_rng(3).normal(size=(n, 5))
+        bwdR = s.solve_triangular(Y, transpose=True)
+        s.GRAD_CHUNK = 1024
+        gll, grad = s.log_probability_and_grad(y)
+        q.put((rank, float(ll), s.info, mean, s.bytes_received, fwd, csq, float(ll_new), bwdR, float(gll),
+               np.array(grad["kernel"]), type(s.comm).__name__))
         s.ops.close()
     finally:
         dist.destroy_process_group()
@@ -93,8 +100,18 @@ def test_block_column_path_over_rccl_with_two_ranks(n, nb):
     A = sla.solve_triangular(L, _k(o)(X, xt), lower=True)
     nblk = -(-n // nb)
     npad = nblk * nb
-    for rank, ll, info, mean, nbytes, fwd, csq, ll_new in out:
-        assert info == 0
+    from oracle import grad_np
+
+    Y = np.random.default_rng(3).normal(size=(n, 5))
+    want_grad = grad_np.log_probability_and_grad(lambda t: t[0] * o.ExpSquared(t[1]) + t[2] * o.Matern32(t[3]),
+                                                 np.array([1.5**2, 2.5, 0.3, 1.2]), X, 0.01, y)[1] if n <= 6000 else None
+    for rank, ll, info, mean, nbytes, fwd, csq, ll_new, bwdR, gll, gk, comm_name in out:
+        assert info == 0 and comm_name == "RcclComm"
+        np.testing.assert_allclose(bwdR, sla.solve_triangular(L, Y, lower=True, trans=1), rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(gll, float(gp.log_probability(y)), rtol=1e-8)
+        if want_grad is not None:
+            np.testing.assert_allclose([gk[2 * i] for i in (0, 1, 3, 4)], want_grad, rtol=2e-6,
+                                       atol=2e-6 * np.abs(want_grad).max())
         np.testing.assert_allclose(ll, float(gp.log_probability(y)), rtol=1e-8)
         np.testing.assert_allclose(mean, gp.predict(y, xt), rtol=5e-7, atol=5e-7)
         np.testing.assert_allclose(fwd, sla.solve_triangular(L, y, lower=True), rtol=1e-7, atol=1e-8)
@@ -104,6 +121,60 @@ def test_block_column_path_over_rccl_with_two_ranks(n, nb):
         assert nbytes == expect
     assert out[0][1] == out[1][1] and out[0][7] == out[1][7]            # bit-identical scalars on both ranks
     assert np.array_equal(out[0][3], out[1][3]) and np.array_equal(out[0][5], out[1][5])
+    assert np.array_equal(out[0][8], out[1][8]) and np.array_equal(out[0][10], out[1][10])
+
+
+_TWO_RANKS_NO_TORCH = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["TGP_ROOT"])
+from tinygp_amd import GaussianProcess, kernels, synthetic
+from tinygp_amd.solvers import DistributedDirectSolver
+n = 6000
+X, y = synthetic.make_inputs(n, 1)
+gp = GaussianProcess(1.5**2 * kernels.ExpSquared(2.5), X, diag=0.01, solver=DistributedDirectSolver, nb=512)
+ll = float(gp.log_probability(y))
+cond = gp.condition(y, np.linspace(X[0], X[-1], 33))
+mu, var = np.array(cond.gp.loc), np.array(cond.gp.variance)
+assert "torch" not in sys.modules and type(gp.solver._bc.comm).__name__ == "RcclComm" and gp.solver._bc.comm.world == 2
+np.savez(os.environ["TGP_TEST_OUT"] + os.environ["RANK"], ll=ll, mu=mu, var=var)
+gp.solver.close()
+print("OK")
+"""
+
+
+@needs_two
+def test_two_ranks_without_torch_in_the_process(tmp_path):
+    """The launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*), the communicator id over TCP, RCCL from the C
+    ABI: a sharded GaussianProcess with no torch anywhere."""
+    from oracle import tinygp_np as o
+    from tinygp_amd import synthetic
+
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, TGP_ROOT=str(ROOT), TGP_TEST_OUT=str(tmp_path / "res"), RANK=str(r), WORLD_SIZE="2",
+                   LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29941")
+        env.pop("PYTHONPATH", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", _TWO_RANKS_NO_TORCH], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            p.kill()  # (the exact process this test started)
+            outs.append(p.communicate())
+    assert all(p.returncode == 0 and "OK" in o_[0] for p, o_ in zip(procs, outs)), [o_[1][-1500:] for o_ in outs]
+    X, y = synthetic.make_inputs(6000, 1)
+    ref = o.GaussianProcess(1.5**2 * o.ExpSquared(2.5), X, diag=0.01)
+    rc = ref.condition(y, np.linspace(X[0], X[-1], 33))
+    want_mu, want_var = rc.gp.loc, rc.gp.variance
+    res = [np.load(str(tmp_path / "res") + f"{r}.npz") for r in range(2)]
+    for g in res:
+        np.testing.assert_allclose(g["ll"], float(ref.log_probability(y)), rtol=1e-8)
+        np.testing.assert_allclose(g["mu"], want_mu, rtol=5e-7, atol=5e-7)
+        np.testing.assert_allclose(g["var"], want_var, rtol=5e-7, atol=5e-7)
+    assert float(res[0]["ll"]) == float(res[1]["ll"])
 
 
 @needs_two
