@@ -37,7 +37,8 @@ extern "C" {
  *  round 3 -> 4: tgp_chain_stamps, tgp_chain_task, the resident-factor solves of the block-column driver -- tgp_dist_fwd_block,
  *  _bwd_block, _trmv_partial, _cross_cov, _colsumsq_owned, _gram_owned -- and tgp_dist_abort added;
  *  round 4 -> 5: tgp_comm_* (RCCL from the C ABI), tgp_stream_* transfers, TGP_E_TIMEOUT, options poll_timeout_ms /
- *  chain_fast_update, chain_polls = 1 now means a stream wait-value; tgp_dist_bwd_*_multi, tgp_dist_identity_cols,
+ *  chain_fast_update / host_join, chain_polls = 3 (stream wait-value); tgp_dist_fwd_partial / _fwd_solve_left,
+ *  tgp_dist_bwd_*_multi, tgp_dist_gather_owned, tgp_dist_identity_cols,
  *  tgp_dist_grad_* -- multi-RHS backward solve and gradient on the block-column path) */
 #define TGP_ABI_VERSION 5
 
@@ -125,9 +126,19 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       carries trailing updates only;  "chain_lds_pad" (10240): unused dynamic LDS that keeps a
  *                       second chain workgroup off a compute unit;  "chain_pre_wait" (0): pre(p) behind the next
  *                       panel's first potf2 on chain-bound panels;  "chain_polls" (1): consumers of a block column
- *                       (forward steps, early shares) follow behind a one-wave poll while the launch runs; 0: behind
- *                       the whole launch -- for profilers that run kernels one at a time (rocprofv3 --pmc);
- *                       "chain_stamps" (0): tgp_chain_stamps below
+ *                       (forward steps, early shares) follow behind a one-wave poll, bounded by wall clock, while the
+ *                       launch runs; 3: behind hipStreamWaitValue32 (the runtime's own one-wave wait kernel, no timeout:
+ *                       the host then joins the pass with a deadline); 0: behind the whole launch -- the DEFAULT of a
+ *                       context created under a counter-collecting profiler (ROCPROF_COUNTER_COLLECTION, i.e.
+ *                       rocprofv3 --pmc, or TGP_SERIALIZED_KERNELS=1), which runs kernels one at a time in its own order;
+ *                       "chain_fast_update" (0): fp64 update tasks on the 4x4x4 MFMA form with LDS-direct operands
+ *                       (measured slower: DESIGN 4.2);  "chain_stamps" (0): tgp_chain_stamps below
+ *   "poll_timeout_ms"   wall-clock bound of every device-side wait (default 4000; one value per process and device).  A
+ *                       wait that expires makes the call return TGP_E_TIMEOUT; tgp_solver_factor* has then already
+ *                       repeated the pass ONCE on the launch-per-block path ("timeout_retries" counts them; read-only).
+ *                       "host_join" (1): passes that enqueued stream wait-values are joined by polling an event with a
+ *                       deadline instead of hipStreamSynchronize;  "fault_inject" (0): TEST hook, 1 = the next such
+ *                       deadline has passed at once
  *   "kmat_plain_div"    1: the straight-line assembly kernel takes r / l, r^2 / l^2 by the division sequence instead
  *                       of the bit-identical reciprocal + FMA form (kmat.hip, UDiv) -- the tests' switch
  *   "chain_reserve"     workgroup slots (of two per CU) that a trailing update running beside a panel

@@ -100,7 +100,7 @@ class HipBlockOps:
         self._pool_bytes = 0
 
     # -- buffers ---------------------------------------------------------------------------
-    POOL_LIMIT = 8 << 30
+    POOL_LIMIT = 32 << 30  # (an MI355X has 288 GB; the gradient at N = 131 072 cycles through four 2-GB buffers per chunk)
 
     def _alloc(self, shape, dtype=None, zero=False) -> DevBuf:
         dtype = self.dtype if dtype is None else np.dtype(dtype)
