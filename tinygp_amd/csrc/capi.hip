@@ -115,9 +115,19 @@ static int assemble_lower(tgp_ctx* ctx, const tgp::KProg& kp, int64_t n, int d, 
   }
   TGP_TRY(launch_kmat_cols<T>(ctx, ctx->stream, kp, n, n, d, X, X, diag, A, npad, npad, npad, flags, 0, t1));
   if (t1 < tc) {
-    TGP_TRY(launch_kmat_cols<T>(ctx, ctx->asm_stream, kp, n, n, d, X, X, diag, A, npad, npad, npad,
-                                flags, t1, tc - t1));
-    TGP_TRY(ev_record(ctx, ctx->ev_asm, ctx->asm_stream));
+    auto side = [=]() -> int {
+      TGP_TRY(launch_kmat_cols<T>(ctx, ctx->asm_stream, kp, n, n, d, X, X, diag, A, npad, npad, npad,
+                                  flags, t1, tc - t1));
+      return ev_record(ctx, ctx->ev_asm, ctx->asm_stream);
+    };
+    if (ctx->asm_defer != 0) {
+      // Round 5 experiment: the other columns' assembly saturates the memory system for 0.25 ms, and the first panel's
+      // potf2 -- one workgroup, latency-bound -- took 163 us beside it instead of 27 (profiles/r05_e).  Deferred: potrf
+      // launches it behind that potf2 (run_deferred_asm in chol.hip).
+      ctx->deferred_asm = side;
+    } else {
+      TGP_TRY(side());
+    }
     ctx->asm_pending = true;
   }
   return TGP_OK;
@@ -223,6 +233,7 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
   }
   if (ctx->ev_c) hipEventDestroy(ctx->ev_c);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_asm_gate) hipEventDestroy(ctx->ev_asm_gate);
   if (ctx->rescue_stream) hipStreamDestroy(ctx->rescue_stream);
   if (ctx->update_stream) {
     hipStreamSynchronize(ctx->update_stream);
@@ -294,6 +305,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "split_tail")) return &ctx->split_tail;
   if (!strcmp(key, "gemm_role")) return &ctx->gemm_role;
   if (!strcmp(key, "host_join")) return &ctx->host_join;
+  if (!strcmp(key, "asm_defer")) return &ctx->asm_defer;
   if (!strcmp(key, "fault_inject")) return &ctx->fault_inject;
   if (!strcmp(key, "poll_timeout_ms")) return &ctx->poll_timeout_ms;
   if (!strcmp(key, "timeout_retries")) return &ctx->timeout_retries;  // (read: passes repeated after a device-side timeout)
@@ -631,6 +643,7 @@ static int factor_impl(tgp_solver* s, const tgp_kop* prog, int nops, const void*
       if (q) (void)hipStreamSynchronize(q);
     (void)hipGetLastError();
     ctx->asm_pending = false;
+    ctx->deferred_asm = nullptr;
     ctx->ev_used = 0;
     ctx->timeout_retries++;
     const int64_t keep = ctx->chain_kernel;
@@ -641,6 +654,7 @@ static int factor_impl(tgp_solver* s, const tgp_kop* prog, int nops, const void*
   if (st < 0) {
     tgp_ctx* ctx = s->ctx;
     ctx->asm_pending = false;
+    ctx->deferred_asm = nullptr;
     ctx->ev_used = 0;
     s->factored = false;
     for (hipStream_t q : {ctx->asm_stream, ctx->panel_stream, ctx->update_stream, ctx->solve_stream,

@@ -1991,6 +1991,20 @@ __global__ __launch_bounds__(512) void trsv_bwd_stream_kernel(int nblk, const T*
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
+// the side-stream assembly that assemble_lower held back (ctx option asm_defer): now, behind everything queued on `behind`
+// (NULL: at once)
+int run_deferred_asm(tgp_ctx* ctx, hipStream_t behind) {
+  if (!ctx->deferred_asm) return TGP_OK;
+  auto f = std::move(ctx->deferred_asm);
+  ctx->deferred_asm = nullptr;
+  if (behind != nullptr && ctx->asm_stream != nullptr) {
+    if (ctx->ev_asm_gate == nullptr) TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_asm_gate, hipEventDisableTiming));
+    TGP_HIP_TRY(hipEventRecord(ctx->ev_asm_gate, behind));
+    TGP_HIP_TRY(hipStreamWaitEvent(ctx->asm_stream, ctx->ev_asm_gate, 0));
+  }
+  return f();
+}
+
 int set_poll_limit(tgp_ctx* ctx, int64_t ms) {
   TGP_ARG_CHECK(ms >= 1 && ms <= 3600000, "poll_timeout_ms must be in [1, 3600000]");
   const long long ticks = (long long)ms * 100000LL;  // s_memrealtime: 100 MHz
@@ -2098,7 +2112,10 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
                 "chain: bad panel shape (R=%lld, columns [%lld, %lld))", (long long)R, (long long)cb, (long long)ce);
   // a panel's first block has no in-panel update pending: plain potf2 in front of the launch (in the look-ahead
   // schedule it already ran on the main stream, in front of the big update: head_done)
-  if (cb == 0 && !head_done) TGP_TRY(launch_potf2<T>(ctx, st, A0, ld, dinv0, ctx->d_info, (int32_t)pivot_base));
+  if (cb == 0 && !head_done) {
+    TGP_TRY(launch_potf2<T>(ctx, st, A0, ld, dinv0, ctx->d_info, (int32_t)pivot_base));
+    if (!ctx->trace) TGP_TRY(run_deferred_asm(ctx, st));  // (asm_defer: the other columns' assembly behind the first potf2)
+  }
   // the pollers of the previous launch read the counters this launch zeroes: they must be through
   if (ctx->chain_polls_pending) {
     TGP_TRY(st_wait(ctx, st, ctx->ev_f));
@@ -2437,6 +2454,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
 
   // columns right of the first panel may still be in assembly (capi.hip, factor_impl)
   auto join_assembly = [&]() -> int {
+    TGP_TRY(run_deferred_asm(ctx, nullptr));
     if (ctx->asm_pending) {
       TGP_TRY(st_wait(ctx, S0, ctx->ev_asm));
       ctx->asm_pending = false;
@@ -2480,6 +2498,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     TGP_TRY(ev_record(ctx, ctx->ev_a, S0));
     TGP_TRY(st_wait(ctx, S1, ctx->ev_a));
     TGP_TRY(panel(S1, 0, s0[1] - s0[0], false, 0, no_mid));
+    TGP_TRY(run_deferred_asm(ctx, nullptr));  // (whatever form the first panel took: ev_asm is recorded from here on)
     TGP_TRY(ev_record(ctx, ev_chain[0], S1));
     for (int64_t p = 0; p + 1 < P; ++p) {
       const int64_t kb = s0[p + 1] - s0[p], next = s0[p + 1], wn = s0[p + 2] - s0[p + 1], mt = n - next;

@@ -149,6 +149,9 @@ struct tgp_ctx {
   // whole launch (the default under a counter-collecting profiler, which runs kernels one at a time in its own order)
   int64_t chain_polls = 1;
   bool wait_values_inflight = false;  // this factorisation enqueued stream wait-values: join with a deadline (join_bounded)
+  int64_t asm_defer = 0;         // 1: the side-stream assembly of the columns right of the first panel starts behind the first potf2
+  std::function<int()> deferred_asm;  // ... the launch that was held back (cleared when run)
+  hipEvent_t ev_asm_gate = nullptr;
   int64_t fault_inject = 0;      // TEST hook. 1: the next bounded join expires at once (exercises rescue + retry), then clears
   int64_t host_join = 1;         // 0: plain hipStreamSynchronize even then (A/B of the polling join)
   bool serializing_tool = false; // a counter-collecting profiler is attached (ROCPROF_COUNTER_COLLECTION): chain_polls defaults to 0
@@ -313,6 +316,7 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
 int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, int64_t R, int64_t c, bool first_external);
 int set_poll_limit(tgp_ctx* ctx, int64_t ms);
 int join_bounded(tgp_ctx* ctx, hipStream_t st, int64_t n);
+int run_deferred_asm(tgp_ctx* ctx, hipStream_t behind);
 template <typename T>
 int panel_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int64_t pivot_off,
                 int64_t j0, bool pend);
