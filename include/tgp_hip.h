@@ -522,6 +522,12 @@ int tgp_stream_d2d(tgp_ctx* ctx, int which, void* dst_dev, const void* src_dev, 
 int tgp_stream_memset(tgp_ctx* ctx, int which, void* dst_dev, int byte, int64_t bytes);
 int tgp_stream_sync(tgp_ctx* ctx, int which);
 
+/* Test hook, host only: the MFMA products' workgroup-id -> output-tile map (csrc/tile_order.h, the text the kernels decode
+ * their ids with) for tm x tn tiles (`lower`: tiles ti >= tj only, tn <= tm) in the order `band` selects (0: column by column;
+ * > 0: bands of that many tile rows -- ctx option "tile_band").  *n_tiles = ids of the launch; id >= 0: its (ti, tj).
+ * tests/test_host_logic.py checks that every order is a bijection onto the tiles. */
+int tgp_tile_order(int64_t tm, int64_t tn, int32_t lower, int32_t band, int64_t id, int32_t* ti, int32_t* tj, int64_t* n_tiles);
+
 #ifdef __cplusplus
 }
 #endif

@@ -301,3 +301,32 @@ def test_transform_gradient_is_only_attributed_to_a_transform_that_covers_every_
     assert covering_transform(k1 + k2) is None             # no transform at all
     assert covering_transform(transforms.Linear(np.ones(3), lin)) is None  # nested: two parameters, one device result
     assert covering_transform(lin + transforms.Linear(np.ones(3), k2)) is None
+
+
+@pytest.mark.parametrize("tm,tn,lower", [(1, 1, 1), (7, 7, 1), (120, 120, 1), (112, 8, 1), (37, 5, 1), (16, 16, 1), (33, 16, 1),
+                                         (9, 4, 0), (120, 8, 0), (5, 11, 0)])
+@pytest.mark.parametrize("band", [0, 1, 4, 8, 16, 32, 1000])
+def test_tile_orders_are_bijections(tm, tn, lower, band):
+    """csrc/tile_order.h through the library's test hook: whatever order the ctx option tile_band selects, the ids of a launch
+    hit every output tile exactly once (lower: the tiles ti >= tj only), and a band's tiles stay inside its rows."""
+    import ctypes as C
+
+    from tinygp_amd import _ffi
+
+    lib = _ffi.lib()
+    n = C.c_int64()
+    _ffi.check(lib.tgp_tile_order(tm, tn, lower, band, -1, None, None, C.byref(n)), "tgp_tile_order")
+    want = {(i, j) for j in range(tn) for i in range(tm) if not lower or i >= j}
+    assert n.value == len(want)
+    ti, tj = C.c_int32(), C.c_int32()
+    got, order = set(), []
+    for b in range(n.value):
+        _ffi.check(lib.tgp_tile_order(tm, tn, lower, band, b, C.byref(ti), C.byref(tj), None), "tgp_tile_order")
+        got.add((ti.value, tj.value))
+        order.append((ti.value, tj.value))
+    assert got == want and len(order) == len(want)
+    if band > 0:  # band-major, then column-major inside a band
+        keys = [(i // band, j, i) for i, j in order]
+        assert keys == sorted(keys)
+    else:
+        assert order == sorted(order, key=lambda t: (t[1], t[0]))

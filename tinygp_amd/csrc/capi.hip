@@ -8,6 +8,8 @@
 #include "tgp_common.h"
 #define CHAIN_HD __host__ __device__
 #include "chain_tasks.h"
+#define TILE_HD
+#include "tile_order.h"
 
 namespace tgp {
 
@@ -306,6 +308,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "gemm_role")) return &ctx->gemm_role;
   if (!strcmp(key, "host_join")) return &ctx->host_join;
   if (!strcmp(key, "asm_defer")) return &ctx->asm_defer;
+  if (!strcmp(key, "tile_band")) return &ctx->tile_band;
   if (!strcmp(key, "fault_inject")) return &ctx->fault_inject;
   if (!strcmp(key, "poll_timeout_ms")) return &ctx->poll_timeout_ms;
   if (!strcmp(key, "timeout_retries")) return &ctx->timeout_retries;  // (read: passes repeated after a device-side timeout)
@@ -1190,6 +1193,26 @@ int tgp_solver_timings(tgp_solver* s, double* ms, int n) {
 }
 
 // the chain kernel's ticket -> task map on the host (chain_tasks.h): ticket < 0 -> *n_tasks only
+int tgp_tile_order(int64_t tm, int64_t tn, int32_t lower, int32_t band, int64_t id, int32_t* ti, int32_t* tj, int64_t* n_tiles) {
+  if (!(tm >= 1 && tn >= 1 && tm <= 65535 && tn <= 65535 && band >= 0 && (!lower || tn <= tm))) {
+    tgp::set_error("tgp_tile_order: bad shape");
+    return TGP_E_ARG;
+  }
+  const int64_t n = tile_count((int)tm, (int)tn, lower);
+  if (n_tiles) *n_tiles = n;
+  if (id >= 0) {
+    if (id >= n || !ti || !tj) {
+      tgp::set_error("tgp_tile_order: id out of range");
+      return TGP_E_ARG;
+    }
+    int a = 0, b = 0;
+    tile_decode((int)id, (int)tm, (int)tn, lower, band, a, b);
+    *ti = a;
+    *tj = b;
+  }
+  return TGP_OK;
+}
+
 int tgp_chain_task(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t ticket, int32_t* out5, int64_t* n_tasks) {
   if (!(R >= 1 && cb >= 0 && cb < ce && ce <= nblk && nblk <= 64 && nblk <= R && R <= (1 << 20))) {
     tgp::set_error("tgp_chain_task: bad panel shape");

@@ -22,6 +22,9 @@
 
 #include "tgp_common.h"
 
+#define TILE_HD __host__ __device__
+#include "tile_order.h"
+
 namespace tgp {
 
 namespace {
@@ -82,26 +85,13 @@ struct GemmArgs {
   // time); workgroup ids enumerate 8 x 8 PATCHES of tiles, one patch per XCD at a time (see the kernel).
   int batch;
   int64_t sA, sB, sC;
+  int band;  // tile order: 0 column by column, > 0 bands of that many tile rows (tile_order.h; ctx option tile_band)
 };
 
-// Linear workgroup id -> (ti, tj).  Tiles are enumerated column by column (tj major) so
+// Linear workgroup id -> (ti, tj): tile_order.h (shared with the CPU test hook).  band == 0: column by column (tj major) so
 // that consecutive ids share the B tile; for `lower` column tj holds rows tj..tm-1.
-__device__ __forceinline__ void decode_tile(int b, int tm, int tn, int lower, int& ti, int& tj) {
-  if (!lower) {
-    tj = b / tm;
-    ti = b - tj * tm;
-    return;
-  }
-  // offset(tj) = tj*tm - tj*(tj-1)/2
-  const float fm = 2.0f * float(tm) + 1.0f;
-  int t = int((fm - sqrtf(fm * fm - 8.0f * float(b))) * 0.5f);
-  if (t < 0) t = 0;
-  if (t > tn - 1) t = tn - 1;
-  auto off = [tm](int q) { return q * tm - (q * (q - 1)) / 2; };
-  while (t > 0 && off(t) > b) --t;
-  while (t + 1 < tn && off(t + 1) <= b) ++t;
-  tj = t;
-  ti = tj + (b - off(t));
+__device__ __forceinline__ void decode_tile(int b, int tm, int tn, int lower, int& ti, int& tj, int band = 0) {
+  tile_decode(b, tm, tn, lower, band, ti, tj);
 }
 
 // Block-cyclic variant: local block column q (tiles [q*dnbt, (q+1)*dnbt)) starts at global tile
@@ -198,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
   if (g.dG > 0) {
     decode_tile_dist<T>(bid, g, ti, tj, gt);
   } else {
-    decode_tile(bid, g.tm, g.tn, g.lower, ti, tj);
+    decode_tile(bid, g.tm, g.tn, g.lower, ti, tj, g.band);
     gt = tj;
   }
 
@@ -583,7 +573,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
   T(*sB)[BK * S_LD] = reinterpret_cast<T(*)[BK * S_LD]>(sBm);
   __builtin_amdgcn_s_setprio(1);
   int ti, tj;
-  decode_tile(blockIdx.x, g.tm, g.tn, g.lower, ti, tj);
+  {
+    int bid = blockIdx.x;
+    if (g.band > 0) {  // (with bands: the XCD-aware bijective remap of gemm_nt_kernel -- a contiguous run of ids per XCD)
+      const int nx = 8, q = g.nblk / nx, r = g.nblk % nx;
+      const int xcd = bid % nx, idx = bid / nx;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    decode_tile(bid, g.tm, g.tn, g.lower, ti, tj, g.band);
+  }
   if (g.skip00 && ti < 2 && tj < 2) return;  // that tile is updated inside the next potf2
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1;
@@ -874,6 +872,7 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   g.dG = g.dr = g.dl0 = g.dnbt = 0;
   g.split_first = 0; g.split_s = 1; g.ngrid = 0; g.ws = nullptr; g.cnt = nullptr;
   g.batch = 1; g.sA = g.sB = g.sC = 0;
+  g.band = (int)ctx->tile_band;
   TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");
   // short-K updates, and (role 4) a latency-bound update with too few big tiles to fill the chip
   if ((((role == 1 || role == 3) && k <= 256) || role == 4) && (mode == 0 || mode == 1)) {
@@ -971,6 +970,7 @@ int launch_gemm_tri(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t 
   g.tm = int(m / BM); g.tn = int(n / BN);
   g.k = int(k); g.lower = lower; g.mode = mode;
   g.batch = batch; g.sA = sA; g.sB = sB; g.sC = sC;
+  g.band = 0;
   const int64_t ptm = (g.tm + 7) / 8, ptn = (g.tn + 7) / 8;
   const int64_t patches = int64_t(batch) * (lower ? ptm * (ptm + 1) / 2 : ptm * ptn);
   const int64_t grid = (patches + 7) / 8 * 8 * 64;
@@ -1002,6 +1002,7 @@ int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb
   g.dG = G; g.dr = rank; g.dl0 = int(l0); g.dnbt = int(nb / BN);
   g.split_first = 0; g.split_s = 1; g.ngrid = 0; g.ws = nullptr; g.cnt = nullptr;
   g.batch = 1; g.sA = g.sB = g.sC = 0;
+  g.band = 0;
   int64_t total = 0;
   for (int64_t q = 0; q < nloc; ++q) {
     const int64_t g0 = ((l0 + q) * G + rank) * g.dnbt;

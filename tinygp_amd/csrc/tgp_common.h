@@ -149,6 +149,7 @@ struct tgp_ctx {
   // whole launch (the default under a counter-collecting profiler, which runs kernels one at a time in its own order)
   int64_t chain_polls = 1;
   bool wait_values_inflight = false;  // this factorisation enqueued stream wait-values: join with a deadline (join_bounded)
+  int64_t tile_band = 0;         // tile order of the MFMA products: 0 column by column, > 0 bands of that many tile rows (tile_order.h)
   int64_t asm_defer = 0;         // 1: the side-stream assembly of the columns right of the first panel starts behind the first potf2
   std::function<int()> deferred_asm;  // ... the launch that was held back (cleared when run)
   hipEvent_t ev_asm_gate = nullptr;
