@@ -133,6 +133,10 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       rocprofv3 --pmc, or TGP_SERIALIZED_KERNELS=1), which runs kernels one at a time in its own order;
  *                       "chain_fast_update" (0): fp64 update tasks on the 4x4x4 MFMA form with LDS-direct operands
  *                       (measured slower: DESIGN 4.2);  "chain_stamps" (0): tgp_chain_stamps below
+ *   "tile_band"         order of the MFMA products' output tiles over the workgroup ids: bands of this many tile rows, column
+ *                       by column inside a band (default 8: the 64 tiles an XCD has resident share 8 + 8 operand panels
+ *                       instead of 64 + 1 -- fabric traffic of a trailing-update launch 3.28 -> 1.78 GB at N = 16 384, same
+ *                       time); 0: column by column over all rows (rounds 1-4).  csrc/tile_order.h, tgp_tile_order
  *   "poll_timeout_ms"   wall-clock bound of every device-side wait (default 4000; one value per process and device).  A
  *                       wait that expires makes the call return TGP_E_TIMEOUT; tgp_solver_factor* has then already
  *                       repeated the pass ONCE on the launch-per-block path ("timeout_retries" counts them; read-only).

@@ -149,7 +149,12 @@ struct tgp_ctx {
   // whole launch (the default under a counter-collecting profiler, which runs kernels one at a time in its own order)
   int64_t chain_polls = 1;
   bool wait_values_inflight = false;  // this factorisation enqueued stream wait-values: join with a deadline (join_bounded)
-  int64_t tile_band = 0;         // tile order of the MFMA products: 0 column by column, > 0 bands of that many tile rows (tile_order.h)
+  // tile order of the MFMA products (tile_order.h): bands of this many tile rows, column by column inside a band; 0 = column
+  // by column over all rows (rounds 1-4).  Round 5, measured at c2 (profiles/r05_j, r05_k): fabric traffic of a
+  // trailing-update launch 2 x 1 471 + 334 MB = 3.28 GB at 0 -> 2 x 725 + 334 = 1.78 GB at 8 (714 at 4, 932 at 16, 1 296 at 32);
+  // 64 x 64-tile kernel 663 -> 284 MB; the evaluation's time does not move (25.41 / 25.48 vs 25.45 / 25.58 ms; N = 65 536
+  // 1 381.7 vs 1 379.6): the fabric was never the bound -- a third of its traffic is simply not needed
+  int64_t tile_band = 8;
   int64_t asm_defer = 0;         // 1: the side-stream assembly of the columns right of the first panel starts behind the first potf2
   std::function<int()> deferred_asm;  // ... the launch that was held back (cleared when run)
   hipEvent_t ev_asm_gate = nullptr;

@@ -3,7 +3,7 @@
 // TILE_HD is defined by the includer (__host__ __device__ in HIP code, empty in a host-only translation unit).
 //
 // band == 0: column by column (tj major; consecutive ids share the B operand's tile; `lower`: column tj holds rows tj .. tm-1).
-// band  > 0 (round 5 experiment, ctx option "tile_band"): BANDS of `band` tile rows, top down; inside a band column by column.
+// band  > 0 (round 5, ctx option "tile_band", default 8): BANDS of `band` tile rows, top down; inside a band column by column.
 //   The 64 workgroups an XCD has resident then cover a patch of ~band rows x 64/band columns -- band + 64/band operand panels
 //   instead of 64 + 1 -- with the same contiguous, equal-length run of ids per XCD as before (no half-empty diagonal
 //   patches: the 8 x 8 patch order of profiles/r03_j cut the fabric traffic by a third and lost 4 % to that imbalance).
