@@ -109,7 +109,7 @@ __device__ __forceinline__ void decode_tile_dist(int b, const GemmArgs<T>& g, in
     ++q;
   }
   int tir, s;
-  decode_tile(b, g.tm - g0, g.dnbt, 1, tir, s);
+  decode_tile(b, g.tm - g0, g.dnbt, 1, tir, s, g.band);  // (band order inside the block column: 8 x 8 patches per XCD)
   ti = g0 + tir;
   tj = q * g.dnbt + s;
   gt = g0 + s;
@@ -1002,7 +1002,7 @@ int launch_gemm_nt_dist(tgp_ctx* ctx, hipStream_t st, int64_t n_rows, int64_t nb
   g.dG = G; g.dr = rank; g.dl0 = int(l0); g.dnbt = int(nb / BN);
   g.split_first = 0; g.split_s = 1; g.ngrid = 0; g.ws = nullptr; g.cnt = nullptr;
   g.batch = 1; g.sA = g.sB = g.sC = 0;
-  g.band = 0;
+  g.band = (int)ctx->tile_band;
   int64_t total = 0;
   for (int64_t q = 0; q < nloc; ++q) {
     const int64_t g0 = ((l0 + q) * G + rank) * g.dnbt;
