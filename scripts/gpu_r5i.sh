@@ -23,7 +23,7 @@ for cn in FETCH_SIZE WRITE_SIZE; do
 timeout 150 rocprofv3 --pmc $cn --kernel-trace -d $O/pmc_$cn -o bench -- python bench.py --steps 2 --warmup 1 $B --no-profile > $O/pmc_$cn.log 2>&1
 echo "-- c2 $cn rc=$?"; python scripts/pmc_summary.py $(ls $O/pmc_$cn/*.db | head -1) $cn | head -4
 done
-python scripts/pmc_to_bench.py $(ls $O/pmc_FETCH_SIZE/*.db | head -1) $(ls $O/pmc_WRITE_SIZE/*.db | head -1) profiles/r05_l_final_evidence.md | cut -c1-300
+python scripts/pmc_to_bench.py $(ls $O/pmc_FETCH_SIZE/*.db | head -1) $(ls $O/pmc_WRITE_SIZE/*.db | head -1) profiles/r05_o_final_evidence.md | cut -c1-300
 cp gpurun_out/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 echo "== bench default (the driver's line)"; date
