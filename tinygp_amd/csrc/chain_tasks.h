@@ -13,134 +13,129 @@ struct ChainTask {
 };
 constexpr int CHAIN_CRIT_PARTS = 8;  // workgroups that share the update of tile (k+2, k+1) from column k
 
-// Tasks of step k (column k is made final, everything right of it receives its update) and their TICKET ORDER.
-//   solve(i, k), i = r0 .. R-1            r0 = k + 2 while xsolve(k+1) owns tile (k+1, k)
-//   U1: update(i, k+1, k), i = k+2 ..     the column the NEXT step solves; its first tile, (k+2, k+1), as CHAIN_CRIT_PARTS tasks
-//   D:  update(k+2, k+2, k)               the diagonal tile the step after next factors
-//   A:  xsolve(k+2), diag(k+2)            if block k+2 is factored by this launch (k + 2 < ce) -- THE NEXT STEP'S diagonal tasks
-//   U2: update(i, c, k), c = k+2 .. nblk-1, i = c .., without D        the bulk
-// (the launch opens with diag(cb) if cb > 0, then xsolve(cb+1), diag(cb+1) if cb + 1 < ce.)
-// Round 5: A sits IN FRONT of the bulk of its predecessor step.  Until round 4 a step was [A | solves | all updates], so the
-// diagonal tasks of step k+1 drew their tickets behind the (R-k)^2/2 bulk updates of step k -- ~460 tasks of 22 us on 256
-// compute units at N = 4 096 -- although they need none of them: the stamped timeline showed xsolve / diag STARTING 15-37 us
-// late and the first ~11 blocks of a 32-block launch at 45-65 us per block instead of 36 (profiles/r05_p).  Everything A
-// waits for -- the updates of tiles (k+2, k+1) and (k+2, k+2) through column k, the progress of diag(k+1) -- has an earlier
-// ticket in this order too (tests/test_chain_tasks.py checks every wait of every task of a launch).
-struct ChainStep {
-  int nd0;   // the launch's FIRST step only: xsolve(k+1), diag(k+1) in front (0 / 1)
-  int r0, ns;
-  int a, b;  // updated columns a = k+1 .. b = nblk-1 (a > b: none)
-  int crit;  // extra tickets of the split update of tile (k+2, k+1) (CHAIN_CRIT_PARTS - 1, or 0)
-  int nu1;   // U1 tickets (crit included)
-  int nD;    // D (0 / 1)
-  int nA;    // A: 2 or 0
-  int nu2;   // U2 tickets
+// TICKET ORDER (round 5).  With DG(j) = [xsolve(j), diag(j)] (block j is factored by this launch: cb < j < ce),
+// Solves(k) = solve(i, k) for the rows below (i from k+2 while xsolve(k+1) owns tile (k+1, k)), and the updates FROM column k
+//   Crit(k)   update(k+2, k+1, k)   in CHAIN_CRIT_PARTS parts -- the tile xsolve(k+2) waits for
+//   D(k)      update(k+2, k+2, k)   the diagonal tile diag(k+2) factors
+//   U1r(k)    update(i,   k+1, k), i >= k+3    the rest of the column the next step solves
+//   E(k)      update(k+3, k+2, k), update(k+3, k+3, k)    what Crit(k+1) and D(k+1) build on
+//   Bulk(k)   every other update(i, c, k), c >= k+2
+// a launch hands out
+//   [diag(cb) if cb > 0]  DG(cb+1)  Solves(cb) Crit(cb) D(cb)
+//   then for k = cb, cb+1, ...:   U1r(k) E(k) | DG(cb+2) if k == cb | Solves(k+1) Crit(k+1) D(k+1) | DG(k+3) | Bulk(k)
+// -- the DIAGONAL LANE of the next step (its solves, the two tiles the block after next needs, that block's xsolve and
+// potf2) sits IN FRONT of the bulk of this step.  Until round 4 a step was [DG | Solves | all updates]: the diagonal tasks of
+// step k+1 drew their tickets behind the (R-k)^2 / 2 bulk updates of step k -- ~460 tasks of 22 us on 256 compute units at
+// N = 4 096 -- although they need none of them; the stamped timeline showed xsolve / diag starting 15-37 us late and the
+// first ~11 blocks of a 32-block launch at 45-65 us per block instead of 36.  Everything a task of the lane waits for has
+// an earlier ticket in this order too (tests/test_chain_tasks.py checks every wait of every task of a launch).
+struct ChainLaunch {
+  int R, nblk, cb, ce;
 };
-CHAIN_HD inline ChainStep chain_step(int k, int R, int nblk, int cb, int ce) {
-  ChainStep s;
-  const int nd = k + 1 < ce ? 1 : 0;  // block k+1 is factored by this launch (its diagonal tasks precede this step's solves)
-  s.nd0 = (k == cb) ? nd : 0;
-  s.r0 = nd ? k + 2 : k + 1;
-  s.ns = R - s.r0 > 0 ? R - s.r0 : 0;
-  s.a = k + 1;
-  s.b = nblk - 1;
-  const bool upd = s.a <= s.b;
-  s.crit = (upd && R - (s.a + 1) >= 1) ? CHAIN_CRIT_PARTS - 1 : 0;
-  s.nu1 = upd ? (R - (s.a + 1) > 0 ? R - (s.a + 1) : 0) + s.crit : 0;
-  s.nD = (s.a + 1 <= s.b) ? 1 : 0;  // (nblk <= R: row k+2 exists whenever column k+2 does)
-  s.nA = (k + 2 < ce) ? 2 : 0;
-  int u2 = 0;
-  for (int c = s.a + 1; c <= s.b; ++c) u2 += R - c;
-  s.nu2 = u2 - s.nD;
-  return s;
+CHAIN_HD inline bool chain_factored(const ChainLaunch& q, int j) { return j > q.cb && j < q.ce; }  // DG(j) exists
+CHAIN_HD inline int chain_solve_r0(const ChainLaunch& q, int k) { return chain_factored(q, k + 1) ? k + 2 : k + 1; }
+CHAIN_HD inline int chain_n_solves(const ChainLaunch& q, int k) {
+  const int n = q.R - chain_solve_r0(q, k);
+  return n > 0 ? n : 0;
 }
-CHAIN_HD inline int chain_step_tickets(const ChainStep& s) { return 2 * s.nd0 + s.ns + s.nu1 + s.nD + s.nA + s.nu2; }
+// update(i, c, k) exists for k+1 <= c <= nblk-1, c <= i <= R-1, except tile (k+1, k+1) (diag(k+1)'s own fold)
+CHAIN_HD inline bool chain_has_update(const ChainLaunch& q, int i, int c, int k) {
+  return c >= k + 1 && c <= q.nblk - 1 && i >= c && i <= q.R - 1 && !(i == k + 1 && c == k + 1);
+}
+CHAIN_HD inline int chain_n_crit(const ChainLaunch& q, int k) { return chain_has_update(q, k + 2, k + 1, k) ? CHAIN_CRIT_PARTS : 0; }
+CHAIN_HD inline int chain_n_D(const ChainLaunch& q, int k) { return chain_has_update(q, k + 2, k + 2, k) ? 1 : 0; }
+CHAIN_HD inline int chain_n_U1r(const ChainLaunch& q, int k) {
+  if (k + 1 > q.nblk - 1) return 0;
+  const int n = q.R - (k + 3);
+  return n > 0 ? n : 0;
+}
+CHAIN_HD inline int chain_n_E(const ChainLaunch& q, int k) {
+  return (chain_has_update(q, k + 3, k + 2, k) ? 1 : 0) + (chain_has_update(q, k + 3, k + 3, k) ? 1 : 0);
+}
+CHAIN_HD inline int chain_n_bulk(const ChainLaunch& q, int k) {
+  const int m = q.nblk - 1 - (k + 2) + 1;  // columns k+2 .. nblk-1
+  if (m <= 0) return 0;
+  const int n = m * q.R - ((k + 2 + q.nblk - 1) * m) / 2;  // sum of (R - c): (first + last) * m is even or m is
+  return n - chain_n_D(q, k) - chain_n_E(q, k);
+}
+
+// one walk over the order above: `t` < 0 counts the tickets (returned), `t` >= 0 decodes that ticket into *out
+CHAIN_HD inline int64_t chain_walk(const ChainLaunch& q, int64_t t, ChainTask* out) {
+  int64_t seen = 0;
+  ChainTask task = {-1, 0, 0, 0, 0};
+#define CHAIN_GROUP(count, body)                          \
+  do {                                                    \
+    const int64_t cnt_ = (count);                         \
+    if (t >= 0 && t < seen + cnt_) {                      \
+      const int u = int(t - seen);                        \
+      (void)u;                                            \
+      body;                                               \
+      *out = task;                                        \
+      return seen + cnt_;                                 \
+    }                                                     \
+    seen += cnt_;                                         \
+  } while (0)
+  auto dg = [&](int j, int u) { task.kind = u == 0 ? 5 : 1; task.c = j; };
+  auto solve = [&](int k, int u) { task.kind = 0; task.i = chain_solve_r0(q, k) + u; task.c = k; };
+  auto crit = [&](int k, int u) { task.kind = 4; task.i = k + 2; task.c = k + 1; task.k = k; task.part = u; };
+  auto dtile = [&](int k) { task.kind = 3; task.i = task.c = k + 2; task.k = k; };
+  auto u1r = [&](int k, int u) { task.kind = 2; task.i = k + 3 + u; task.c = k + 1; task.k = k; };
+  auto etile = [&](int k, int u) {
+    const bool first = chain_has_update(q, k + 3, k + 2, k);
+    task.k = k;
+    task.i = k + 3;
+    if (first && u == 0) { task.kind = 2; task.c = k + 2; }
+    else { task.kind = 3; task.c = k + 3; }
+  };
+  auto bulk = [&](int k, int u) {  // column by column; D(k) and E(k) are the FIRST rows of columns k+2 and k+3: skipped
+    for (int c = k + 2; c <= q.nblk - 1; ++c) {
+      int skip = 0;
+      if (c == k + 2) skip = (chain_has_update(q, k + 2, k + 2, k) ? 1 : 0) + (chain_has_update(q, k + 3, k + 2, k) ? 1 : 0);
+      else if (c == k + 3) skip = chain_has_update(q, k + 3, k + 3, k) ? 1 : 0;
+      const int cnt = q.R - c - skip;
+      if (u < cnt) {
+        task.i = c + skip + u;
+        task.c = c;
+        task.k = k;
+        task.kind = task.i == c ? 3 : 2;
+        return;
+      }
+      u -= cnt;
+    }
+  };
+  if (q.cb > 0) CHAIN_GROUP(1, { task.kind = 1; task.c = q.cb; });
+  const int k0 = q.cb;
+  if (chain_factored(q, k0 + 1)) CHAIN_GROUP(2, dg(k0 + 1, u));
+  CHAIN_GROUP(chain_n_solves(q, k0), solve(k0, u));
+  CHAIN_GROUP(chain_n_crit(q, k0), crit(k0, u));
+  CHAIN_GROUP(chain_n_D(q, k0), dtile(k0));
+  for (int k = k0; k < q.ce; ++k) {
+    CHAIN_GROUP(chain_n_U1r(q, k), u1r(k, u));
+    CHAIN_GROUP(chain_n_E(q, k), etile(k, u));
+    if (k == k0 && chain_factored(q, k + 2)) CHAIN_GROUP(2, dg(k + 2, u));
+    if (k + 1 < q.ce) {  // column k+1 is solved by this launch: its diagonal lane
+      CHAIN_GROUP(chain_n_solves(q, k + 1), solve(k + 1, u));
+      CHAIN_GROUP(chain_n_crit(q, k + 1), crit(k + 1, u));
+      CHAIN_GROUP(chain_n_D(q, k + 1), dtile(k + 1));
+    }
+    if (chain_factored(q, k + 3)) CHAIN_GROUP(2, dg(k + 3, u));
+    CHAIN_GROUP(chain_n_bulk(q, k), bulk(k, u));
+  }
+#undef CHAIN_GROUP
+  return seen;
+}
 
 // tickets of a launch over block columns [cb, ce) of a panel with R row tiles and nblk block columns.  A continuation
 // launch (cb > 0) starts with diag(cb): tile (cb, cb-1) is final since the launch before; a panel's very first block
 // (cb == 0) is factored in front of the launch.
 CHAIN_HD inline int64_t chain_task_count(int R, int nblk, int cb, int ce) {
-  int64_t tasks = cb > 0 ? 1 : 0;
-  for (int k = cb; k < ce; ++k) tasks += chain_step_tickets(chain_step(k, R, nblk, cb, ce));
-  return tasks;
+  const ChainLaunch q = {R, nblk, cb, ce};
+  return chain_walk(q, -1, nullptr);
 }
 
 CHAIN_HD inline ChainTask chain_decode_ticket(int t, int R, int nblk, int cb, int ce) {
+  const ChainLaunch q = {R, nblk, cb, ce};
   ChainTask task = {-1, 0, 0, 0, 0};
-  if (cb > 0) {
-    if (t == 0) {
-      task.kind = 1;
-      task.c = cb;
-      return task;
-    }
-    --t;
-  }
-  for (int k = cb; k < ce; ++k) {
-    const ChainStep s = chain_step(k, R, nblk, cb, ce);
-    const int all = chain_step_tickets(s);
-    if (t >= all) {
-      t -= all;
-      continue;
-    }
-    if (s.nd0) {  // the launch's first step: xsolve(k+1) in front of diag(k+1)
-      if (t < 2) {
-        task.kind = t == 0 ? 5 : 1;
-        task.c = k + 1;
-        return task;
-      }
-      t -= 2;
-    }
-    if (t < s.ns) {
-      task.kind = 0;
-      task.i = s.r0 + t;
-      task.c = k;
-      return task;
-    }
-    t -= s.ns;
-    if (t < s.nu1) {  // U1: column a from column k; its first tile (a+1, a) in CHAIN_CRIT_PARTS parts
-      const int i0 = s.a + 1;
-      task.c = s.a;
-      task.k = k;
-      if (s.crit) {
-        if (t < CHAIN_CRIT_PARTS) {
-          task.kind = 4;
-          task.i = i0;
-          task.part = t;
-          return task;
-        }
-        t -= CHAIN_CRIT_PARTS - 1;
-      }
-      task.kind = 2;
-      task.i = i0 + t;
-      return task;
-    }
-    t -= s.nu1;
-    if (t < s.nD) {  // D: the diagonal tile (k+2, k+2) from column k
-      task.kind = 3;
-      task.i = task.c = s.a + 1;
-      task.k = k;
-      return task;
-    }
-    t -= s.nD;
-    if (t < s.nA) {  // A: the NEXT step's diagonal tasks
-      task.kind = t == 0 ? 5 : 1;
-      task.c = k + 2;
-      return task;
-    }
-    t -= s.nA;
-    for (int c = s.a + 1; c <= s.b; ++c) {  // U2: the bulk
-      const int i0 = (c == s.a + 1) ? c + 1 : c;  // (tile (a+1, a+1) was D)
-      const int cnt = R - i0;
-      if (t < cnt) {
-        task.i = i0 + t;
-        task.c = c;
-        task.k = k;
-        task.kind = task.i == c ? 3 : 2;
-        return task;
-      }
-      t -= cnt;
-    }
-    return task;  // (unreachable for t < chain_task_count)
-  }
+  chain_walk(q, t, &task);
   return task;
 }
