@@ -23,9 +23,16 @@ for cn in FETCH_SIZE WRITE_SIZE; do
 timeout 150 rocprofv3 --pmc $cn --kernel-trace -d $O/pmc_$cn -o bench -- python bench.py --steps 2 --warmup 1 $B --no-profile > $O/pmc_$cn.log 2>&1
 echo "-- c2 $cn rc=$?"; python scripts/pmc_summary.py $(ls $O/pmc_$cn/*.db | head -1) $cn | head -4
 done
-python scripts/pmc_to_bench.py $(ls $O/pmc_FETCH_SIZE/*.db | head -1) $(ls $O/pmc_WRITE_SIZE/*.db | head -1) profiles/r05_o_final_evidence.md | cut -c1-300
+python scripts/pmc_to_bench.py $(ls $O/pmc_FETCH_SIZE/*.db | head -1) $(ls $O/pmc_WRITE_SIZE/*.db | head -1) profiles/r05_s_final_evidence.md | cut -c1-300
 cp gpurun_out/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+echo "== ticket orders on this box: hybrid (tree) | lane everywhere (batch r's library is gone: skipped) | DG-only | round 4"; date
+one() { timeout 300 python bench.py $B --no-profile --workload $1 --steps $2 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.3f ms' % d['ms_per_step'])"; }
+for n in n4096 c2; do s=20; [ $n = c2 ] && s=12; for rep in 1 2; do
+echo "-- $n hybrid"; one $n $s
+[ -f tinygp_amd/lib/libtgp_hip_v2order.so ] && { echo "-- $n dg-only"; TGP_HIP_LIBRARY=$R/tinygp_amd/lib/libtgp_hip_v2order.so one $n $s; }
+[ -f tinygp_amd/lib/libtgp_hip_oldorder.so ] && { echo "-- $n round4"; TGP_HIP_LIBRARY=$R/tinygp_amd/lib/libtgp_hip_oldorder.so one $n $s; }
+done; done
 echo "== bench default (the driver's line)"; date
 timeout 900 python bench.py 2>/dev/null | tail -1 | tee $O/bench_default.json | cut -c1-1500
 date

@@ -63,8 +63,11 @@ def expected(R, nblk, cb, ce):
     return want
 
 
+# (nblk == R: the launch covers the whole rest of the matrix -- the order with the next step's diagonal lane in front of the bulk;
+# otherwise a panel's launch -- only its two diagonal tasks move: csrc/chain_tasks.h)
 SHAPES = [(1, 1, 0, 1), (2, 1, 0, 1), (2, 2, 0, 2), (3, 2, 0, 2), (8, 8, 0, 8), (12, 8, 0, 8), (32, 32, 0, 32), (40, 8, 0, 5),
-          (40, 8, 5, 8), (9, 8, 3, 4), (64, 64, 0, 64), (70, 64, 60, 64), (128, 8, 0, 8), (16, 8, 7, 8)]
+          (40, 8, 5, 8), (9, 8, 3, 4), (64, 64, 0, 64), (70, 64, 60, 64), (128, 8, 0, 8), (16, 8, 7, 8), (3, 3, 0, 3), (4, 4, 0, 4),
+          (5, 5, 0, 5), (16, 16, 0, 16), (16, 16, 4, 16), (32, 32, 8, 20), (48, 8, 0, 8), (64, 64, 30, 64)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"R{r}-nblk{n}-cols{a}to{b}" for r, n, a, b in SHAPES])

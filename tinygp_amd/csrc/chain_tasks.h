@@ -23,6 +23,12 @@ constexpr int CHAIN_CRIT_PARTS = 8;  // workgroups that share the update of tile
 // a launch hands out
 //   [diag(cb) if cb > 0]  DG(cb+1)  Solves(cb) Crit(cb) D(cb)
 //   then for k = cb, cb+1, ...:   U1r(k) E(k) | DG(cb+2) if k == cb | Solves(k+1) Crit(k+1) D(k+1) | DG(k+3) | Bulk(k)
+// when the launch covers the WHOLE REST of the matrix (nblk == R: the one-launch tail, N <= 4 096) -- chain-bound by design.
+// A panel's launch (8 block columns, up to 128 row tiles) keeps the solves in their own step:
+//   ... for k = cb, cb+1, ...:   Solves(k) Crit(k) U1r(k) D(k) | DG(k+2) | Bulk(k) with E(k)
+// -- there only the two diagonal tasks move in front of the bulk: a hundred solves spinning for L_{k+1,k+1} beside a big
+// trailing update cost more than the lane gains (one box, profiles/r05_r: N = 4 096 1.378 lane / 1.393 DG-only / 1.422 round 4;
+// c2 25.66 / 25.40 / 25.63).
 // -- the DIAGONAL LANE of the next step (its solves, the two tiles the block after next needs, that block's xsolve and
 // potf2) sits IN FRONT of the bulk of this step.  Until round 4 a step was [DG | Solves | all updates]: the diagonal tasks of
 // step k+1 drew their tickets behind the (R-k)^2 / 2 bulk updates of step k -- ~460 tasks of 22 us on 256 compute units at
@@ -31,7 +37,12 @@ constexpr int CHAIN_CRIT_PARTS = 8;  // workgroups that share the update of tile
 // an earlier ticket in this order too (tests/test_chain_tasks.py checks every wait of every task of a launch).
 struct ChainLaunch {
   int R, nblk, cb, ce;
+  int lane;  // 1: the next step's whole diagonal lane in front of the bulk; 0: its two diagonal tasks only
 };
+CHAIN_HD inline ChainLaunch chain_launch(int R, int nblk, int cb, int ce) {
+  ChainLaunch q = {R, nblk, cb, ce, nblk == R ? 1 : 0};
+  return q;
+}
 CHAIN_HD inline bool chain_factored(const ChainLaunch& q, int j) { return j > q.cb && j < q.ce; }  // DG(j) exists
 CHAIN_HD inline int chain_solve_r0(const ChainLaunch& q, int k) { return chain_factored(q, k + 1) ? k + 2 : k + 1; }
 CHAIN_HD inline int chain_n_solves(const ChainLaunch& q, int k) {
@@ -56,7 +67,7 @@ CHAIN_HD inline int chain_n_bulk(const ChainLaunch& q, int k) {
   const int m = q.nblk - 1 - (k + 2) + 1;  // columns k+2 .. nblk-1
   if (m <= 0) return 0;
   const int n = m * q.R - ((k + 2 + q.nblk - 1) * m) / 2;  // sum of (R - c): (first + last) * m is even or m is
-  return n - chain_n_D(q, k) - chain_n_E(q, k);
+  return n - chain_n_D(q, k) - (q.lane ? chain_n_E(q, k) : 0);
 }
 
 // one walk over the order above: `t` < 0 counts the tickets (returned), `t` >= 0 decodes that ticket into *out
@@ -90,8 +101,8 @@ CHAIN_HD inline int64_t chain_walk(const ChainLaunch& q, int64_t t, ChainTask* o
   auto bulk = [&](int k, int u) {  // column by column; D(k) and E(k) are the FIRST rows of columns k+2 and k+3: skipped
     for (int c = k + 2; c <= q.nblk - 1; ++c) {
       int skip = 0;
-      if (c == k + 2) skip = (chain_has_update(q, k + 2, k + 2, k) ? 1 : 0) + (chain_has_update(q, k + 3, k + 2, k) ? 1 : 0);
-      else if (c == k + 3) skip = chain_has_update(q, k + 3, k + 3, k) ? 1 : 0;
+      if (c == k + 2) skip = (chain_has_update(q, k + 2, k + 2, k) ? 1 : 0) + ((q.lane && chain_has_update(q, k + 3, k + 2, k)) ? 1 : 0);
+      else if (c == k + 3) skip = (q.lane && chain_has_update(q, k + 3, k + 3, k)) ? 1 : 0;
       const int cnt = q.R - c - skip;
       if (u < cnt) {
         task.i = c + skip + u;
@@ -106,6 +117,17 @@ CHAIN_HD inline int64_t chain_walk(const ChainLaunch& q, int64_t t, ChainTask* o
   if (q.cb > 0) CHAIN_GROUP(1, { task.kind = 1; task.c = q.cb; });
   const int k0 = q.cb;
   if (chain_factored(q, k0 + 1)) CHAIN_GROUP(2, dg(k0 + 1, u));
+  if (!q.lane) {
+    for (int k = k0; k < q.ce; ++k) {
+      CHAIN_GROUP(chain_n_solves(q, k), solve(k, u));
+      CHAIN_GROUP(chain_n_crit(q, k), crit(k, u));
+      CHAIN_GROUP(chain_n_U1r(q, k), u1r(k, u));
+      CHAIN_GROUP(chain_n_D(q, k), dtile(k));
+      if (chain_factored(q, k + 2)) CHAIN_GROUP(2, dg(k + 2, u));
+      CHAIN_GROUP(chain_n_bulk(q, k), bulk(k, u));
+    }
+    return seen;
+  }
   CHAIN_GROUP(chain_n_solves(q, k0), solve(k0, u));
   CHAIN_GROUP(chain_n_crit(q, k0), crit(k0, u));
   CHAIN_GROUP(chain_n_D(q, k0), dtile(k0));
@@ -129,12 +151,12 @@ CHAIN_HD inline int64_t chain_walk(const ChainLaunch& q, int64_t t, ChainTask* o
 // launch (cb > 0) starts with diag(cb): tile (cb, cb-1) is final since the launch before; a panel's very first block
 // (cb == 0) is factored in front of the launch.
 CHAIN_HD inline int64_t chain_task_count(int R, int nblk, int cb, int ce) {
-  const ChainLaunch q = {R, nblk, cb, ce};
+  const ChainLaunch q = chain_launch(R, nblk, cb, ce);
   return chain_walk(q, -1, nullptr);
 }
 
 CHAIN_HD inline ChainTask chain_decode_ticket(int t, int R, int nblk, int cb, int ce) {
-  const ChainLaunch q = {R, nblk, cb, ce};
+  const ChainLaunch q = chain_launch(R, nblk, cb, ce);
   ChainTask task = {-1, 0, 0, 0, 0};
   chain_walk(q, t, &task);
   return task;
