@@ -39,8 +39,10 @@ extern "C" {
  *  round 4 -> 5: tgp_comm_* (RCCL from the C ABI), tgp_stream_* transfers, TGP_E_TIMEOUT, options poll_timeout_ms /
  *  chain_fast_update / host_join, chain_polls = 3 (stream wait-value); tgp_dist_fwd_partial / _fwd_solve_left,
  *  tgp_dist_bwd_*_multi, tgp_dist_gather_owned, tgp_dist_identity_cols,
- *  tgp_dist_grad_* -- multi-RHS backward solve and gradient on the block-column path) */
-#define TGP_ABI_VERSION 5
+ *  tgp_dist_grad_* -- multi-RHS backward solve and gradient on the block-column path;
+ *  round 5 -> 6: tgp_chain_tasks (the chain launch's task TABLE with its K-batched updates), options chain_batch /
+ *  chain_batch_lag / chain_batch_rowlag) */
+#define TGP_ABI_VERSION 6
 
 /* element types: follows the dtype of the caller's arrays (gp.py:89) */
 #define TGP_F32 0
@@ -132,7 +134,12 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       context created under a counter-collecting profiler (ROCPROF_COUNTER_COLLECTION, i.e.
  *                       rocprofv3 --pmc, or TGP_SERIALIZED_KERNELS=1), which runs kernels one at a time in its own order;
  *                       "chain_fast_update" (0): fp64 update tasks on the 4x4x4 MFMA form with LDS-direct operands
- *                       (measured slower: DESIGN 4.2);  "chain_stamps" (0): tgp_chain_stamps below
+ *                       (measured slower: DESIGN 4.2);  "chain_stamps" (0): tgp_chain_stamps below;
+ *                       "chain_batch" (1 = off; measured slower, csrc/tgp_common.h), "chain_batch_lag" (1), "chain_batch_rowlag" (4), "chain_batch_minrows" (32): K-BATCHED updates
+ *                       (round 6, fp64): tile (i, c) with i >= c + rowlag takes the updates from `batch` consecutive block
+ *                       columns as ONE task (K = 128 batch, the tile read and written once) as long as the batch ends at
+ *                       least lag + 1 columns in front of c and at least minrows row tiles are left behind it (the launch is
+ *                       still throughput-bound); csrc/chain_tasks.h, tgp_chain_tasks
  *   "tile_band"         order of the MFMA products' output tiles over the workgroup ids: bands of this many tile rows, column
  *                       by column inside a band (default 8: the 64 tiles an XCD has resident share 8 + 8 operand panels
  *                       instead of 64 + 1 -- fabric traffic of a trailing-update launch 3.28 -> 1.78 GB at N = 16 384, same
@@ -492,6 +499,13 @@ int tgp_chain_stamps(tgp_ctx* ctx, int64_t* out, int64_t cap_tasks, int64_t* n_t
  * 4 a part (an eighth) of an update | 5 xsolve.  tests/test_chain_tasks.py checks on the CPU that every task of a launch
  * exists exactly once and waits for EARLIER tickets only. */
 int tgp_chain_task(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t ticket, int32_t* out5, int64_t* n_tasks);
+/* The same for the TABLE a launch is really given (round 6): ticket order of tgp_chain_task with the K-batched updates of the
+ * policy (batch, lag, rowlag, minrows: options chain_batch*) folded in -- the list launch_chain uploads, word for word.  out6 (or
+ * NULL) takes {kind, row tile, block column, LAST source column, part, FIRST source column} per task for at most
+ * cap_tasks tasks, *n_tasks the length of the list; kind 6 = update of the tile from block columns first .. last in one
+ * product. */
+int tgp_chain_tasks(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t batch, int64_t lag, int64_t rowlag, int64_t minrows,
+                    int32_t* out6, int64_t cap_tasks, int64_t* n_tasks);
 
 /* ---- RCCL from the C ABI (round 5) -------------------------------------------------------------------------------
  * The block-column driver's collectives -- north_star's "RCCL broadcast of the current panel and reduce of the solve

@@ -23,7 +23,7 @@ def test_library_exports_every_symbol():
     lib = _ffi.load_library()  # raises if the .so is missing or a symbol is absent
     for name in header_symbols():
         assert hasattr(lib, name), name
-    assert lib.tgp_abi_version() == _ffi.ABI_VERSION == 5
+    assert lib.tgp_abi_version() == _ffi.ABI_VERSION == 6
 
 
 def test_missing_library_is_loud(tmp_path):

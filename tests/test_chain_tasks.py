@@ -4,8 +4,12 @@ tickets (a workgroup that holds ticket t is running or done once ticket t + 1 is
 ticket of a launch through the library's own map (csrc/chain_tasks.h via tgp_chain_task: the text the kernel decodes
 its ticket with and launch_chain sizes the grid by) and checks, on the CPU,
   * that the tasks of the launch are exactly the ones the factorisation needs, each once;
-  * that every wait of chain_kernel (csrc/chol.hip) is for an earlier ticket."""
+  * that every wait of chain_kernel (csrc/chol.hip) is for an earlier ticket.
+Round 6: the kernel reads its task from a TABLE the host builds from the same header (chain_build: the ticket order with
+the K-batched updates of a policy folded in, tgp_chain_tasks); the same two checks run on that list for several policies --
+an update (i, c, k) is covered exactly once, by its own task or inside ONE batch, and a batch waits for earlier tickets only."""
 import ctypes as C
+import functools
 
 import pytest
 
@@ -13,6 +17,7 @@ from tinygp_amd import _ffi
 
 
 
+@functools.lru_cache(maxsize=None)
 def tasks_of(R, nblk, cb, ce):
     lib = _ffi.lib()
     n = C.c_int64()
@@ -22,7 +27,17 @@ def tasks_of(R, nblk, cb, ce):
     for t in range(n.value):
         _ffi.check(lib.tgp_chain_task(R, nblk, cb, ce, t, out, None), "tgp_chain_task")
         tasks.append(tuple(out))
-    return tasks
+    return tuple(tasks)
+
+
+def table_of(R, nblk, cb, ce, batch, lag, rowlag, minrows=0):
+    """the list launch_chain uploads: (kind, i, c, last k, part, first k) per ticket"""
+    lib = _ffi.lib()
+    n = C.c_int64()
+    _ffi.check(lib.tgp_chain_tasks(R, nblk, cb, ce, batch, lag, rowlag, minrows, None, 0, C.byref(n)), "tgp_chain_tasks")
+    out = (C.c_int32 * (6 * max(n.value, 1)))()
+    _ffi.check(lib.tgp_chain_tasks(R, nblk, cb, ce, batch, lag, rowlag, minrows, out, n.value, C.byref(n)), "tgp_chain_tasks")
+    return [tuple(out[6 * t: 6 * t + 6]) for t in range(n.value)]
 
 
 import functools
@@ -115,6 +130,93 @@ def test_every_task_once_and_waits_only_for_earlier_tickets(shape):
             deps = [final_of_tile(i, k), final_of_tile(c, k)] + updates_of(i, c, k)
         late = [d for d in deps if d is not None and d >= me]
         assert not late, (task, me, late)
+
+
+POLICIES = [(1, 1, 2, 0), (4, 1, 4, 0), (4, 1, 2, 0), (2, 1, 2, 0), (8, 2, 3, 0), (3, 1, 5, 0), (16, 1, 4, 0), (4, 1, 4, 32), (8, 1, 4, 20)]
+
+
+@pytest.mark.parametrize("policy", POLICIES, ids=[f"batch{b}-lag{g}-rowlag{r}-minrows{m}" for b, g, r, m in POLICIES])
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"R{r}-nblk{n}-cols{a}to{b}" for r, n, a, b in SHAPES])
+def test_table_covers_every_update_once_and_batches_wait_for_earlier_tickets(shape, policy):
+    R, nblk, cb, ce = shape
+    batch, lag, rowlag, minrows = policy
+    table = table_of(R, nblk, cb, ce, batch, lag, rowlag, minrows)
+    plain = tasks_of(R, nblk, cb, ce)
+    if batch <= 1:
+        assert [t[:5] for t in table] == list(plain) and all(t[5] == t[3] for t in table)
+    # every task of the unbatched launch is there once -- as itself, or (kind 2 only) inside exactly one batch
+    covered = {}
+    for n, t in enumerate(table):
+        kind, i, c, k, part, k0 = t
+        if kind == 6:
+            assert k - k0 + 1 >= 2 and k - k0 + 1 <= batch and k0 >= cb and k < ce
+            assert i >= c + rowlag and k + 1 + lag <= c  # off the diagonal lane, done lag + 1 steps ahead of column c
+            assert R - (k + 1) >= minrows                # only while the launch is throughput-bound
+            for kk in range(k0, k + 1):
+                assert (2, i, c, kk, 0) not in covered
+                covered[(2, i, c, kk, 0)] = n
+        else:
+            assert k0 == k and t[:5] not in covered
+            covered[t[:5]] = n
+    assert sorted(covered) == sorted(expected(R, nblk, cb, ce))
+    # a batch keeps the ticket position of its LAST update relative to everything that is not absorbed
+    kept = [t[:5] if t[0] != 6 else (2, t[1], t[2], t[3], 0) for t in table]
+    ks = set(kept)
+    assert kept == [t for t in plain if t in ks]
+
+    def final_of_tile(i, c):
+        if c < cb:
+            return None
+        if i == c + 1 and (5, 0, i, 0, 0) in covered:
+            return covered[(5, 0, i, 0, 0)]
+        return covered[(0, i, c, 0, 0)]
+
+    def updates_of(i, c, upto):
+        out = []
+        for k in range(cb, upto):
+            if i == c:
+                out.append(covered[(3, i, c, k, 0)])
+            elif (4, i, c, k, 0) in covered:
+                out += [covered[(4, i, c, k, p)] for p in range(crit_parts())]
+            else:
+                out.append(covered[(2, i, c, k, 0)])
+        return out
+
+    for me, t in enumerate(table):
+        kind, i, c, k, part, k0 = t
+        if kind == 0:
+            deps = updates_of(i, c, c) + [covered.get((1, 0, c, 0, 0))]
+        elif kind == 5:
+            deps = updates_of(c, c - 1, c - 1) + [covered.get((1, 0, c - 1, 0, 0))]
+        elif kind == 1:
+            deps = ([covered[(5, 0, c, 0, 0)]] if (5, 0, c, 0, 0) in covered else []) + updates_of(c, c, c - 1)
+        elif kind == 6:  # operands of EVERY column of the batch final (the kernel waits for the last: it implies the others)
+            deps = [final_of_tile(i, kk) for kk in range(k0, k + 1)] + [final_of_tile(c, kk) for kk in range(k0, k + 1)]
+            deps += updates_of(i, c, k0)
+            # "final in column k implies final in the columns before": the solve of tile (i, k) waited for all of them
+            for kk in range(k0, k):
+                a, b = final_of_tile(i, kk), final_of_tile(i, k)
+                assert a is None or a < b
+        else:
+            deps = [final_of_tile(i, k), final_of_tile(c, k)] + updates_of(i, c, k)
+        late = [d for d in deps if d is not None and d >= me]
+        assert not late, (t, me, late)
+
+
+def test_batches_are_staggered_over_the_steps():
+    """the boundaries of a tile's batches depend on (i + c): every step of a long launch ends about the same share of them"""
+    table = table_of(64, 64, 0, 64, 4, 1, 4)
+    ends = {}
+    for kind, i, c, k, part, k0 in table:
+        if kind == 6:
+            ends[k] = ends.get(k, 0) + 1
+    for k in range(8, 28):  # (the tiles right of a step get fewer as the launch advances: compare neighbouring steps)
+        win = [ends.get(kk, 0) for kk in range(k, k + 4)]
+        assert min(win) > 0.7 * max(win), (k, win)
+    n_updates = sum(1 for t in tasks_of(64, 64, 0, 64) if t[0] == 2)
+    n_left = sum(1 for t in table if t[0] == 2)
+    n_batched = sum(t[3] - t[5] + 1 for t in table if t[0] == 6)
+    assert n_left + n_batched == n_updates and n_batched > 0.7 * n_updates  # most of the one-launch tail's updates are batched
 
 
 def test_chain_task_rejects_bad_shapes():

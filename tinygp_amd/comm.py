@@ -62,21 +62,72 @@ class _Complete:
         return None
 
 
+def _job_nonce() -> bytes:
+    """16 bytes that every rank of ONE job derives the same way and another job does not: ``TGP_COMM_NONCE`` if set,
+    else the launcher's run id (``TORCHELASTIC_RUN_ID``) with the rendezvous endpoint, else zeros (no check)."""
+    import hashlib
+
+    key = os.environ.get("TGP_COMM_NONCE")
+    if key is None and os.environ.get("TORCHELASTIC_RUN_ID"):
+        key = "|".join(os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"))
+    return hashlib.sha256(key.encode()).digest()[:16] if key else b"\0" * 16
+
+
+_HELLO = b"TGPC"
+
+
+def _recv_exact(s, n: int) -> bytes:
+    data = b""
+    while len(data) < n:
+        chunk = s.recv(n - len(data))
+        if not chunk:
+            raise ConnectionError("closed")
+        data += chunk
+    return data
+
+
 def _exchange_tcp(rank: int, world: int, payload: bytes | None, addr: str, port: int, timeout: float) -> bytes:
-    """Rank 0 serves ``payload`` to world - 1 connections; the others fetch it (retrying until rank 0 listens)."""
+    """Rank 0 serves ``payload`` to the world - 1 OTHER RANKS of this job; the others fetch it (retrying until rank 0
+    listens).  A client says who it is first -- magic, rank, job nonce -- and rank 0 counts distinct valid ranks, not raw
+    connections: a port scanner, a health check or a leftover rank of another job is closed without using up a slot
+    and without seeing the id (advisor r5).  Rank 0 listens on ``addr`` (MASTER_ADDR), not on every interface."""
     if world == 1:
         return payload
+    if not 0 < port < 65536:
+        raise ValueError(f"communicator id port {port} is outside 1..65535 (set TGP_COMM_PORT)")
+    nonce = _job_nonce()
     if rank == 0:
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind(("", port))
-        srv.listen(world)
-        srv.settimeout(timeout)
         try:
-            for _ in range(world - 1):
-                conn, _ = srv.accept()
+            srv.bind((addr, port))
+        except OSError:  # MASTER_ADDR names another interface of this host (or a name that does not resolve here)
+            srv.bind(("", port))
+        srv.listen(world + 8)
+        deadline = time.monotonic() + timeout
+        served = set()
+        try:
+            while len(served) < world - 1:
+                left = deadline - time.monotonic()
+                if left <= 0:
+                    raise _ffi.TgpError(f"rank 0: only {len(served)} of {world - 1} ranks fetched the communicator id "
+                                        f"within {timeout:.0f} s")
+                srv.settimeout(left)
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
                 with conn:
-                    conn.sendall(struct.pack("<I", len(payload)) + payload)
+                    try:
+                        conn.settimeout(5.0)
+                        hello = _recv_exact(conn, 4 + 4 + 16)
+                        (peer,) = struct.unpack("<I", hello[4:8])
+                        if hello[:4] != _HELLO or hello[8:] != nonce or not 0 < peer < world:
+                            continue  # not a rank of this job: closed, no id, no slot
+                        conn.sendall(struct.pack("<I", len(payload)) + payload)
+                        served.add(peer)
+                    except (ConnectionError, OSError):
+                        continue
         finally:
             srv.close()
         return payload
@@ -86,21 +137,10 @@ def _exchange_tcp(rank: int, world: int, payload: bytes | None, addr: str, port:
         try:
             with socket.create_connection((addr, port), timeout=5.0) as s:
                 s.settimeout(timeout)
-                head = b""
-                while len(head) < 4:
-                    chunk = s.recv(4 - len(head))
-                    if not chunk:
-                        raise ConnectionError("closed")
-                    head += chunk
-                (n,) = struct.unpack("<I", head)
-                data = b""
-                while len(data) < n:
-                    chunk = s.recv(n - len(data))
-                    if not chunk:
-                        raise ConnectionError("closed")
-                    data += chunk
-                return data
-        except (ConnectionError, OSError) as e:  # rank 0 is not listening yet
+                s.sendall(_HELLO + struct.pack("<I", rank) + nonce)
+                (n,) = struct.unpack("<I", _recv_exact(s, 4))
+                return _recv_exact(s, n)
+        except (ConnectionError, OSError) as e:  # rank 0 is not listening yet (or belongs to another job)
             last = e
             time.sleep(0.05)
     raise _ffi.TgpError(f"rank {rank}: no communicator id from {addr}:{port} within {timeout:.0f} s ({last})")
@@ -135,21 +175,48 @@ class RcclComm:
         return cls(ctx, world, rank, uid)
 
     @classmethod
-    def from_file(cls, ctx: _ffi.Ctx, path, world: int, rank: int, timeout: float = 600.0) -> "RcclComm":
+    def from_file(cls, ctx: _ffi.Ctx, path, world: int, rank: int, timeout: float = 600.0,
+                  stale_after: float = 120.0) -> "RcclComm":
+        """The id travels through a file on a shared path.  The file is ``magic | job nonce | wall-clock stamp | id``:
+        rank 0 REMOVES whatever is at the path before it writes, a reader accepts only a file of ITS job (nonce, see
+        ``_job_nonce``) that is not older than ``stale_after`` seconds before the reader started waiting -- a file an
+        earlier run or an earlier communicator left behind is ignored, not joined (advisor r5) -- and rank 0 removes the
+        file once the communicator is up (``ncclCommInitRank`` returns when every rank has joined, i.e. has read it)."""
         path = os.fspath(path)
+        nonce = _job_nonce()
+        t_start = time.time()
         if rank == 0:
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
             tmp = f"{path}.tmp.{os.getpid()}"
             with open(tmp, "wb") as f:
-                f.write(cls.unique_id())
-            os.replace(tmp, path)  # atomic: a reader sees all 128 bytes or no file
+                f.write(_HELLO + nonce + struct.pack("<d", time.time()) + cls.unique_id())
+            os.replace(tmp, path)  # atomic: a reader sees the whole record or no file
         deadline = time.monotonic() + timeout
-        while not os.path.exists(path):
+        uid = None
+        while uid is None:
+            try:
+                with open(path, "rb") as f:
+                    rec = f.read()
+            except FileNotFoundError:
+                rec = b""
+            if len(rec) == 4 + 16 + 8 + ID_BYTES and rec[:4] == _HELLO and rec[4:20] == nonce:
+                (stamp,) = struct.unpack("<d", rec[20:28])
+                if stamp >= t_start - stale_after:
+                    uid = rec[28:]
+                    break
             if time.monotonic() > deadline:
-                raise _ffi.TgpError(f"rank {rank}: {path} did not appear within {timeout:.0f} s")
+                raise _ffi.TgpError(f"rank {rank}: no fresh communicator id at {path} within {timeout:.0f} s")
             time.sleep(0.02)
-        with open(path, "rb") as f:
-            uid = f.read()
-        return cls(ctx, world, rank, uid)
+        comm = cls(ctx, world, rank, uid)
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        return comm
 
     @classmethod
     def from_torch(cls, ctx: _ffi.Ctx, dist=None, group=None) -> "RcclComm":

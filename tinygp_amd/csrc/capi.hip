@@ -261,6 +261,8 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
   if (ctx->d_chain_flags) hipFree(ctx->d_chain_flags);
   if (ctx->d_chain_ticket) hipFree(ctx->d_chain_ticket);
   if (ctx->d_chain_stamps) hipFree(ctx->d_chain_stamps);
+  for (auto& kv : ctx->chain_tables)
+    if (kv.second.dev) hipFree(kv.second.dev);
   if (ctx->d_dinv) hipFree(ctx->d_dinv);
   if (ctx->d_work) hipFree(ctx->d_work);
   if (ctx->d_gemm_ws) hipFree(ctx->d_gemm_ws);
@@ -297,6 +299,10 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "chain_pre_wait")) return &ctx->chain_pre_wait;
   if (!strcmp(key, "chain_polls")) return &ctx->chain_polls;
   if (!strcmp(key, "chain_fast_update")) return &ctx->chain_fast_update;
+  if (!strcmp(key, "chain_batch")) return &ctx->chain_batch;
+  if (!strcmp(key, "chain_batch_lag")) return &ctx->chain_batch_lag;
+  if (!strcmp(key, "chain_batch_rowlag")) return &ctx->chain_batch_rowlag;
+  if (!strcmp(key, "chain_batch_minrows")) return &ctx->chain_batch_minrows;
   if (!strcmp(key, "kmat_plain_div")) return &ctx->kmat_plain_div;
   if (!strcmp(key, "chain_reserve")) return &ctx->chain_reserve;
   if (!strcmp(key, "gate_split")) return &ctx->gate_split;
@@ -322,6 +328,10 @@ static int set_option_checked(tgp_ctx* ctx, const char* key, int64_t value, int6
     TGP_ARG_CHECK(value >= TILE && value % TILE == 0, "nb_outer must be a positive multiple of %d", TILE);
   if (slot == &ctx->sub_panel || slot == &ctx->nb_first)
     TGP_ARG_CHECK(value >= 0 && value % TILE == 0, "%s must be a multiple of %d (0: off)", key, TILE);
+  if (slot == &ctx->chain_batch) TGP_ARG_CHECK(value >= 0 && value <= 32, "chain_batch must be in [0, 32]");
+  if (slot == &ctx->chain_batch_lag) TGP_ARG_CHECK(value >= 1 && value <= 64, "chain_batch_lag must be in [1, 64]");
+  if (slot == &ctx->chain_batch_minrows) TGP_ARG_CHECK(value >= 0 && value <= 4096, "chain_batch_minrows must be in [0, 4096]");
+  if (slot == &ctx->chain_batch_rowlag) TGP_ARG_CHECK(value >= 2 && value <= 4096, "chain_batch_rowlag must be in [2, 4096]");
   if (old) *old = *slot;
   // (the bound lives in a device global of the library: it holds for every context of the process on this device)
   if (slot == &ctx->poll_timeout_ms && ctx->has_device) return set_poll_limit(ctx, value);
@@ -1227,6 +1237,23 @@ int tgp_chain_task(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t tick
     }
     const ChainTask t = chain_decode_ticket((int)ticket, (int)R, (int)nblk, (int)cb, (int)ce);
     out5[0] = t.kind; out5[1] = t.i; out5[2] = t.c; out5[3] = t.k; out5[4] = t.part;
+  }
+  return TGP_OK;
+}
+
+int tgp_chain_tasks(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t batch, int64_t lag, int64_t rowlag, int64_t minrows,
+                    int32_t* out6, int64_t cap_tasks, int64_t* n_tasks) {
+  if (!(R >= 1 && cb >= 0 && cb < ce && ce <= nblk && nblk <= 64 && nblk <= R && R <= tgp::CHAIN_MAX_ROW_TILES) ||
+      !(batch >= 0 && batch <= 32 && lag >= 1 && rowlag >= 2 && minrows >= 0) || n_tasks == nullptr || cap_tasks < 0) {
+    tgp::set_error("tgp_chain_tasks: bad panel shape or policy");
+    return TGP_E_ARG;
+  }
+  const std::vector<ChainTask> list = chain_build((int)R, (int)nblk, (int)cb, (int)ce, ChainPolicy{(int)batch, (int)lag, (int)rowlag, (int)minrows});
+  *n_tasks = (int64_t)list.size();
+  for (int64_t u = 0; out6 != nullptr && u < (int64_t)list.size() && u < cap_tasks; ++u) {
+    const ChainTask t = chain_unpack(chain_pack(list[size_t(u)]));  // through the table's packing: what the kernel sees
+    int32_t* o = out6 + 6 * u;
+    o[0] = t.kind; o[1] = t.i; o[2] = t.c; o[3] = t.k; o[4] = t.part; o[5] = t.k0;
   }
   return TGP_OK;
 }

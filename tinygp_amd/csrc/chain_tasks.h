@@ -3,14 +3,33 @@
 // enumerates every ticket of a launch on the CPU and checks that each task exists exactly once and waits for EARLIER
 // tickets only -- what makes one-task-per-workgroup deadlock-free without co-residency).  CHAIN_HD is defined by the
 // includer (__host__ __device__ in HIP code, empty in a host-only translation unit).
+//
+// Round 6: the kernel no longer decodes its ticket.  launch_chain builds the launch's task list ONCE per shape on the host
+// (chain_build below: this header's order, with the K-BATCHED updates of ChainPolicy folded in), keeps it on the device as a
+// table of packed 64-bit words and a workgroup reads tasks[ticket].  The walk below is host code now (it cost every
+// workgroup 1-3 us of scalar work at its start); the device needs the packing and CHAIN_CRIT_PARTS only.
 #pragma once
 #include <cstdint>
+#include <vector>
 
 struct ChainTask {
   int kind;  // 0 solve(i, c) | 1 diag(c) | 2 update(i, c, k) | 3 update of the diagonal tile (c, c) from column k |
-             // 4 one of CHAIN_CRIT_PARTS parts (`part`) of update(i, c, k) | 5 xsolve(c): the streamed solve of tile (c, c-1) | -1 none
+             // 4 one of CHAIN_CRIT_PARTS parts (`part`) of update(i, c, k) | 5 xsolve(c): the streamed solve of tile (c, c-1) |
+             // 6 update(i, c, [k0, k]): ONE product over block columns k0 .. k (K = 128 (k - k0 + 1)), ChainPolicy | -1 none
   int i, c, k, part;
+  int k0;    // kind 6: first block column of the batch (else = k)
 };
+// one table word: kind 4 bits | part 4 | c 8 | k 8 | k0 8 | i 16
+CHAIN_HD inline uint64_t chain_pack(const ChainTask& t) {
+  return uint64_t(t.kind & 15) | (uint64_t(t.part & 15) << 4) | (uint64_t(t.c & 255) << 8) | (uint64_t(t.k & 255) << 16) |
+         (uint64_t(t.k0 & 255) << 24) | (uint64_t(t.i & 65535) << 32);
+}
+CHAIN_HD inline ChainTask chain_unpack(uint64_t w) {
+  ChainTask t;
+  t.kind = int(w & 15); t.part = int((w >> 4) & 15); t.c = int((w >> 8) & 255); t.k = int((w >> 16) & 255);
+  t.k0 = int((w >> 24) & 255); t.i = int((w >> 32) & 65535);
+  return t;
+}
 constexpr int CHAIN_CRIT_PARTS = 8;  // workgroups that share the update of tile (k+2, k+1) from column k
 
 // TICKET ORDER (round 5).  With DG(j) = [xsolve(j), diag(j)] (block j is factored by this launch: cb < j < ce),
@@ -70,17 +89,30 @@ CHAIN_HD inline int chain_n_bulk(const ChainLaunch& q, int k) {
   return n - chain_n_D(q, k) - (q.lane ? chain_n_E(q, k) : 0);
 }
 
-// one walk over the order above: `t` < 0 counts the tickets (returned), `t` >= 0 decodes that ticket into *out
-CHAIN_HD inline int64_t chain_walk(const ChainLaunch& q, int64_t t, ChainTask* out) {
+// one walk over the order above: `t` < 0 counts the tickets (returned), `t` >= 0 decodes that ticket into *out;
+// `all` != NULL (host): every task of the launch is appended in ticket order (one walk, not one per ticket)
+typedef std::vector<ChainTask> ChainTaskList;
+inline int64_t chain_walk(const ChainLaunch& q, int64_t t, ChainTask* out, ChainTaskList* all = nullptr) {
   int64_t seen = 0;
-  ChainTask task = {-1, 0, 0, 0, 0};
+  ChainTask task = {-1, 0, 0, 0, 0, 0};
+#define CHAIN_EMIT_ALL(cnt_, body)                        \
+  if (all != nullptr) {                                   \
+    for (int u = 0; u < int(cnt_); ++u) {                 \
+      task = ChainTask{-1, 0, 0, 0, 0, 0};                \
+      body;                                               \
+      task.k0 = task.k;                                   \
+      all->push_back(task);                               \
+    }                                                     \
+  }
 #define CHAIN_GROUP(count, body)                          \
   do {                                                    \
     const int64_t cnt_ = (count);                         \
+    CHAIN_EMIT_ALL(cnt_, body)                            \
     if (t >= 0 && t < seen + cnt_) {                      \
       const int u = int(t - seen);                        \
       (void)u;                                            \
       body;                                               \
+      task.k0 = task.k;                                   \
       *out = task;                                        \
       return seen + cnt_;                                 \
     }                                                     \
@@ -144,6 +176,7 @@ CHAIN_HD inline int64_t chain_walk(const ChainLaunch& q, int64_t t, ChainTask* o
     CHAIN_GROUP(chain_n_bulk(q, k), bulk(k, u));
   }
 #undef CHAIN_GROUP
+#undef CHAIN_EMIT_ALL
   return seen;
 }
 
@@ -157,7 +190,63 @@ CHAIN_HD inline int64_t chain_task_count(int R, int nblk, int cb, int ce) {
 
 CHAIN_HD inline ChainTask chain_decode_ticket(int t, int R, int nblk, int cb, int ce) {
   const ChainLaunch q = chain_launch(R, nblk, cb, ce);
-  ChainTask task = {-1, 0, 0, 0, 0};
+  ChainTask task = {-1, 0, 0, 0, 0, 0};
   chain_walk(q, t, &task);
   return task;
+}
+
+// ---- K-BATCHED updates (round 6) ------------------------------------------------------------------------------------
+// A right-looking update task reads and writes its 128 x 128 tile for ONE 128-deep product: 256 KB of tile traffic per
+// 4.2 MFLOP.  A launch over many block columns (the one-launch tail) is bound by exactly that -- N = 8 192 as one launch ran
+// at 27 TFLOP/s (profiles/r06_a) -- and the tiles far from the diagonal are in no hurry: tile (i, c) is needed when the
+// chain reaches column c, and its row when it reaches row i.  So the updates of a tile are BATCHED along k: tile (i, c)
+// has boundaries at the block columns b with (b - cb + (i + c)) % batch == 0 -- staggered over the tiles so that every
+// step carries the same share of batch tasks -- and ONE task applies the columns between two boundaries,
+// update(i, c, [k0, k1)), K = 128 (k1 - k0): the tile is read and written once per batch (and the 4x4x4 MFMA form's
+// prologue / publish are paid once: chain_update_fast).  A batch exists when
+//   i >= c + rowlag      the tile is off the diagonal lane (tiles near the diagonal feed xsolve / diag within a step or two),
+//   k1 + lag <= c        its last column is solved at least lag + 1 steps before column c is,
+//   k1 <= ce, k1 - k0 >= 2,
+//   R - k1 >= minrows    the launch is still THROUGHPUT-bound when the batch is handed out: (R - k)^2 / 2 update tasks per
+//                        step fill 256 compute units for longer than a step of the diagonal chain while more than ~30 row
+//                        tiles are left; behind that the chain sets the pace, a 70-us batch task only delays the tiles the
+//                        diagonal lane needs next (N = 4 096 as one launch: 1.35 -> 1.81 ms with batches everywhere,
+//                        profiles/r06_b), and every update stays the single task it was
+// and takes the ticket update(i, c, k1 - 1) had (everything it waits for -- X_{i,k1-1}, X_{c,k1-1}, the tile's previous batch
+// or update -- has an earlier ticket there: tests/test_chain_tasks.py); the updates it absorbs disappear.  Every other
+// update stays the single task it was.  The order of summation inside a tile changes with the policy (deterministic for
+// a given policy; the results of different policies agree to rounding).
+struct ChainPolicy {
+  int batch;    // block columns per batch (<= 1: off)
+  int lag;      // >= 1
+  int rowlag;   // >= 2
+  int minrows;  // row tiles that must be left behind the batch's last column (0: no such condition)
+};
+CHAIN_HD inline bool chain_batch_of(const ChainLaunch& q, const ChainPolicy& p, int i, int c, int k, int* k0, int* k1) {
+  if (p.batch <= 1 || i < c + p.rowlag) return false;
+  const int r = (k + 1 - q.cb + i + c) % p.batch;
+  const int e = r == 0 ? k + 1 : k + 1 + (p.batch - r);  // first boundary behind column k
+  const int b = e - p.batch > q.cb ? e - p.batch : q.cb;
+  if (e + p.lag > c || e > q.ce || e - b < 2 || q.R - e < p.minrows) return false;
+  *k0 = b;
+  *k1 = e;
+  return true;
+}
+
+// the launch's task list in ticket order, batches folded in (host)
+inline std::vector<ChainTask> chain_build(int R, int nblk, int cb, int ce, const ChainPolicy& p) {
+  const ChainLaunch q = chain_launch(R, nblk, cb, ce);
+  std::vector<ChainTask> all, out;
+  chain_walk(q, -1, nullptr, &all);
+  out.reserve(all.size());
+  for (ChainTask t : all) {
+    int k0 = 0, k1 = 0;
+    if (t.kind == 2 && chain_batch_of(q, p, t.i, t.c, t.k, &k0, &k1)) {
+      if (t.k != k1 - 1) continue;  // absorbed by the batch that ends at column k1 - 1
+      t.kind = 6;
+      t.k0 = k0;
+    }
+    out.push_back(t);
+  }
+  return out;
 }

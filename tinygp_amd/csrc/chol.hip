@@ -465,6 +465,7 @@ struct ChainArgs {
   long long* stamps;   // measurement hook (ctx option chain_stamps): 16 words per task from this base, or NULL
   int32_t launch;
   int32_t fast_update;  // fp64 whole-tile updates on the 4x4x4 MFMA form, LDS-direct operands (chain_update_fast)
+  const uint64_t* tasks;  // the launch's task list in ticket order, one packed word per task (chain_tasks.h, chain_pack)
 };
 
 // all threads; wave 0 polls up to three state words (lane l: word f[l] == v[l]; NULL: nothing to wait for),
@@ -668,7 +669,9 @@ __device__ __forceinline__ void chain_update_full(const ChainArgs<T>& q, T* S, i
 // accumulators, beside the first operand transfer; the MFMA's NEG field turns the products into -X_ik X_ck^T, so the
 // accumulators end as the updated tile and the epilogue is 32 write-through stores per lane, nothing loaded.
 // Wave tile 32 rows x 64 columns: acc[a][b][t] <-> row wr*32 + b*16 + rot4(lane, t), column wc*64 + a*16 + arow4(lane).
-__device__ __forceinline__ void chain_update_fast(const ChainArgs<double>& q, double* S, int i, int c, int k) {
+// Round 6: the product runs over block columns [k, k1) -- K = 128 (k1 - k), the operands of consecutive block columns are
+// consecutive columns of the panel -- so that a BATCHED update (chain_tasks.h, ChainPolicy) reads and writes its tile once.
+__device__ __forceinline__ void chain_update_fast(const ChainArgs<double>& q, double* S, int i, int c, int k, int k1) {
   using M = Mfma<double>;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -724,7 +727,7 @@ __device__ __forceinline__ void chain_update_fast(const ChainArgs<double>& q, do
 #pragma unroll
       for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(acc[a][b][t]));
   __syncthreads();
-  constexpr int nkt = TILE / FK;
+  const int nkt = (k1 - k) * (TILE / FK);
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) issue_tile(kt + 1, buf ^ 1);
@@ -749,7 +752,9 @@ __device__ __forceinline__ void chain_update_fast(const ChainArgs<double>& q, do
       // one k-step's operands at a time (24 registers): left to itself the scheduler reads two steps ahead, runs out
       // of the 128 registers and reloads a spilled index behind the transfers it has just issued -- with a vmcnt(0)
       // that waits for THEM.  The other wave of the SIMD covers the read latency.
+#ifndef TGP_PROBE_WIDE
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next k-tile has landed (the only wait of the transfers)
     __syncthreads();
@@ -1159,20 +1164,26 @@ __device__ __forceinline__ void chain_fold_stream(const ChainArgs<T>& q, T* S, i
 // lane-derived values of every phase across the whole loop body -- 100+ spilled VGPRs under the 128-register cap
 // that keeps two chain workgroups on a CU beside the trailing update.  Tickets are taken at workgroup start, so
 // every earlier ticket belongs to a workgroup that is running or done, whatever order the hardware starts them in.
+#ifdef TGP_PROBE_WIDE  // measurement build: 256 registers per wave (nothing co-resident)
+#define CHAIN_WAVES_PER_EU 2
+#else
+#define CHAIN_WAVES_PER_EU 4
+#endif
 template <typename T>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void chain_kernel(const ChainArgs<T> q) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(CHAIN_WAVES_PER_EU, CHAIN_WAVES_PER_EU))) void chain_kernel(const ChainArgs<T> q) {
   __shared__ __attribute__((aligned(16))) T S[36 * 256];
   __shared__ T Rs[2 * 16];
   __shared__ T Dg[256];
-  __shared__ int s_task[6];
+  __shared__ int s_task[7];
   using acc_t = typename Mfma<T>::acc_t;
   if (threadIdx.x == 0) {
-    // ticket -> task (chain_tasks.h: the same map sizes the launch on the host and is checked on the CPU)
+    // ticket -> task: one word of the launch's table (built on the host by chain_tasks.h, the text the CPU test checks)
     const int t = atomicAdd(q.ticket, 1);
     s_task[4] = t;
-    const ChainTask task = chain_decode_ticket(t, q.R, q.nblk, q.cb, q.ce);
+    const ChainTask task = chain_unpack(q.tasks[t]);
     const int kind = task.kind, ti = task.i, tc = task.c, tk = task.k;
     s_task[5] = task.part;
+    s_task[6] = task.k0;
     s_task[0] = kind; s_task[1] = ti; s_task[2] = tc; s_task[3] = tk;
   }
   __syncthreads();
@@ -1180,18 +1191,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int ti = __builtin_amdgcn_readfirstlane(s_task[1]);
   const int tc = __builtin_amdgcn_readfirstlane(s_task[2]);
   const int tk = __builtin_amdgcn_readfirstlane(s_task[3]);
-  if (kind < 0) return;
+  if (kind > 6) return;
   long long* st = nullptr;
   if (q.stamps != nullptr) {  // {kind, row tile, block column, launch | update column << 8, stamps ...}
     st = q.stamps + int64_t(__builtin_amdgcn_readfirstlane(s_task[4])) * 16;
     if (threadIdx.x == 0) {
-      st[0] = kind; st[1] = kind == 1 ? tc : ti; st[2] = tc; st[3] = q.launch | (tk << 8);
+      st[0] = kind; st[1] = kind == 1 ? tc : ti; st[2] = tc; st[3] = q.launch | (tk << 8) | (s_task[6] << 16);
       for (int k = 1; k < 12; ++k) st[4 + k] = 0;
     }
     chain_stamp(st, 0);  // task started
   }
   const uint32_t E = q.epoch32;
   const bool head_final = q.cb == 0;  // L_00 was factored in front of the launch
+  if constexpr (sizeof(T) == 8) {
+    if (kind == 6) {  // ---- update(i, c, [k0, k]): the batched form (fp64 only: the policy is off for fp32) ----
+      const int i = ti, c = tc, k = tk, k0 = __builtin_amdgcn_readfirstlane(s_task[6]);
+      uint32_t* wt = q.flags + i * CHAIN_FLAG_LD + c;
+      // X_{i,k} / X_{c,k} final implies the block columns before them are (their solves waited for exactly those); the
+      // tile carries every update from the columns in front of the batch
+      chain_wait<8>(q.flags + i * CHAIN_FLAG_LD + k, E + CHAIN_FINAL, q.flags + c * CHAIN_FLAG_LD + k, E + CHAIN_FINAL,
+                    k0 > q.cb ? wt : nullptr, E + uint32_t(k0), q.info);
+      chain_stamp(st, 1);
+      chain_update_fast(q, S, i, c, k0, k + 1);
+      chain_stamp(st, 2);
+      chain_publish(wt, E + uint32_t(k + 1));
+      chain_stamp(st, 3);
+      return;
+    }
+  }
   if (kind >= 2 && kind <= 4) {  // ---- update(i, c, k) ----
     const int i = ti, c = tc, k = tk;
     uint32_t* wt = q.flags + i * CHAIN_FLAG_LD + c;
@@ -1200,7 +1227,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     chain_stamp(st, 1);  // operands final, the tile carries every earlier update
     if (kind == 2) {
       if constexpr (sizeof(T) == 8) {
-        if (q.fast_update) chain_update_fast(q, S, i, c, k);
+        if (q.fast_update) chain_update_fast(q, S, i, c, k, k + 1);
         else chain_update_full<T, 1>(q, S, i, c, k, 0);
       } else {
         chain_update_full<T, 1>(q, S, i, c, k, 0);
@@ -2103,6 +2130,13 @@ int launch_panel_step(tgp_ctx* ctx, hipStream_t st, int64_t m, T* Ljj, int64_t l
   return TGP_OK;
 }
 
+// the update-batching policy of a launch: fp64 only (the batched product is chain_update_fast, the 4x4x4 fp64 form)
+template <typename T>
+ChainPolicy chain_policy(const tgp_ctx* ctx) {
+  if (sizeof(T) != 8 || ctx->chain_batch <= 1) return ChainPolicy{1, 1, 2, 0};
+  return ChainPolicy{(int)ctx->chain_batch, (int)ctx->chain_batch_lag, (int)ctx->chain_batch_rowlag, (int)ctx->chain_batch_minrows};
+}
+
 // Persistent chain over block columns [cb, ce) of the panel whose origin is A0 (R row tiles down to the end of
 // the matrix; dinv0 = the inverses of the panel's first block).  head_done: L_cb,cb is already factored.
 template <typename T>
@@ -2126,7 +2160,25 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
     trace_push(ctx, 11, st, trace_off(ctx, A0), ld, R, cb, ce, nblk);
     return TGP_OK;
   }
-  const int64_t tasks = chain_task_count((int)R, (int)nblk, (int)cb, (int)ce);  // (chain_tasks.h)
+  // the launch's task list (chain_tasks.h: ticket order + K-batched updates), one table per shape and policy, kept on the
+  // device for the life of the context (13 shapes per evaluation at c2, the same in every evaluation)
+  const ChainPolicy pol = chain_policy<T>(ctx);
+  const std::array<int64_t, 8> key = {R, nblk, cb, ce, pol.batch, pol.lag, pol.rowlag, pol.minrows};
+  auto found = ctx->chain_tables.find(key);
+  if (found == ctx->chain_tables.end()) {
+    const std::vector<ChainTask> list = chain_build((int)R, (int)nblk, (int)cb, (int)ce, pol);
+    tgp_ctx::ChainTable tab;
+    tab.count = (int64_t)list.size();
+    if (tab.count > 0) {
+      std::vector<uint64_t> words(list.size());
+      for (size_t u = 0; u < list.size(); ++u) words[u] = chain_pack(list[u]);
+      TGP_HIP_TRY(hipMalloc((void**)&tab.dev, words.size() * sizeof(uint64_t)));
+      // (blocking copy on the null stream: the library's streams are non-blocking, nothing of theirs is joined)
+      TGP_HIP_TRY(hipMemcpy(tab.dev, words.data(), words.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    found = ctx->chain_tables.emplace(key, tab).first;
+  }
+  const int64_t tasks = found->second.count;
   if (tasks == 0) {  // a one-block panel: potf2 in front was all of it; the pollers' event still marks this point
     if (counters_ready != nullptr) TGP_TRY(ev_record(ctx, counters_ready, st));
     return TGP_OK;
@@ -2142,6 +2194,7 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
   q.stamps = nullptr;
   q.launch = (int32_t)ctx->chain_launches++;
   q.fast_update = (int32_t)ctx->chain_fast_update;
+  q.tasks = found->second.dev;
   if (ctx->chain_stamps != 0 && ctx->chain_stamp_base + tasks <= CHAIN_STAMP_TASKS) {
     if (ctx->d_chain_stamps == nullptr)
       TGP_HIP_TRY(hipMalloc((void**)&ctx->d_chain_stamps, size_t(CHAIN_STAMP_TASKS) * 16 * sizeof(long long)));
@@ -2511,6 +2564,10 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
         TGP_TRY(st_wait(ctx, S0, ev_chain[p & 1]));
         if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S0, ctx->ev_asm));
         if (p + 2 < P) {
+          // (Round 6, measured and removed, profiles/r06_g: pre(p) on a high-priority side stream BESIDE rest(p) -- both wait
+          // for chain(p) and rest(p-1), they touch different columns -- so that the main stream carries rest launches only
+          // and the next gate does not wait for a launch queued behind a whole trailing update: pre then takes 0.74-1.3 ms
+          // instead of 0.34 and c2 27.2 instead of 25.8 ms.)
           if (pre_waits) TGP_TRY(st_wait(ctx, S0, ctx->ev_h));  // behind the next panel's first potf2 (see tgp_common.h)
           const int64_t next2 = s0[p + 2], wn2 = s0[p + 3] - s0[p + 2], mt2 = n - next2;
           TGP_TRY(trailing(S0, mt2, wn2, kb, A + s0[p] * ld + next2, A + next2 * ld + next2, first_role(mt2, wn2)));

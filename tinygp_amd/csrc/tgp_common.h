@@ -7,7 +7,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <chrono>
+#include <array>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -136,6 +138,23 @@ struct tgp_ctx {
   // form -- the task is bound by its prologue (tile + first operands: one round trip), the per-k-step LDS latency under the
   // 128-register cap and 32 scattered 8-byte write-through stores per lane, not by the MFMA form; c2 26.1 vs 25.5 ms
   int64_t chain_fast_update = 0;
+  // K-batched update tasks of the chain launch (round 6, chain_tasks.h ChainPolicy; fp64 only): block columns per batch
+  // (<= 1: off), columns between a batch's end and the tile's own column, rows between the tile and the diagonal, row tiles
+  // that must be left.  BUILT, parity-green, MEASURED, OFF (profiles/r06_b, r06_c, r06_f): a K = 512 batch task takes 74 us
+  // = 18.5 us per 128^3 against 19-20 + 1.6 for the single tasks (the product streams its operands from the Infinity Cache
+  // one k-tile ahead, not from the L2 as the trailing update does with its tile order) -- 8-17 % less compute-unit time per
+  // flop -- while the tile's NEXT task waits three times as long for it: N = 4 096 as one launch 1.81 vs 1.35 ms with batches
+  // everywhere, N = 8 192 as ONE launch 5.1-5.6 vs 6.7 ms unbatched but 4.75 ms panel by panel, c2 25.8 vs 25.2 ms
+  int64_t chain_batch = 1;
+  int64_t chain_batch_lag = 1;
+  int64_t chain_batch_rowlag = 4;
+  int64_t chain_batch_minrows = 32;
+  // task tables of the chain launches (ticket -> packed task), one per launch shape and policy, built on first use
+  struct ChainTable {
+    uint64_t* dev = nullptr;
+    int64_t count = 0;
+  };
+  std::map<std::array<int64_t, 8>, ChainTable> chain_tables;
   int64_t chain_full_rows = 4096;     // with at most this many rows left the WHOLE rest is one chain launch (measured
                                       // at N = 16 384: 4096 26.6 ms, 6144 26.9, 8192 27.6; per-block chain 28.2)
   int64_t chain_depth2 = 1;           // gate + chain of the next panel on the priority stream, two panels ahead

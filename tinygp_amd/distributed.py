@@ -48,6 +48,7 @@ import os
 import numpy as np
 
 from tinygp_amd import _ffi
+from tinygp_amd._device import MAX_DIM
 
 __all__ = ["HipBlockOps", "BlockCyclicCholesky"]
 
@@ -294,10 +295,13 @@ class HipBlockOps:
     def grad_end(self, d: int):
         """(partial sums as a device buffer of 2 * nops + d float64 for the all-reduce, diag(K^-1) on the host)"""
         gp_ = (C.c_double * (2 * self._grad_nops))()
-        gl = (C.c_double * max(d, 1))()
+        # the library writes one double per INPUT DIMENSION of the data into grad_logscale whenever the pointer is
+        # non-NULL -- whatever `d` the caller wants back (advisor r5: an array of max(d, 1) was overrun by D >= 2
+        # inputs without a covering transform).  NULL when no log-scale gradient is wanted, TGP_MAX_DIM doubles else.
+        gl = (C.c_double * MAX_DIM)() if d > 0 else None
         diag = np.empty(self.n, dtype=self.dtype)
         _ffi.check(self.lib.tgp_dist_grad_end(self.h, gp_, gl, _ffi.ptr(diag)), "tgp_dist_grad_end")
-        part = np.array(list(gp_) + list(gl)[:d], dtype=np.float64)
+        part = np.array(list(gp_) + (list(gl)[:d] if d > 0 else []), dtype=np.float64)
         buf = self._alloc((part.size,), np.float64)
         _ffi.check(self.lib.tgp_stream_h2d(self.ctx.handle, MAIN, C.c_void_p(buf.ptr), _ffi.ptr(part), part.nbytes),
                    "tgp_stream_h2d")
