@@ -41,7 +41,7 @@ extern "C" {
  *  tgp_dist_bwd_*_multi, tgp_dist_gather_owned, tgp_dist_identity_cols,
  *  tgp_dist_grad_* -- multi-RHS backward solve and gradient on the block-column path;
  *  round 5 -> 6: tgp_chain_tasks (the chain launch's task TABLE with its K-batched updates), options chain_batch /
- *  chain_batch_lag / chain_batch_rowlag) */
+ *  chain_batch_lag / chain_batch_rowlag / chain_batch_minrows, trsv_groups; tgp_solver_timings ms[7]) */
 #define TGP_ABI_VERSION 6
 
 /* element types: follows the dtype of the caller's arrays (gp.py:89) */
@@ -163,7 +163,9 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "split_tail"        1: the last, partly filled round of tiles of a trailing update is split along k
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
  *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming
- *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block
+ *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block;
+ *                       "trsv_groups" (0 = by size: 3 / 4 / 6): workgroups per block row of the forward launch -- G - 1
+ *                       helpers stream the raw tiles, the primary applies W_b, tf_b = W_b L[b,b-1] and tf2_b = W_b L[b,b-2]
  *   "keep_grad_buffers" 1: tgp_solver_grad keeps its (N + 128) x N work matrix between calls whatever its
  *                       size (default: kept up to 4 GiB, released at once above) */
 int tgp_ctx_set_option(tgp_ctx* ctx, const char* key, int64_t value, int64_t* old);
@@ -318,7 +320,8 @@ int tgp_solver_device_factor(tgp_solver* s, void** L_dev, int64_t* n_pad);
  * ms[1]=potrf total, ms[2]=sum of the 128x128-tile trailing-update launches (event spans),
  * ms[3]=number of those launches, ms[4]=separate trsv pass (0 when fused), ms[5]=HOST time from the entry of the last
  * factorisation to its last enqueue (how far ahead of the device the submitting thread runs),
- * ms[6]=algorithmic flops of those launches */
+ * ms[6]=algorithmic flops of those launches, ms[7]=length of the UNION of their intervals (launches of the main and the
+ * priority stream overlap at large N: their sum can exceed the evaluation, the union cannot) */
 int tgp_solver_timings(tgp_solver* s, double* ms, int n);
 
 /* ---- block-cyclic column Cholesky over the GPUs of one node (BASELINE configs 4 / 5) ----------

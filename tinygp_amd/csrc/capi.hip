@@ -139,7 +139,7 @@ static int assemble_lower(tgp_ctx* ctx, const tgp::KProg& kp, int64_t n, int d, 
 template <typename T>
 static int ensure_winv(tgp_solver* s) {
   if (s->winv_valid) return TGP_OK;
-  if (!s->winv) TGP_HIP_TRY(hipMalloc(&s->winv, 3 * size_t(s->npad / TILE) * 16384 * sizeof(T)));  // W, W^T, tf
+  if (!s->winv) TGP_HIP_TRY(hipMalloc(&s->winv, 4 * size_t(s->npad / TILE) * 16384 * sizeof(T)));  // W, W^T, tf, tf2
   TGP_TRY(compute_winv<T>(s->ctx, s->npad, (const T*)s->A, s->npad, (T*)s->winv));
   s->winv_valid = true;
   return TGP_OK;
@@ -287,6 +287,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "first_small_tiles")) return &ctx->first_small_tiles;
   if (!strcmp(key, "keep_grad_buffers")) return &ctx->keep_grad_buffers;
   if (!strcmp(key, "stream_trsv")) return &ctx->stream_trsv;
+  if (!strcmp(key, "trsv_groups")) return &ctx->trsv_groups;
   if (!strcmp(key, "nb_wide_rows")) return &ctx->nb_wide_rows;
   if (!strcmp(key, "dist_solve_aux")) return &ctx->dist_solve_aux;
   if (!strcmp(key, "solve_on_update")) return &ctx->solve_on_update;
@@ -749,6 +750,7 @@ static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void*
     s->ms[2] = ctx->prof_syrk_ms;
     s->ms[3] = (double)ctx->prof_syrk_launches;
     s->ms[6] = ctx->prof_syrk_flops;
+    s->ms[7] = ctx->prof_syrk_union_ms;
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     hipEventDestroy(e2);

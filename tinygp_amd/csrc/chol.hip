@@ -16,6 +16,7 @@
 // trsm    X L^T = B for a 128-column panel: one wave per 16 rows, transposed recurrence
 //         Y_j = inv(L_jj) (B_j^T - sum_{k<j} L_jk Y_k) so that an MFMA result (D layout)
 //         is directly the next MFMA's B operand -- no LDS, no shuffles.
+#include <algorithm>
 #include <functional>
 #include <type_traits>
 
@@ -1591,13 +1592,13 @@ __device__ __forceinline__ T bits_to(typename Sent<T>::bits_t b) {
 // tmp <- y, y <- sentinel, ticket <- 0
 template <typename T>
 __global__ __launch_bounds__(256) void trsv_prep_kernel(int64_t n, T* __restrict__ y, T* __restrict__ tmp,
-                                                        int32_t* __restrict__ ticket, T* __restrict__ part) {
+                                                        int32_t* __restrict__ ticket, T* __restrict__ part, int nparts) {
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (i == 0) *ticket = 0;
   if (i < n) {
     tmp[i] = y[i];
     y[i] = bits_to<T>(Sent<T>::value);
-    part[i] = bits_to<T>(Sent<T>::value);  // the helpers' partial sums
+    for (int h = 0; h < nparts; ++h) part[int64_t(h) * n + i] = bits_to<T>(Sent<T>::value);  // the helpers' partial sums
   }
 }
 
@@ -1609,7 +1610,7 @@ __global__ __launch_bounds__(256) void trsv_prep_kernel(int64_t n, T* __restrict
 // With it the hop from x_{b-1} to x_b is ONE matrix-vector product and one reduction.
 template <typename T>
 __global__ __launch_bounds__(128) void winv_kernel(int nblk, const T* __restrict__ L, int64_t ld, T* __restrict__ winv,
-                                                   T* __restrict__ winvT, T* __restrict__ tfwd) {
+                                                   T* __restrict__ winvT, T* __restrict__ tfwd, T* __restrict__ tfwd2) {
   __shared__ T Lp[8256];
   __shared__ T Wp[8256];
   const int c = threadIdx.x;
@@ -1635,9 +1636,13 @@ __global__ __launch_bounds__(128) void winv_kernel(int nblk, const T* __restrict
   }
   __syncthreads();  // every column of W is in Wp; Lp is free: it takes 64 rows of a neighbouring tile at a time
   T* Lt = Lp;  // [64][128]: thread c reads Lt[k * 128 + c] -- conflict-free; W entries are LDS broadcasts
-  if (b >= 1) {  // tf_b[:, c] = W_b L[b, b-1][:, c], in two halves of the inner index k
-    const T* tile = Lb - int64_t(128) * ld;  // tile (b, b-1): element (k, c) at c * ld + k
-    T* o = tfwd + int64_t(b) * 16384 + int64_t(c) * 128;
+  // Round 6: the same for tile (b, b-2) -- tf2_b = W_b L[b, b-2] -- so that the forward solve's primary workgroup has NO
+  // product with W_b behind x_{b-2} either: x_b = W_b (y_b - sum_{c <= b-3} L_bc x_c) - tf2_b x_{b-2} - tf_b x_{b-1}
+  for (int which = 1; which <= 2; ++which) {
+    if (b < which) break;
+    // tf_b[:, c] = W_b L[b, b-which][:, c], in two halves of the inner index k
+    const T* tile = Lb - int64_t(128 * which) * ld;  // tile (b, b-which): element (k, c) at c * ld + k
+    T* o = (which == 1 ? tfwd : tfwd2) + int64_t(b) * 16384 + int64_t(c) * 128;
     for (int h = 0; h < 2; ++h) {
       __syncthreads();
       for (int cc = 0; cc < 128; ++cc)  // column cc, rows 64h .. 64h+63: half the threads, coalesced
@@ -1663,8 +1668,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T* __restrict__ L, int64_t ld,
                                                               const T* __restrict__ winv,
                                                               const T* __restrict__ tfwd,
+                                                              const T* __restrict__ tfwd2,
                                                               const T* __restrict__ yin, T* __restrict__ x,
-                                                              int32_t* __restrict__ ticket, T* __restrict__ part) {
+                                                              int32_t* __restrict__ ticket, T* __restrict__ part,
+                                                              int G) {
   typedef T T2 __attribute__((ext_vector_type(2)));
   using bits_t = typename Sent<T>::bits_t;
   // 256 threads = one wave per SIMD (up to 512 VGPRs each): lane = 2 rows, wave = 32 columns;
@@ -1676,41 +1683,37 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
   __shared__ T sr[128];
   __shared__ T sp[128];
   // tf_b lives in LDS (128 KiB in fp64: this kernel runs one workgroup per CU anyway): loaded FIRST, long before
-  // the hop that needs it, and it costs no registers -- as a third register image next to the tile double buffer
-  // it spilled, and fetched after W_b's product its latency sat on the hop (0.53 instead of 0.45 ms at N = 16 384)
+  // the hop that needs it, and it costs no registers
   __shared__ __attribute__((aligned(16))) T sT[128 * 128];
   const int tid = threadIdx.x, rq = tid & 63;
   const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar address math
   if (tid == 0) sb = atomicAdd(ticket, 1);
   __syncthreads();
-  // Round 3 (batch 31's stamps): the dependent part of a hop -- x_{b-1} seen -> x_b published -- is 0.63 us, but a
-  // workgroup was ready for it only every OTHER hop: it must pull one 128-KiB tile through ONE CU's memory path per
-  // hop (2.3-2.8 us at the ~50 GB/s a CU reaches), and that, not the hand-off, set the 3.4 us per block.  Two
-  // workgroups per block row now share the tiles -- tickets 2b (helper: tiles b-3, b-5, ..., its partial sums handed
-  // over as a tagged granule one hop before they are needed) and 2b+1 (primary: tiles b-2, b-4, ..., then W_b, tf_b
-  // and the hop) -- so each streams a tile every second hop.
+  // G workgroups per block row, tickets in this order: G - 1 HELPERS stream the raw tiles (b, c), c <= b - 3 -- helper h the
+  // tiles c = b-3-h, b-3-h-(G-1), ... in increasing c, a tile two steps ... one step ahead in registers -- and hand their
+  // partial sums over as tagged granules; the PRIMARY streams no tile at all:
+  //   x_b = W_b (y_b - sum of the helpers) - tf2_b x_{b-2} - tf_b x_{b-1},   tf_b = W_b L[b, b-1], tf2_b = W_b L[b, b-2]
+  // (winv_kernel), all three operands requested at its START: nothing the primary waits for is ever more than one matrix-
+  // vector product and one reduction away from x_b.  Round 5 had one helper and the primary streamed every other tile: what
+  // followed the arrival of x_{b-2} -- its tile's product, the helper's hand-off, W_b's product: four L2 round trips and
+  // four barriers, 4.3 us -- had to fit into ONE hop, and the period was 2.47 us per block whatever the bandwidth (N = 16 384:
+  // 0.316 ms = 3.4 TB/s; more workgroups per row alone: slower, profiles/r06_h).
   const int tk = __builtin_amdgcn_readfirstlane(sb);
-  const int b = tk >> 1;
-  const bool helper = (tk & 1) == 0;  // (the helper's ticket first: a workgroup only ever waits for EARLIER tickets)
+  const int b = tk / G;
+  const int role = tk - b * G;
+  const int nh = G - 1;               // helpers per row
+  const bool helper = role < nh;      // (their tickets first: a workgroup only ever waits for EARLIER tickets)
+  const int64_t npad = int64_t(nblk) * 128;
   if (b >= nblk) return;
-  if (b >= 1 && !helper) {  // column j of tf_b: 64 lanes x 16 bytes = one wave transfer
-    const T* tb = tfwd + int64_t(b) * 16384 + int64_t(NC * cg) * 128 + 2 * rq;
-    T2 stage[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) stage[j] = *reinterpret_cast<const T2*>(tb + j * 128);
-#pragma unroll
-    for (int j = 0; j < NC; ++j) *reinterpret_cast<T2*>(&sT[(NC * cg + j) * 128 + 2 * rq]) = stage[j];
-  }
   // uniform (SGPR) base + one 32-bit lane offset per load: no per-load address registers
   const T* Lrow = L + int64_t(b) * 128 + int64_t(NC * cg) * ld;  // + (c*128 + j) * ld + 2 rq
-  T acc0 = 0, acc1 = 0;
-  T2 bufA[NC], bufB[NC];  // tile double buffer; W_b and tf_b take them over at the end
+  T2 bufA[NC], bufB[NC];
   auto load_tile = [&](T2 (&buf)[NC], int c) {
     const T* p = Lrow + int64_t(c) * 128 * ld;
 #pragma unroll
     for (int j = 0; j < NC; ++j) buf[j] = *reinterpret_cast<const T2*>(p + int64_t(j) * ld + 2 * rq);
   };
-  // a 128 x 128 column-major block of `base` (W_b, tf_b): this lane's 2 rows x NC columns
+  // a 128 x 128 column-major block of `base` (W_b, tf2_b): this lane's 2 rows x NC columns
   auto load_blk = [&](T2 (&buf)[NC], const T* base) {
     const T* wb = base + int64_t(b) * 16384 + int64_t(NC * cg) * 128;
 #pragma unroll
@@ -1744,117 +1747,108 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
     }
   };
   auto sum4 = [&](int i) { return (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]); };
-  auto publish = [&](T xv) {
+  auto store_tagged = [&](T* dst, T v) {
     bits_t out;
-    __builtin_memcpy(&out, &xv, sizeof(T));
+    __builtin_memcpy(&out, &v, sizeof(T));
     if (out == Sent<T>::value) out ^= 1;  // cannot happen for a computed value; keeps the protocol total
-    __hip_atomic_store(reinterpret_cast<bits_t*>(x + int64_t(b) * 128 + tid), out, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<bits_t*>(dst), out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  // next: 0 nothing, 1 tile c+2 (this workgroup's next), 2 W_b -- always issued BEFORE waiting for x_c
-  auto step = [&](int c, T2 (&cur)[NC], T2 (&nxt)[NC], int next) {
-    if (next == 1) load_tile(nxt, c + 2);
-    if (next == 2) load_blk(nxt, winv);
-    const int slot = (c >> 1) & 1;
-    wait_x(c, slot);
-    if (tid < 128) xb = (next == 1) ? load_x_bits<T>(x + int64_t(c + 2) * 128 + tid) : Sent<T>::value;
-    T a0, a1;
-    matvec(cur, &sx[slot][NC * cg], a0, a1);
-    acc0 += a0;
-    acc1 += a1;
-  };
-  // r' = y_b - (tiles 0..b-2) x; p = W_b r' (W in `wf`); then the hop: x_b = p - tf_b x_{b-1} (tf_b from LDS).
-  // Only the last product, one reduction and the store sit between x_{b-1} and x_b.
-  auto finish = [&](T2 (&wf)[NC]) {
-    if (b >= 1 && tid < 128) xb = load_x_bits<T>(x + int64_t(b - 1) * 128 + tid);  // (usually still the sentinel)
+
+  if (helper) {
+    const int last = b - 3 - role;
+    if (last < 0) return;  // (the first blocks have no tiles for every helper; the primary does not wait for those)
+    const int first = last % nh;
+    const int cnt = (last - first) / nh + 1;  // this workgroup's tiles
+    T acc0 = 0, acc1 = 0;
+    // the next tile is always requested BEFORE waiting for x_c
+    auto step = [&](int c, T2 (&cur)[NC], T2 (&nxt)[NC], bool more, int slot) {
+      if (more) load_tile(nxt, c + nh);
+      wait_x(c, slot);
+      if (tid < 128) xb = more ? load_x_bits<T>(x + int64_t(c + nh) * 128 + tid) : Sent<T>::value;
+      T a0, a1;
+      matvec(cur, &sx[slot][NC * cg], a0, a1);
+      acc0 += a0;
+      acc1 += a1;
+    };
+    load_tile(bufA, first);
+    int c = first, left = cnt;
+    for (; left >= 2; left -= 2, c += 2 * nh) {
+      step(c, bufA, bufB, true, 0);
+      step(c + nh, bufB, bufA, left > 2, 1);
+    }
+    if (left == 1) step(c, bufA, bufB, false, 0);
     red[cg][2 * rq] = acc0;
     red[cg][2 * rq + 1] = acc1;
     __syncthreads();
-    if (tid < 128) {
-      T pv = T(0);
-      if (b >= 3) {  // the helper's tiles b-3, b-5, ...: handed over one hop ago as a rule
-        bits_t pb = Sent<T>::value;
-        PollClock pclk;
-        for (long spin = 0; pb == Sent<T>::value && !pclk.expired(spin); ++spin) {
-          if (spin) __builtin_amdgcn_s_sleep(1);
-          pb = load_x_bits<T>(part + int64_t(b) * 128 + tid);
-        }
-        pv = bits_to<T>(pb);
-      }
-      sr[tid] = (yin[int64_t(b) * 128 + tid] - sum4(tid)) - pv;
-    }
-    __syncthreads();
-    T p0, p1;
-    matvec(wf, &sr[NC * cg], p0, p1);
-    red[cg][2 * rq] = p0;
-    red[cg][2 * rq + 1] = p1;
-    __syncthreads();
-    if (b == 0) {
-      if (tid < 128) publish(sum4(tid));
-      return;
-    }
-    if (tid < 128) sp[tid] = sum4(tid);
-    wait_x(b - 1, 0);  // (its barrier also separates the reads of `red` above from the writes below)
-    T q0 = 0, q1 = 0;
-    {
-      const T* tcol = &sT[(NC * cg) * 128 + 2 * rq];
-      const T* xv = &sx[0][NC * cg];
+    if (tid < 128) store_tagged(part + int64_t(role) * npad + int64_t(b) * 128 + tid, sum4(tid));
+    return;
+  }
+
+  // ---- the primary ----
+  if (b >= 1) {  // tf_b -> LDS; column j: 64 lanes x 16 bytes = one wave transfer (bufA is the staging image)
+    const T* tb = tfwd + int64_t(b) * 16384 + int64_t(NC * cg) * 128 + 2 * rq;
 #pragma unroll
-      for (int j = 0; j < NC; ++j) {
-        const T2 t2 = *reinterpret_cast<const T2*>(tcol + j * 128);
-        q0 += t2.x * xv[j];
-        q1 += t2.y * xv[j];
+    for (int j = 0; j < NC; ++j) bufA[j] = *reinterpret_cast<const T2*>(tb + j * 128);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) *reinterpret_cast<T2*>(&sT[(NC * cg + j) * 128 + 2 * rq]) = bufA[j];
+    __builtin_amdgcn_sched_barrier(0);  // (the staging image is free before the next two are requested)
+  }
+  load_blk(bufB, winv);                 // W_b
+  if (b >= 2) load_blk(bufA, tfwd2);    // tf2_b
+  if (tid < 128) {
+    const T yv = yin[int64_t(b) * 128 + tid];
+    T pv = T(0);
+    for (int h = 0; h < nh && b - 3 - h >= 0; ++h) {  // the helpers' sums, in helper order
+      bits_t pb = Sent<T>::value;
+      PollClock pclk;
+      for (long spin = 0; pb == Sent<T>::value && !pclk.expired(spin); ++spin) {
+        if (spin) __builtin_amdgcn_s_sleep(1);
+        pb = load_x_bits<T>(part + int64_t(h) * npad + int64_t(b) * 128 + tid);
       }
+      pv += bits_to<T>(pb);
     }
+    sr[tid] = yv - pv;
+    if (b >= 2) xb = load_x_bits<T>(x + int64_t(b - 2) * 128 + tid);  // (its round trip under W_b's product)
+  }
+  __syncthreads();
+  T p0, p1;
+  matvec(bufB, &sr[NC * cg], p0, p1);
+  red[cg][2 * rq] = p0;
+  red[cg][2 * rq + 1] = p1;
+  __syncthreads();
+  if (b == 0) {
+    if (tid < 128) store_tagged(x + tid, sum4(tid));
+    return;
+  }
+  if (tid < 128) sp[tid] = sum4(tid);
+  if (b >= 2) {
+    wait_x(b - 2, 1);  // (its barrier also separates the reads of `red` above from the writes below)
+    xb = Sent<T>::value;
+    if (tid < 128) xb = load_x_bits<T>(x + int64_t(b - 1) * 128 + tid);  // (usually still the sentinel)
+    T q0, q1;
+    matvec(bufA, &sx[1][NC * cg], q0, q1);
     red[cg][2 * rq] = q0;
     red[cg][2 * rq + 1] = q1;
     __syncthreads();
-    if (tid < 128) publish(sp[tid] - sum4(tid));
-  };
-  // tiles (b, 0 .. b-2) are streamed (tile (b, b-1) is inside tf_b): the primary takes c = b-2, b-4, ..., the helper
-  // c = b-3, b-5, ... -- each in INCREASING c: first = its parity's smallest index, last = b-2 resp. b-3
-  const int last = helper ? b - 3 : b - 2;
-  if (helper) {
-    if (last < 0) return;  // (blocks 0..2 have no helper tiles; the primary does not wait for them)
-  } else if (last < 0) {
-    load_blk(bufA, winv);
-    finish(bufA);
-    return;
+    if (tid < 128) sp[tid] -= sum4(tid);
   }
-  const int first = last & 1;
-  const int cnt = (last - first) / 2 + 1;  // this workgroup's tiles
-  load_tile(bufA, first);
-  int c = first, left = cnt;
-  for (; left > 2; left -= 2, c += 4) {
-    step(c, bufA, bufB, 1);
-    step(c + 2, bufB, bufA, 1);
-  }
-  const int tail_next = helper ? 0 : 2;  // the primary's last step fetches W_b into the free buffer
-  bool w_in_a;
-  if (left == 2) {
-    step(c, bufA, bufB, 1);
-    step(c + 2, bufB, bufA, tail_next);
-    w_in_a = true;
-  } else {
-    step(c, bufA, bufB, tail_next);
-    w_in_a = false;
-  }
-  if (helper) {  // partial sums of this workgroup's tiles -> part[b] (tagged like x)
-    red[cg][2 * rq] = acc0;
-    red[cg][2 * rq + 1] = acc1;
-    __syncthreads();
-    if (tid < 128) {
-      const T pv = sum4(tid);
-      bits_t out;
-      __builtin_memcpy(&out, &pv, sizeof(T));
-      if (out == Sent<T>::value) out ^= 1;
-      __hip_atomic_store(reinterpret_cast<bits_t*>(part + int64_t(b) * 128 + tid), out, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+  // the hop: x_{b-1} seen -> one product with tf_b (LDS), one reduction, the store
+  wait_x(b - 1, 0);  // (barrier: `red` is free again)
+  T q0 = 0, q1 = 0;
+  {
+    const T* tcol = &sT[(NC * cg) * 128 + 2 * rq];
+    const T* xv = &sx[0][NC * cg];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const T2 t2 = *reinterpret_cast<const T2*>(tcol + j * 128);
+      q0 += t2.x * xv[j];
+      q1 += t2.y * xv[j];
     }
-    return;
   }
-  if (w_in_a) finish(bufA);
-  else finish(bufB);
+  red[cg][2 * rq] = q0;
+  red[cg][2 * rq + 1] = q1;
+  __syncthreads();
+  if (tid < 128) store_tagged(x + int64_t(b) * 128 + tid, sp[tid] - sum4(tid));
 }
 
 // Backward substitution L^T x = z in one launch: workgroup (ticket) t owns block b = nblk-1-t, i.e.
@@ -2470,8 +2464,11 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   const bool prof_on = ctx->profile != 0 && !ctx->trace;
   std::vector<ProfSpan> spans;
   ctx->ev_used = 0;
-  hipEvent_t prof_t0 = nullptr;  // TGP_SPAN_DUMP=1 (with ctx->profile): where each trailing-update launch sits in the evaluation
-  if (prof_on && getenv("TGP_SPAN_DUMP") != nullptr) {
+  // common time base of the launch spans: their UNION (launches of the same kernel on the main and the priority stream run
+  // beside each other at large N) is what the bench divides the flops by; TGP_SPAN_DUMP=1 also prints where each launch sits
+  hipEvent_t prof_t0 = nullptr;
+  const bool span_dump = prof_on && getenv("TGP_SPAN_DUMP") != nullptr;
+  if (prof_on) {
     TGP_TRY(prof_event(ctx, &prof_t0));
     TGP_HIP_TRY(hipEventRecord(prof_t0, S0));
   }
@@ -2726,16 +2723,29 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   if (prof_on) {
     ctx->prof_syrk_ms = 0;
     ctx->prof_syrk_flops = 0;
+    ctx->prof_syrk_union_ms = 0;
     ctx->prof_syrk_launches = (int64_t)spans.size();
+    std::vector<std::pair<double, double>> iv;  // [start, end) of every launch on the common time base
     for (auto& sp : spans) {
-      float ms = 0;
+      float ms = 0, at = 0;
       TGP_HIP_TRY(hipEventElapsedTime(&ms, sp.e0, sp.e1));
+      TGP_HIP_TRY(hipEventElapsedTime(&at, prof_t0, sp.e0));
       ctx->prof_syrk_ms += ms;
       ctx->prof_syrk_flops += sp.flops;
-      if (prof_t0 != nullptr) {
-        float at = 0;
-        TGP_HIP_TRY(hipEventElapsedTime(&at, prof_t0, sp.e0));
+      iv.emplace_back(double(at), double(at) + double(ms));
+      if (span_dump)
         fprintf(stderr, "span at %8.3f ms  + %7.3f ms  %8.2f GF  %5.1f TF/s\n", at, ms, sp.flops * 1e-9, sp.flops / ms * 1e-9);
+    }
+    // length of the union of the intervals: the time during which AT LEAST ONE trailing-update launch was running
+    std::sort(iv.begin(), iv.end());
+    double hi = -1e300;
+    for (const auto& q : iv) {
+      if (q.first > hi) {
+        ctx->prof_syrk_union_ms += q.second - q.first;
+        hi = q.second;
+      } else if (q.second > hi) {
+        ctx->prof_syrk_union_ms += q.second - hi;
+        hi = q.second;
       }
     }
   }
@@ -2753,7 +2763,7 @@ int compute_winv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* winv) {
   if (n == 0) return TGP_OK;
   const int64_t sec = (n / TILE) * 16384;
   hipLaunchKernelGGL((winv_kernel<T>), dim3((unsigned)(n / TILE)), dim3(128), 0, ctx->stream, (int)(n / TILE), L, ld,
-                     winv, winv + sec, winv + 2 * sec);
+                     winv, winv + sec, winv + 2 * sec, winv + 3 * sec);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -2765,15 +2775,19 @@ int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int tra
   hipStream_t st = ctx->stream;
   const int64_t nb = n / TILE;
   if (winv != nullptr && n > 0) {  // one streaming launch (trsv_fwd_stream_kernel / trsv_bwd_stream_kernel)
-    TGP_TRY(ensure_work(ctx, 2 * size_t(n) * sizeof(T) + 1024));
+    // workgroups per block row of the forward solve (ctx option trsv_groups, 2..8; 0 = by size, measured in
+    // profiles/r06_b: N = 4 096 0.079 / 0.081 / 0.087 ms with 3 / 4 / 6, N = 16 384 0.367 / 0.288 / 0.284, N = 65 536 3.22 / 3.03 / 2.98)
+    const int G_auto = nb <= 40 ? 3 : (nb <= 256 ? 4 : 6);
+    const int G = transpose ? 2 : (ctx->trsv_groups <= 0 ? G_auto : (int)std::min<int64_t>(std::max<int64_t>(ctx->trsv_groups, 2), 8));
+    TGP_TRY(ensure_work(ctx, size_t(G) * size_t(n) * sizeof(T) + 1024));
     T* tmp = static_cast<T*>(ctx->d_work);
     int32_t* ticket = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->d_work) + size_t(n) * sizeof(T) + 64);
-    T* part = static_cast<T*>(ctx->d_work) + n + 64;  // the helpers' partial sums, n entries
+    T* part = static_cast<T*>(ctx->d_work) + n + 64;  // the helpers' partial sums, (G - 1) x n entries
     hipLaunchKernelGGL((trsv_prep_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, y, tmp, ticket,
-                       part);
+                       part, G - 1);
     if (!transpose)
-      hipLaunchKernelGGL((trsv_fwd_stream_kernel<T>), dim3((unsigned)(2 * nb)), dim3(256), 0, st, (int)nb, L, ld, winv,
-                         winv + 2 * nb * 16384, (const T*)tmp, y, ticket, part);
+      hipLaunchKernelGGL((trsv_fwd_stream_kernel<T>), dim3((unsigned)(G * nb)), dim3(256), 0, st, (int)nb, L, ld, winv,
+                         winv + 2 * nb * 16384, winv + 3 * nb * 16384, (const T*)tmp, y, ticket, part, G);
     else
       hipLaunchKernelGGL((trsv_bwd_stream_kernel<T>), dim3((unsigned)(2 * nb)), dim3(512), 0, st, (int)nb, L, ld,
                          winv + nb * 16384, (const T*)tmp, y, ticket, part);

@@ -104,6 +104,7 @@ struct tgp_ctx {
   int64_t profile = 0;
   int64_t first_split = 5;  // blocks of a panel after which its share of the next block-column update is issued early (0: off)
   int64_t stream_trsv = 1;  // forward solves on a resident factor: one streaming launch (0: one launch pair per block)
+  int64_t trsv_groups = 0;  // workgroups per block row of that launch (chol.hip, trsv_fwd_stream_kernel; 0: by size, 3 / 4 / 6)
   int64_t keep_grad_buffers = 0;  // tgp_solver_grad keeps its (N + 128) x N work matrix between calls
   int64_t first_small_tiles = 1100;  // look-ahead block-column updates up to this many tiles use 64x64 tiles
   // panel chain as ONE launch per 128-column block (panel_step_kernel: potf2 + the rows' own pending update
@@ -205,7 +206,7 @@ struct tgp_ctx {
   // profiling (option "profile"): event pairs around trailing-update launches
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
-  double prof_syrk_ms = 0, prof_syrk_flops = 0;
+  double prof_syrk_ms = 0, prof_syrk_flops = 0, prof_syrk_union_ms = 0;
   int64_t prof_syrk_launches = 0;
   int cus = 0;
   // dry run: launches and event operations are recorded here instead of being issued
