@@ -133,6 +133,9 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       the host then joins the pass with a deadline); 0: behind the whole launch -- the DEFAULT of a
  *                       context created under a counter-collecting profiler (ROCPROF_COUNTER_COLLECTION, i.e.
  *                       rocprofv3 --pmc, or TGP_SERIALIZED_KERNELS=1), which runs kernels one at a time in its own order;
+ *                       "chain_fwd_tasks" (1, round 6): the fused forward substitution (gp.py:318-320) as TASKS of the chain
+ *                       launch -- no poller and no forward-step launch at all, chain_polls then only concerns the early
+ *                       shares of the non-default schedules; 0: round 5's followers on the solve stream;
  *                       "chain_fast_update" (0): fp64 update tasks on the 4x4x4 MFMA form with LDS-direct operands
  *                       (measured slower: DESIGN 4.2);  "chain_stamps" (0): tgp_chain_stamps below;
  *                       "chain_batch" (1 = off; measured slower, csrc/tgp_common.h), "chain_batch_lag" (1), "chain_batch_rowlag" (4), "chain_batch_minrows" (32): K-BATCHED updates
@@ -506,9 +509,10 @@ int tgp_chain_task(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t tick
  * policy (batch, lag, rowlag, minrows: options chain_batch*) folded in -- the list launch_chain uploads, word for word.  out6 (or
  * NULL) takes {kind, row tile, block column, LAST source column, part, FIRST source column} per task for at most
  * cap_tasks tasks, *n_tasks the length of the list; kind 6 = update of the tile from block columns first .. last in one
- * product. */
+ * product.  fwd != 0: with the forward substitution of the launch's block columns as tasks -- kind 7 fsolve(c) (z_c =
+ * L_cc^-1 y_c), kind 8 fupdate(c, g) (rows of group g = `row tile` field below block c, 16 row tiles per group). */
 int tgp_chain_tasks(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t batch, int64_t lag, int64_t rowlag, int64_t minrows,
-                    int32_t* out6, int64_t cap_tasks, int64_t* n_tasks);
+                    int64_t fwd, int32_t* out6, int64_t cap_tasks, int64_t* n_tasks);
 
 /* ---- RCCL from the C ABI (round 5) -------------------------------------------------------------------------------
  * The block-column driver's collectives -- north_star's "RCCL broadcast of the current panel and reduce of the solve

@@ -30,13 +30,13 @@ def tasks_of(R, nblk, cb, ce):
     return tuple(tasks)
 
 
-def table_of(R, nblk, cb, ce, batch, lag, rowlag, minrows=0):
+def table_of(R, nblk, cb, ce, batch, lag, rowlag, minrows=0, fwd=0):
     """the list launch_chain uploads: (kind, i, c, last k, part, first k) per ticket"""
     lib = _ffi.lib()
     n = C.c_int64()
-    _ffi.check(lib.tgp_chain_tasks(R, nblk, cb, ce, batch, lag, rowlag, minrows, None, 0, C.byref(n)), "tgp_chain_tasks")
+    _ffi.check(lib.tgp_chain_tasks(R, nblk, cb, ce, batch, lag, rowlag, minrows, fwd, None, 0, C.byref(n)), "tgp_chain_tasks")
     out = (C.c_int32 * (6 * max(n.value, 1)))()
-    _ffi.check(lib.tgp_chain_tasks(R, nblk, cb, ce, batch, lag, rowlag, minrows, out, n.value, C.byref(n)), "tgp_chain_tasks")
+    _ffi.check(lib.tgp_chain_tasks(R, nblk, cb, ce, batch, lag, rowlag, minrows, fwd, out, n.value, C.byref(n)), "tgp_chain_tasks")
     return [tuple(out[6 * t: 6 * t + 6]) for t in range(n.value)]
 
 
@@ -217,6 +217,59 @@ def test_batches_are_staggered_over_the_steps():
     n_left = sum(1 for t in table if t[0] == 2)
     n_batched = sum(t[3] - t[5] + 1 for t in table if t[0] == 6)
     assert n_left + n_batched == n_updates and n_batched > 0.7 * n_updates  # most of the one-launch tail's updates are batched
+
+
+FWD_GROUP = 16  # CHAIN_FWD_GROUP of csrc/chain_tasks.h: row tiles per fupdate task
+
+
+@pytest.mark.parametrize("policy", [(1, 1, 2, 0), (4, 1, 4, 0)], ids=["plain", "batch4"])
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"R{r}-nblk{n}-cols{a}to{b}" for r, n, a, b in SHAPES])
+def test_forward_substitution_tasks_ride_along_and_wait_for_earlier_tickets(shape, policy):
+    """Round 6: fsolve(c) / fupdate(c, g) as tasks of the launch (kinds 7, 8).  The rest of the list is unchanged, every
+    block column of the launch has its fsolve, every row tile below c + 1 is in exactly one fupdate(c, .), and what
+    chain_kernel waits for in those tasks has an earlier ticket."""
+    R, nblk, cb, ce = shape
+    table = table_of(R, nblk, cb, ce, *policy, fwd=1)
+    assert [t for t in table if t[0] not in (7, 8)] == table_of(R, nblk, cb, ce, *policy, fwd=0)
+    at = {}
+    for n, t in enumerate(table):
+        kind, i, c, k, part, k0 = t
+        if kind in (7, 8):
+            key = (kind, c, i if kind == 8 else 0)
+            assert key not in at
+            at[key] = n
+    final = {}  # ticket that makes tile (i, c) of the launch final / factors block c
+    for n, t in enumerate(table):
+        kind, i, c, k, part, k0 = t
+        if kind == 0:
+            final[(i, c)] = n
+        elif kind == 5:
+            final[(c, c - 1)] = n
+        elif kind == 1:
+            final[(c, c)] = n
+    for c in range(cb, ce):
+        me = at[(7, c, 0)]
+        deps = [final.get((c, c))]                                  # L_cc (None: factored in front of the launch)
+        if c > cb:
+            deps.append(at[(7, c - 1, 0)])                          # z_{c-1}
+            deps.append(final.get((c, c - 1)))                      # the tile fsolve(c) applies itself
+        if c - 1 > cb:
+            deps.append(at[(8, c - 2, c // FWD_GROUP)])             # row c carries the columns cb .. c-2
+        assert all(d is None or d < me for d in deps), (c, me, deps)
+        rows = set()
+        for g in range(0, (R - 1) // FWD_GROUP + 1):
+            if (8, c, g) not in at:
+                continue
+            mine = [i for i in range(g * FWD_GROUP, min((g + 1) * FWD_GROUP, R)) if i > c + 1]
+            assert mine, "a task without rows"
+            rows |= set(mine)
+            me = at[(8, c, g)]
+            deps = [at[(7, c, 0)]] + [final[(i, c)] for i in range(c + 1, R)] + [final.get((c, c))]
+            if c > cb:
+                deps.append(at[(8, c - 1, g)])                      # column order per group
+            assert all(d is None or d < me for d in deps), (c, g, me, deps)
+        assert rows == set(range(c + 2, R))
+    assert len(at) == sum(1 for t in table if t[0] in (7, 8))
 
 
 def test_chain_task_rejects_bad_shapes():

@@ -425,6 +425,7 @@ def test_a_timed_out_hand_off_is_released_and_the_pass_repeated_on_the_per_block
     if ctx.get_option("chain_kernel") != 1:
         pytest.skip("the persistent chain is switched off")
     keep_polls = ctx.set_option("chain_polls", 3)  # followers behind stream wait-values: the mode that needs the host deadline
+    keep_fwd = ctx.set_option("chain_fwd_tasks", 0)  # (round 6's default has no followers at all: the forward steps are chain tasks)
     n = 4096
     X, y = _cases.synthetic.make_inputs(n, 1)
     k = 1.5**2 * kernels.ExpSquared(2.5)
@@ -437,6 +438,7 @@ def test_a_timed_out_hand_off_is_released_and_the_pass_repeated_on_the_per_block
     finally:
         ctx.set_option("fault_inject", 0)
         ctx.set_option("chain_polls", keep_polls)
+        ctx.set_option("chain_fwd_tasks", keep_fwd)
     np.testing.assert_allclose(got, want, rtol=LL_RTOL)
     assert ctx.get_option("timeout_retries") == before + 1
     assert ctx.get_option("chain_kernel") == 1
@@ -513,12 +515,25 @@ def test_ragged_multi_panel_sizes_against_oracle(n):
                                rtol=5e-4)
 
 
+@pytest.mark.parametrize("fwd_tasks", [1, 0], ids=["forward-steps-as-chain-tasks", "forward-steps-as-followers"])
 @pytest.mark.parametrize("n,reps", [(5000, 40), (4096, 40), (16384, 6)])
-def test_multi_stream_schedule_is_deterministic(n, reps):
+def test_multi_stream_schedule_is_deterministic(n, reps, fwd_tasks):
     """Race detector: the factorisation runs on five streams; its arithmetic has fixed
     reduction orders and no atomics, so repeated fused evaluations of the same inputs must
     be BIT-identical.  A missing stream dependency shows up as an occasional different bit
-    pattern (scripts/stress_determinism.py is the long version)."""
+    pattern (scripts/stress_determinism.py is the long version).  Round 6: with the forward substitution as tasks of
+    the chain launches (the default: per-group column order, tests/test_chain_tasks.py) and as round 5's followers."""
+    from tinygp_amd import _ffi
+
+    ctx = _ffi.default_ctx()
+    keep = ctx.set_option("chain_fwd_tasks", fwd_tasks)
+    try:
+        _deterministic_evaluations(n, reps)
+    finally:
+        ctx.set_option("chain_fwd_tasks", keep)
+
+
+def _deterministic_evaluations(n, reps):
     X, y = _cases.synthetic.make_inputs(n, 1)
     ks = [1.5**2 * kernels.ExpSquared(2.5), 1.4**2 * kernels.ExpSquared(2.2)]
     solver = DirectSolver(ks[0], X, noise.Diagonal(np.full(n, 0.01)))

@@ -138,6 +138,12 @@ def chain_column_accesses(rec, c):
     for cc in range(c + 1, nblk):
         for i in range(cc, rows):
             R.add(("A", t0 + i, t0 + cc)); W.add(("A", t0 + i, t0 + cc))
+    if len(v) > 6 and v[6]:  # round 6: the forward substitution of block column c rides along as tasks of the launch
+        R.add(("Y", t0 + c)); W.add(("Y", t0 + c))
+        if t0 + c > 0:  # fsolve(c) applies tile (c, c-1) -- for a panel's first block the previous panel's last column
+            R.add(("A", t0 + c, t0 + c - 1)); R.add(("Y", t0 + c - 1))
+        for i in range(c + 1, rows):
+            R.add(("Y", t0 + i)); W.add(("Y", t0 + i))
     return R, W
 
 
@@ -264,9 +270,13 @@ CONFIGS = [
     (5120, 512, 1, 3, 1100, 3, 0, dict(chain_kernel=1, chain_full_rows=2048)),
     (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_full_rows=8192)),
     (16384, 1024, 1, 5, 1100, 2, 0, dict(chain_kernel=1, chain_full_rows=0)),
+    # ... round 5's followers (forward steps as launches behind pollers) are still there: chain_fwd_tasks = 0
+    (5120, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_fwd_tasks=0)),
+    (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_fwd_tasks=0)),
+    (5120, 1024, 0, 5, 1100, 3, 0, dict(chain_kernel=1, chain_fwd_tasks=0, chain_full_rows=0)),
     # ... and without pollers (forward steps and early shares behind the whole launch)
-    (5120, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0)),
-    (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0)),
+    (5120, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0, chain_fwd_tasks=0)),
+    (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0, chain_fwd_tasks=0)),
     (16384, 1024, 0, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0)),
 ]
 
@@ -301,7 +311,14 @@ def test_schedule_has_no_data_race(cfg):
         assert not any(r[0] == 10 for r in recs)
     else:
         assert not any(r[0] == 2 for r in recs)  # every trsm of the chain rides in a panel step
-    if cfg[5] & 1:
+    in_chain = len(cfg) > 7 and cfg[7].get("chain_kernel") and cfg[7].get("chain_fwd_tasks", 1)
+    if cfg[5] & 1 and in_chain:
+        # round 6: the forward substitution rides in the chain launches as tasks -- no step launch, no poller for it
+        assert not any(r[0] == 4 for r in recs)
+        assert all(r[8] == 1 for r in recs if r[0] == 11)
+        if cfg[7].get("chain_depth2", 1) and cfg[2]:
+            assert not any(r[0] == 12 for r in recs)  # (the default schedule has no early shares either)
+    elif cfg[5] & 1:
         assert sum(1 for r in recs if r[0] == 4) == T  # one forward-substitution step per block
     assert find_races(recs, T) == []
 
@@ -335,7 +352,7 @@ def test_checker_sees_a_missing_poll_of_the_persistent_chain():
     update start behind a one-wave poll of block column j's count of final tiles while the launch still runs.
     Without the polls (or without the event that keeps a poller behind the zeroing of the counters, or the one that
     keeps the next launch's zeroing behind the last poller) the checker must report the race / refuse the order."""
-    recs = trace(5120, 1024, 1, 5, 1100, 3, 0, chain_kernel=1, chain_full_rows=0)
+    recs = trace(5120, 1024, 1, 5, 1100, 3, 0, chain_kernel=1, chain_full_rows=0, chain_fwd_tasks=0)
     T = 5120 // 128
     assert find_races(recs, T) == []
     polls = [r for r in recs if r[0] == 12]

@@ -101,7 +101,7 @@ SIGNATURES = {
     "tgp_trace_factor": [_i64, C.c_char_p, _i32, _pi64, _i64, _pi64],
     "tgp_chain_stamps": [_vp, _pi64, _i64, _pi64],
     "tgp_chain_task": [_i64, _i64, _i64, _i64, _i64, _pi32, _pi64],
-    "tgp_chain_tasks": [_i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _pi32, _i64, _pi64],
+    "tgp_chain_tasks": [_i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _pi32, _i64, _pi64],
     "tgp_tile_order": [_i64, _i64, _i32, _i32, _i64, _pi32, _pi32, _pi64],
     "tgp_dist_slot_elems": [_i64, _i64],
     "tgp_dist_create": [_vp, _int, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _pvp],
@@ -305,7 +305,7 @@ class Ctx:
         return old.value
 
     # the options that shape the factorisation's schedule (tgp_trace_factor takes the same names)
-    SCHEDULE_OPTIONS = ("nb_outer", "lookahead", "first_split", "first_small_tiles", "nb_wide_rows", "fused_step", "chain_kernel", "chain_fast_update", "chain_batch", "chain_batch_lag", "chain_batch_rowlag", "chain_batch_minrows", "tile_band", "chain_full_rows", "chain_lds_pad", "chain_depth2", "chain_pre_wait", "chain_polls",
+    SCHEDULE_OPTIONS = ("nb_outer", "lookahead", "first_split", "first_small_tiles", "nb_wide_rows", "fused_step", "chain_kernel", "chain_fast_update", "chain_batch", "chain_batch_lag", "chain_batch_rowlag", "chain_batch_minrows", "tile_band", "chain_full_rows", "chain_lds_pad", "chain_depth2", "chain_pre_wait", "chain_polls", "chain_fwd_tasks",
                         "gate_split", "chain_reserve", "reserve_max_tiles", "sub_panel", "sub_panel_min_rows",
                         "nb_first", "split_tail", "solve_on_update")
 

@@ -215,8 +215,8 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipMemset(ctx->d_step_flag, 0, 64));
   TGP_HIP_TRY(hipMalloc(&ctx->d_chain_flags, size_t(tgp::CHAIN_MAX_ROW_TILES) * 64 * sizeof(uint32_t)));
   TGP_HIP_TRY(hipMemset(ctx->d_chain_flags, 0, size_t(tgp::CHAIN_MAX_ROW_TILES) * 64 * sizeof(uint32_t)));
-  TGP_HIP_TRY(hipMalloc(&ctx->d_chain_ticket, 1024));
-  TGP_HIP_TRY(hipMemset(ctx->d_chain_ticket, 0, 1024));
+  TGP_HIP_TRY(hipMalloc(&ctx->d_chain_ticket, 4096));  // (CHAIN_TICKET_WORDS of chol.hip: 544 words)
+  TGP_HIP_TRY(hipMemset(ctx->d_chain_ticket, 0, 4096));
   hipDeviceProp_t prop;
   TGP_HIP_TRY(hipGetDeviceProperties(&prop, device));
   ctx->cus = prop.multiProcessorCount;
@@ -299,6 +299,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "chain_depth2")) return &ctx->chain_depth2;
   if (!strcmp(key, "chain_pre_wait")) return &ctx->chain_pre_wait;
   if (!strcmp(key, "chain_polls")) return &ctx->chain_polls;
+  if (!strcmp(key, "chain_fwd_tasks")) return &ctx->chain_fwd_tasks;
   if (!strcmp(key, "chain_fast_update")) return &ctx->chain_fast_update;
   if (!strcmp(key, "chain_batch")) return &ctx->chain_batch;
   if (!strcmp(key, "chain_batch_lag")) return &ctx->chain_batch_lag;
@@ -1244,13 +1245,13 @@ int tgp_chain_task(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t tick
 }
 
 int tgp_chain_tasks(int64_t R, int64_t nblk, int64_t cb, int64_t ce, int64_t batch, int64_t lag, int64_t rowlag, int64_t minrows,
-                    int32_t* out6, int64_t cap_tasks, int64_t* n_tasks) {
+                    int64_t fwd, int32_t* out6, int64_t cap_tasks, int64_t* n_tasks) {
   if (!(R >= 1 && cb >= 0 && cb < ce && ce <= nblk && nblk <= 64 && nblk <= R && R <= tgp::CHAIN_MAX_ROW_TILES) ||
       !(batch >= 0 && batch <= 32 && lag >= 1 && rowlag >= 2 && minrows >= 0) || n_tasks == nullptr || cap_tasks < 0) {
     tgp::set_error("tgp_chain_tasks: bad panel shape or policy");
     return TGP_E_ARG;
   }
-  const std::vector<ChainTask> list = chain_build((int)R, (int)nblk, (int)cb, (int)ce, ChainPolicy{(int)batch, (int)lag, (int)rowlag, (int)minrows});
+  const std::vector<ChainTask> list = chain_build((int)R, (int)nblk, (int)cb, (int)ce, ChainPolicy{(int)batch, (int)lag, (int)rowlag, (int)minrows}, fwd != 0 ? 1 : 0);
   *n_tasks = (int64_t)list.size();
   for (int64_t u = 0; out6 != nullptr && u < (int64_t)list.size() && u < cap_tasks; ++u) {
     const ChainTask t = chain_unpack(chain_pack(list[size_t(u)]));  // through the table's packing: what the kernel sees

@@ -15,7 +15,8 @@
 struct ChainTask {
   int kind;  // 0 solve(i, c) | 1 diag(c) | 2 update(i, c, k) | 3 update of the diagonal tile (c, c) from column k |
              // 4 one of CHAIN_CRIT_PARTS parts (`part`) of update(i, c, k) | 5 xsolve(c): the streamed solve of tile (c, c-1) |
-             // 6 update(i, c, [k0, k]): ONE product over block columns k0 .. k (K = 128 (k - k0 + 1)), ChainPolicy | -1 none
+             // 6 update(i, c, [k0, k]): ONE product over block columns k0 .. k (K = 128 (k - k0 + 1)), ChainPolicy |
+             // 7 fsolve(c): z_c = L_cc^-1 y_c | 8 fupdate(c, g): y_i -= X_ic z_c for the row tiles i > c of group g = `i` | -1 none
   int i, c, k, part;
   int k0;    // kind 6: first block column of the batch (else = k)
 };
@@ -54,13 +55,34 @@ constexpr int CHAIN_CRIT_PARTS = 8;  // workgroups that share the update of tile
 // N = 4 096 -- although they need none of them; the stamped timeline showed xsolve / diag starting 15-37 us late and the
 // first ~11 blocks of a 32-block launch at 45-65 us per block instead of 36.  Everything a task of the lane waits for has
 // an earlier ticket in this order too (tests/test_chain_tasks.py checks every wait of every task of a launch).
+// FORWARD SUBSTITUTION AS TASKS (round 6).  The fused log_probability needs z = L^-1 y; until round 5
+// step c of it -- z_c = L_cc^-1 y_c, y_i -= X_ic z_c below -- was a pair of small launches on the solve stream behind a
+// one-wave POLL kernel that watched block column c of the running chain launch (128 pollers + 255 launches per evaluation
+// at N = 16 384).  Now it is part of the launch:
+//   F(c) = fsolve(c), fupdate(c, g) for every group g of `gs` row tiles that holds rows below c + 1
+// handed out at the END of step c (behind its bulk: nobody waits for z but the next F).
+//   fsolve(c)     y_c -= X_{c,c-1} z_{c-1} (the ONE tile between z_{c-1} and z_c: the dependent chain of the substitution is
+//                 a tile product and a 128 x 128 solve per block, ~10 us against the factorisation's 36), then z_c = L_cc^-1 y_c;
+//                 waits for L_cc, z_{c-1} and for row c to carry the columns before c - 1;
+//   fupdate(c, g) y_i -= X_ic z_c for the rows i > c + 1 of group g; waits for z_c, for block column c to be final and for
+//                 fupdate(c-1, g) -- the updates of a row arrive in COLUMN ORDER whatever runs where: the sums are fixed.
+// (Row c + 1 of the LAST block column of a panel belongs to the next panel's launch: its fsolve(0) applies that tile.)
 struct ChainLaunch {
   int R, nblk, cb, ce;
   int lane;  // 1: the next step's whole diagonal lane in front of the bulk; 0: its two diagonal tasks only
+  int fwd;   // 1: the forward substitution of the launch's block columns rides along as tasks (kinds 7, 8)
+  int gs;    // row tiles per fupdate task
 };
-CHAIN_HD inline ChainLaunch chain_launch(int R, int nblk, int cb, int ce) {
-  ChainLaunch q = {R, nblk, cb, ce, nblk == R ? 1 : 0};
+constexpr int CHAIN_FWD_GROUP = 16;
+CHAIN_HD inline ChainLaunch chain_launch(int R, int nblk, int cb, int ce, int fwd = 0, int gs = CHAIN_FWD_GROUP) {
+  ChainLaunch q = {R, nblk, cb, ce, nblk == R ? 1 : 0, fwd, gs};
   return q;
+}
+// groups of row tiles with a row below k + 1: (k+2) / gs .. (R-1) / gs
+CHAIN_HD inline int chain_fwd_g0(const ChainLaunch& q, int k) { return (k + 2) / q.gs; }
+CHAIN_HD inline int chain_n_F(const ChainLaunch& q, int k) {
+  if (!q.fwd || k < q.cb || k >= q.ce) return 0;
+  return 1 + (k + 2 <= q.R - 1 ? (q.R - 1) / q.gs - chain_fwd_g0(q, k) + 1 : 0);
 }
 CHAIN_HD inline bool chain_factored(const ChainLaunch& q, int j) { return j > q.cb && j < q.ce; }  // DG(j) exists
 CHAIN_HD inline int chain_solve_r0(const ChainLaunch& q, int k) { return chain_factored(q, k + 1) ? k + 2 : k + 1; }
@@ -146,6 +168,11 @@ inline int64_t chain_walk(const ChainLaunch& q, int64_t t, ChainTask* out, Chain
       u -= cnt;
     }
   };
+  auto fwd = [&](int k, int u) {
+    task.c = k;
+    if (u == 0) { task.kind = 7; }
+    else { task.kind = 8; task.i = chain_fwd_g0(q, k) + u - 1; }
+  };
   if (q.cb > 0) CHAIN_GROUP(1, { task.kind = 1; task.c = q.cb; });
   const int k0 = q.cb;
   if (chain_factored(q, k0 + 1)) CHAIN_GROUP(2, dg(k0 + 1, u));
@@ -157,6 +184,7 @@ inline int64_t chain_walk(const ChainLaunch& q, int64_t t, ChainTask* out, Chain
       CHAIN_GROUP(chain_n_D(q, k), dtile(k));
       if (chain_factored(q, k + 2)) CHAIN_GROUP(2, dg(k + 2, u));
       CHAIN_GROUP(chain_n_bulk(q, k), bulk(k, u));
+      CHAIN_GROUP(chain_n_F(q, k), fwd(k, u));
     }
     return seen;
   }
@@ -174,6 +202,7 @@ inline int64_t chain_walk(const ChainLaunch& q, int64_t t, ChainTask* out, Chain
     }
     if (chain_factored(q, k + 3)) CHAIN_GROUP(2, dg(k + 3, u));
     CHAIN_GROUP(chain_n_bulk(q, k), bulk(k, u));
+    CHAIN_GROUP(chain_n_F(q, k), fwd(k, u));
   }
 #undef CHAIN_GROUP
 #undef CHAIN_EMIT_ALL
@@ -234,8 +263,9 @@ CHAIN_HD inline bool chain_batch_of(const ChainLaunch& q, const ChainPolicy& p, 
 }
 
 // the launch's task list in ticket order, batches folded in (host)
-inline std::vector<ChainTask> chain_build(int R, int nblk, int cb, int ce, const ChainPolicy& p) {
-  const ChainLaunch q = chain_launch(R, nblk, cb, ce);
+inline std::vector<ChainTask> chain_build(int R, int nblk, int cb, int ce, const ChainPolicy& p, int fwd = 0,
+                                          int gs = CHAIN_FWD_GROUP) {
+  const ChainLaunch q = chain_launch(R, nblk, cb, ce, fwd, gs);
   std::vector<ChainTask> all, out;
   chain_walk(q, -1, nullptr, &all);
   out.reserve(all.size());

@@ -447,7 +447,9 @@ constexpr uint32_t CHAIN_FINAL = 127;
 constexpr int CHAIN_COLCNT_OFF = 16;  // d_chain_ticket: [0] the ticket counter, [16 + c] final tiles of block column c,
 constexpr int CHAIN_QCNT_OFF = 96;    // [96 + k] finished parts of the update of tile (k+2, k+1) from column k
 constexpr int CHAIN_XSTEP_OFF = 160;  // [160 + c] column blocks of X_{c,c-1} complete in memory (0..8): xsolve(c) -> diag(c)
-constexpr int CHAIN_TICKET_WORDS = CHAIN_XSTEP_OFF + CHAIN_FLAG_LD;
+constexpr int CHAIN_ZFLAG_OFF = 224;   // [224 + c] z_c = L_cc^-1 y_c is in memory (forward substitution as tasks: fsolve -> fupdate)
+constexpr int CHAIN_YSTATE_OFF = 288;  // [288 + g] block columns of this launch applied to the rows of group g of y
+constexpr int CHAIN_TICKET_WORDS = CHAIN_YSTATE_OFF + int(CHAIN_MAX_ROW_TILES) / CHAIN_FWD_GROUP;
 
 template <typename T>
 struct ChainArgs {
@@ -467,6 +469,9 @@ struct ChainArgs {
   int32_t launch;
   int32_t fast_update;  // fp64 whole-tile updates on the 4x4x4 MFMA form, LDS-direct operands (chain_update_fast)
   const uint64_t* tasks;  // the launch's task list in ticket order, one packed word per task (chain_tasks.h, chain_pack)
+  T* y;                   // forward substitution as tasks: the right-hand side's rows from the panel's first row on (or NULL)
+  int32_t fgs;            // row tiles per fupdate task
+  int32_t fprev;          // rows / columns in FRONT of the panel exist: fsolve(0) applies tile (0, -1) of the previous panel
 };
 
 // all threads; wave 0 polls up to three state words (lane l: word f[l] == v[l]; NULL: nothing to wait for),
@@ -1161,6 +1166,133 @@ __device__ __forceinline__ void chain_fold_stream(const ChainArgs<T>& q, T* S, i
   }
 }
 
+// ---- forward substitution as tasks (round 6; chain_tasks.h, F(c)) --------------------------------------------------
+// all threads; wave 0 polls up to three words -- lane 0: *p0 >= want0, lane 1: *p1 == want1, lane 2: *p2 >= want2 (NULL:
+// nothing to wait for) --, one acquire, barrier
+__device__ __forceinline__ void chain_wait_counts(const int32_t* p0, int want0, const int32_t* p1, int want1,
+                                                  const int32_t* p2, int want2, int32_t* info) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const int32_t* f = lane == 0 ? p0 : (lane == 1 ? p1 : (lane == 2 ? p2 : nullptr));
+    const int want = lane == 0 ? want0 : (lane == 1 ? want1 : want2);
+    auto ready = [&]() {
+      const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return lane == 1 ? v == want : v >= want;
+    };
+    bool ok = f == nullptr || ready();
+    int spin = 0;
+    PollClock clk;
+    while (!__all(ok)) {
+      __builtin_amdgcn_s_sleep(4);
+      if (!ok) ok = ready();
+      bool dead = false;
+      if ((spin & 255) == 255 && lane == 0) dead = clk.expired(spin) || poisoned(info);
+      ++spin;
+      if (__any(dead)) {
+        if (lane == 0) atomicExch(info, STEP_TIMEOUT);
+        break;
+      }
+    }
+    if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+// fsolve(c): y_c -= X_{c,c-1} z_{c-1} (`prev`), then y_c <- L_cc^-1 y_c -- the arithmetic of trsv_diag_fwd_kernel: 16-column
+// sub-steps with the 16 x 16 inverses from `dinv`.  Threads 0..127 own a row each, the others only meet the barriers.
+// Stored write-through.
+template <typename T>
+__device__ __forceinline__ void chain_fsolve(const ChainArgs<T>& q, T* S, int c, bool prev) {
+  const int r = threadIdx.x, rb = (r >> 4) & 7, rl = r & 15;
+  const bool act = r < 128;
+  const int64_t ld = q.ld;
+  const T* Lkk = q.A0 + int64_t(c) * TILE * ld + int64_t(c) * TILE;
+  const T* dinv = q.dinv + int64_t(c) * 2048;
+  T* y = q.y + int64_t(c) * TILE;
+  T* st = S;        // [128]
+  T* sx = S + 128;  // [16]
+  T* sz = S + 256;  // [128] z_{c-1}
+  T t = act ? y[r] : T(0);
+  if (prev) {
+    if (act) sz[r] = y[r - TILE];
+    __syncthreads();
+    if (act) {
+      const T* Xp = Lkk - int64_t(TILE) * ld + r;  // tile (c, c-1): row r
+      T a0 = 0, a1 = 0;
+#pragma unroll 1
+      for (int j0 = 0; j0 < TILE; j0 += 16) {
+        T v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = Xp[int64_t(j0 + j) * ld];
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+          a0 += v[j] * sz[j0 + j];
+          a1 += v[j + 1] * sz[j0 + j + 1];
+        }
+      }
+      t -= a0 + a1;
+    }
+  }
+  T di[16];
+#pragma unroll
+  for (int qq = 0; qq < 16; ++qq) di[qq] = act ? dinv[rb * 256 + qq * 16 + rl] : T(0);
+#pragma unroll 1
+  for (int jb = 0; jb < 8; ++jb) {
+    T cur[16];  // this row's entries of column block jb (requested before the barriers that publish x_jb)
+    const bool below = act && rb > jb;
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) cur[qq] = below ? Lkk[int64_t(jb * 16 + qq) * ld + r] : T(0);
+    if (act) st[r] = t;
+    __syncthreads();
+    if (act && rb == jb) {
+      T x = 0;
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) x += di[qq] * st[jb * 16 + qq];
+      sx[rl] = x;
+      t = x;
+    }
+    __syncthreads();
+    if (below) {
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) t -= cur[qq] * sx[qq];
+    }
+  }
+  if (act) st_agent(y + r, t);
+}
+
+// fupdate(c, g): y_i -= X_ic z_c for the row tiles i > c + 1 of group g (`fgs` tiles; row c + 1 is fsolve(c + 1)'s): wave w
+// takes tiles lo + w, lo + w + 8, ...; lane = two rows, 16 loads of 16 bytes per lane in flight; z_c in LDS
+template <typename T>
+__device__ __forceinline__ void chain_fupdate(const ChainArgs<T>& q, T* S, int c, int g) {
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ld = q.ld;
+  T* z = S;  // [128]
+  if (tid < 128) z[tid] = q.y[int64_t(c) * TILE + tid];
+  __syncthreads();
+  const int lo = g * q.fgs > c + 2 ? g * q.fgs : c + 2;
+  const int hi = (g + 1) * q.fgs < q.R ? (g + 1) * q.fgs : q.R;
+  for (int i = lo + w; i < hi; i += 8) {
+    const T* Lic = q.A0 + int64_t(c) * TILE * ld + int64_t(i) * TILE + 2 * lane;
+    T a0 = 0, a1 = 0;
+#pragma unroll 1
+    for (int j0 = 0; j0 < TILE; j0 += 16) {
+      T2 v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const T2*>(Lic + int64_t(j0 + j) * ld);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        a0 += v[j].x * z[j0 + j];
+        a1 += v[j].y * z[j0 + j];
+      }
+    }
+    T* yi = q.y + int64_t(i) * TILE + 2 * lane;
+    st_agent(yi, T(yi[0] - a0));
+    st_agent(yi + 1, T(yi[1] - a1));
+  }
+}
+
 // One task per workgroup (grid = number of tasks): a task loop inside the kernel lets the compiler hoist the
 // lane-derived values of every phase across the whole loop body -- 100+ spilled VGPRs under the 128-register cap
 // that keeps two chain workgroups on a CU beside the trailing update.  Tickets are taken at workgroup start, so
@@ -1192,7 +1324,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(CHAIN_WAVES
   const int ti = __builtin_amdgcn_readfirstlane(s_task[1]);
   const int tc = __builtin_amdgcn_readfirstlane(s_task[2]);
   const int tk = __builtin_amdgcn_readfirstlane(s_task[3]);
-  if (kind > 6) return;
+  if (kind > 8) return;
   long long* st = nullptr;
   if (q.stamps != nullptr) {  // {kind, row tile, block column, launch | update column << 8, stamps ...}
     st = q.stamps + int64_t(__builtin_amdgcn_readfirstlane(s_task[4])) * 16;
@@ -1204,6 +1336,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(CHAIN_WAVES
   }
   const uint32_t E = q.epoch32;
   const bool head_final = q.cb == 0;  // L_00 was factored in front of the launch
+  if (kind == 7) {  // ---- fsolve(c): y_c -= X_{c,c-1} z_{c-1}, z_c = L_cc^-1 y_c ----
+    const int c = tc;
+    const int g = c / q.fgs;
+    const bool prev = c > 0 || q.fprev != 0;  // (a panel's first block: the previous panel's last column, complete)
+    // row c carries the columns cb .. c-2 of this launch (fupdate(c-2, g) was the last of them); L_cc (a panel's first block is
+    // factored in front of the launch); z_{c-1} when this launch solves it
+    chain_wait_counts(c - 1 > q.cb ? q.ticket + CHAIN_YSTATE_OFF + g : nullptr, c - 1 - q.cb,
+                      (c == 0 && head_final) ? nullptr : reinterpret_cast<const int32_t*>(q.flags + c * CHAIN_FLAG_LD + c),
+                      int32_t(E + CHAIN_FINAL), c > q.cb ? q.ticket + CHAIN_ZFLAG_OFF + (c - 1) : nullptr, 1, q.info);
+    chain_stamp(st, 1);
+    chain_fsolve<T>(q, S, c, prev);
+    chain_stamp(st, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(q.ticket + CHAIN_ZFLAG_OFF + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    chain_stamp(st, 3);
+    return;
+  }
+  if (kind == 8) {  // ---- fupdate(c, g): y_i -= X_ic z_c, rows of group g below block c ----
+    const int c = tc, g = ti;
+    // block column c final (every tile below the diagonal solved: R - c - 1 of them, + the diagonal tile when this launch
+    // factored it), z_c in memory, the group carries the columns before c
+    const int target = q.R - c - ((c == 0 && head_final) ? 1 : 0);
+    chain_wait_counts(q.ticket + CHAIN_COLCNT_OFF + c, target, q.ticket + CHAIN_ZFLAG_OFF + c, 1,
+                      c > q.cb ? q.ticket + CHAIN_YSTATE_OFF + g : nullptr, c - q.cb, q.info);  // (== c - cb: >= is the same here)
+    chain_stamp(st, 1);
+    chain_fupdate<T>(q, S, c, g);
+    chain_stamp(st, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(q.ticket + CHAIN_YSTATE_OFF + g, c - q.cb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    chain_stamp(st, 3);
+    return;
+  }
   if constexpr (sizeof(T) == 8) {
     if (kind == 6) {  // ---- update(i, c, [k0, k]): the batched form (fp64 only: the policy is off for fp32) ----
       const int i = ti, c = tc, k = tk, k0 = __builtin_amdgcn_readfirstlane(s_task[6]);
@@ -2135,7 +2302,7 @@ ChainPolicy chain_policy(const tgp_ctx* ctx) {
 // the matrix; dinv0 = the inverses of the panel's first block).  head_done: L_cb,cb is already factored.
 template <typename T>
 int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int64_t pivot_base, int64_t R,
-                 int64_t nblk, int64_t cb, int64_t ce, bool head_done, hipEvent_t counters_ready) {
+                 int64_t nblk, int64_t cb, int64_t ce, bool head_done, hipEvent_t counters_ready, T* y0, bool fprev) {
   TGP_ARG_CHECK(R >= 1 && R <= CHAIN_MAX_ROW_TILES && cb >= 0 && cb < ce && ce <= nblk && nblk <= CHAIN_FLAG_LD && nblk <= R,
                 "chain: bad panel shape (R=%lld, columns [%lld, %lld))", (long long)R, (long long)cb, (long long)ce);
   // a panel's first block has no in-panel update pending: plain potf2 in front of the launch (in the look-ahead
@@ -2151,16 +2318,17 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
   }
   if (ctx->trace) {  // v: panel origin offset, ld, row tiles, first / end block column
     if (counters_ready != nullptr) TGP_TRY(ev_record(ctx, counters_ready, st));
-    trace_push(ctx, 11, st, trace_off(ctx, A0), ld, R, cb, ce, nblk);
+    trace_push(ctx, 11, st, trace_off(ctx, A0), ld, R, cb, ce, nblk, y0 != nullptr ? 1 : 0);
     return TGP_OK;
   }
   // the launch's task list (chain_tasks.h: ticket order + K-batched updates), one table per shape and policy, kept on the
   // device for the life of the context (13 shapes per evaluation at c2, the same in every evaluation)
   const ChainPolicy pol = chain_policy<T>(ctx);
-  const std::array<int64_t, 8> key = {R, nblk, cb, ce, pol.batch, pol.lag, pol.rowlag, pol.minrows};
+  const int fwd = y0 != nullptr ? 1 : 0;  // the forward substitution of these block columns as tasks of the launch
+  const std::array<int64_t, 9> key = {R, nblk, cb, ce, pol.batch, pol.lag, pol.rowlag, pol.minrows, fwd};
   auto found = ctx->chain_tables.find(key);
   if (found == ctx->chain_tables.end()) {
-    const std::vector<ChainTask> list = chain_build((int)R, (int)nblk, (int)cb, (int)ce, pol);
+    const std::vector<ChainTask> list = chain_build((int)R, (int)nblk, (int)cb, (int)ce, pol, fwd, CHAIN_FWD_GROUP);
     tgp_ctx::ChainTable tab;
     tab.count = (int64_t)list.size();
     if (tab.count > 0) {
@@ -2189,6 +2357,9 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
   q.launch = (int32_t)ctx->chain_launches++;
   q.fast_update = (int32_t)ctx->chain_fast_update;
   q.tasks = found->second.dev;
+  q.y = y0;
+  q.fgs = CHAIN_FWD_GROUP;
+  q.fprev = fprev ? 1 : 0;
   if (ctx->chain_stamps != 0 && ctx->chain_stamp_base + tasks <= CHAIN_STAMP_TASKS) {
     if (ctx->d_chain_stamps == nullptr)
       TGP_HIP_TRY(hipMalloc((void**)&ctx->d_chain_stamps, size_t(CHAIN_STAMP_TASKS) * 16 * sizeof(long long)));
@@ -2324,20 +2495,24 @@ int panel_chain(tgp_ctx* ctx, hipStream_t st, int64_t n, T* A, int64_t ld, T* di
     // of 0.62 of peak, the evaluation took 30.5 instead of 27.4 ms; the launch gaps put the chain on the critical path.)
     // (as in the per-block path: the early share exists when rows AND columns are left behind block after_blocks-1)
     const bool mid_in = after_blocks > cb && after_blocks <= ce && after_blocks < nblk && R > after_blocks;
-    const bool follow = y != nullptr || mid_in;
+    // Round 6: the forward-substitution steps of these block columns are TASKS of the launch (chain_tasks.h, F(c)) -- no
+    // poller, no per-block launch pair on the solve stream (ctx option chain_fwd_tasks = 0: round 5's followers)
+    const bool fwd_in = y != nullptr && ctx->chain_fwd_tasks != 0;
+    T* y_follow = fwd_in ? (T*)nullptr : y;
+    const bool follow = y_follow != nullptr || mid_in;
     const bool polls = follow && ctx->chain_polls != 0;
     // (ev_d is recorded between the launch's memset and the kernel: the pollers wait for the zeroed counters only;
     // without pollers -- chain_polls = 0 -- it is recorded BEHIND the kernel and the followers wait for the whole launch)
     TGP_TRY(launch_chain<T>(ctx, st, A0, ld, d0, pivot_off + k0, R, nblk, cb, ce, head_done && cb == 0,
-                            polls ? ctx->ev_d : (hipEvent_t) nullptr));
+                            polls ? ctx->ev_d : (hipEvent_t) nullptr, fwd_in ? y + k0 : (T*)nullptr, k0 > 0));
     if (follow && !polls) TGP_TRY(ev_record(ctx, ctx->ev_d, st));
     if (follow) TGP_TRY(st_wait(ctx, S2, ctx->ev_d));
     for (int64_t c = cb; c < ce && follow; ++c) {
       const int64_t j0 = k0 + c * TILE;
       const bool mid_here = mid_in && c + 1 == after_blocks;
-      if (y == nullptr && !mid_here) continue;
+      if (y_follow == nullptr && !mid_here) continue;
       if (polls) TGP_TRY(launch_chain_poll(ctx, S2, A0, ld, R, c, cb == 0));
-      if (y != nullptr)
+      if (y_follow != nullptr)
         TGP_TRY(launch_trsv_fwd_step<T>(ctx, S2, n - (j0 + TILE), A + j0 * ld + j0, ld, dinv + (j0 / TILE) * 2048,
                                         y + j0));
       if (mid_here) {

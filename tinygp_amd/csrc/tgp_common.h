@@ -155,7 +155,7 @@ struct tgp_ctx {
     uint64_t* dev = nullptr;
     int64_t count = 0;
   };
-  std::map<std::array<int64_t, 8>, ChainTable> chain_tables;
+  std::map<std::array<int64_t, 9>, ChainTable> chain_tables;
   int64_t chain_full_rows = 4096;     // with at most this many rows left the WHOLE rest is one chain launch (measured
                                       // at N = 16 384: 4096 26.6 ms, 6144 26.9, 8192 27.6; per-block chain 28.2)
   int64_t chain_depth2 = 1;           // gate + chain of the next panel on the priority stream, two panels ahead
@@ -168,6 +168,9 @@ struct tgp_ctx {
   // it (the runtime's own one-wave wait kernel: as fast, no timeout -- measured, not the default); 0: they wait for the
   // whole launch (the default under a counter-collecting profiler, which runs kernels one at a time in its own order)
   int64_t chain_polls = 1;
+  // Round 6: the fused forward substitution as TASKS of the chain launch (chain_tasks.h F(c), chol.hip chain_fsolve /
+  // chain_fupdate): no poller, no forward-step launch at all.  0: round 5's followers on the solve stream (chain_polls)
+  int64_t chain_fwd_tasks = 1;
   bool wait_values_inflight = false;  // this factorisation enqueued stream wait-values: join with a deadline (join_bounded)
   // tile order of the MFMA products (tile_order.h): bands of this many tile rows, column by column inside a band; 0 = column
   // by column over all rows (rounds 1-4).  Round 5, measured at c2 (profiles/r05_j, r05_k): fabric traffic of a
@@ -338,7 +341,8 @@ constexpr int64_t CHAIN_STAMP_TASKS = 32768;
 // persistent chain over block columns [cb, ce) of the panel at A0 (R row tiles, nblk block columns; chol.hip)
 template <typename T>
 int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int64_t pivot_base, int64_t R,
-                 int64_t nblk, int64_t cb, int64_t ce, bool head_done, hipEvent_t counters_ready = nullptr);
+                 int64_t nblk, int64_t cb, int64_t ce, bool head_done, hipEvent_t counters_ready = nullptr,
+                 T* y0 = nullptr, bool fprev = false);
 int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, int64_t R, int64_t c, bool first_external);
 int set_poll_limit(tgp_ctx* ctx, int64_t ms);
 int join_bounded(tgp_ctx* ctx, hipStream_t st, int64_t n);
