@@ -323,10 +323,13 @@ print("OK")
 """
 
 
-@pytest.mark.parametrize("mode", ["env", "file"])
+@pytest.mark.parametrize("mode", ["env", "file", "env-second-id"])
 def test_rccl_from_the_c_abi_without_torch(mode, tmp_path):
     """the library issues ncclBroadcast / ncclReduce / ncclAllReduce itself; the communicator id comes
-    from the launcher's environment (TCP) or a file -- no torch in the process, ONE HIP runtime, results vs LAPACK."""
+    from the launcher's environment (TCP) or a file -- no torch in the process, ONE HIP runtime, results vs LAPACK.
+    Round 6: the priority stream has a communicator of its OWN (panel broadcasts are not ordered against main-stream
+    reduces): a split of the first, or -- `env-second-id`: TGP_COMM_NO_SPLIT -- a second ncclCommInitRank whose id rank 0
+    sends through the first."""
     import subprocess
     import sys
     from pathlib import Path
@@ -335,8 +338,10 @@ def test_rccl_from_the_c_abi_without_torch(mode, tmp_path):
 
     root = Path(__file__).resolve().parent.parent
     out = tmp_path / "res.npz"
-    env = dict(os.environ, TGP_ROOT=str(root), TGP_TEST_COMM=mode, TGP_TEST_OUT=str(out), RANK="0", WORLD_SIZE="1",
+    env = dict(os.environ, TGP_ROOT=str(root), TGP_TEST_COMM=mode.split("-")[0], TGP_TEST_OUT=str(out), RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", TGP_TEST_ID_FILE=str(tmp_path / "id"))
+    if mode == "env-second-id":
+        env["TGP_COMM_NO_SPLIT"] = "1"
     env.pop("PYTHONPATH", None)
     r = subprocess.run([sys.executable, "-c", _NO_TORCH], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

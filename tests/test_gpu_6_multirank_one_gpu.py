@@ -55,7 +55,7 @@ def _worker(rank, world, port, n, nb, dtype_name, m_test, q):
         # this rank's block columns of the factor (lower part), for the LAPACK comparison
         cols = [(j, s.ops.column(l, s.rows(j))) for l, j in enumerate(s.owned)]
         q.put((rank, ll, s.info, mean, ll2, s.bytes_received, cols, res))
-        s.ops.close()
+        s.close(close_ops=True)  # (the communicator this driver made first, then the operations)
     finally:
         dist.destroy_process_group()
 
@@ -68,7 +68,7 @@ def _run(world, n, nb, dtype_name, m_test):
     port = 29700 + (os.getpid() % 200)
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, nb, dtype_name, m_test, q)) for r in range(world)]
     [p.start() for p in procs]
-    out = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    out = sorted((q.get(timeout=300 if world <= 3 else 900) for _ in range(world)), key=lambda t: t[0])
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     return out
@@ -77,6 +77,9 @@ def _run(world, n, nb, dtype_name, m_test):
 @pytest.mark.parametrize("world,n,nb,dtype_name,rtol", [(2, 3000, 512, "float64", 1e-8),
                                                          (3, 2500, 256, "float64", 1e-8),
                                                          (2, 5000, 1024, "float64", 1e-8),
+                                                         # round 6: EIGHT ranks (two block columns each, seven peers per
+                                                         # panel, a reduce chain over eight owners in the forward solve)
+                                                         (8, 4000, 256, "float64", 1e-8),
                                                          (2, 2000, 256, "float32", 5e-4)])
 def test_block_column_driver_with_peers_on_one_gpu(world, n, nb, dtype_name, rtol):
     from oracle import tinygp_np as o

@@ -36,6 +36,7 @@ struct RcclApi {
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;  // optional (NCCL >= 2.18)
 };
 RcclApi g_rccl;
 std::mutex g_rccl_mu;
@@ -77,6 +78,7 @@ int load_rccl() {
     a.field = reinterpret_cast<decltype(a.field)>(dlsym(lib, name));             \
     if (!a.field) {                                                              \
       set_error("librccl has no symbol %s", name);                               \
+      dlclose(lib); /* (advisor r5: the handle leaked on this path) */           \
       return TGP_E_UNSUPPORTED;                                                  \
     }                                                                            \
   } while (0)
@@ -90,6 +92,7 @@ int load_rccl() {
   SYM(Reduce, "ncclReduce");
   SYM(AllReduce, "ncclAllReduce");
 #undef SYM
+  a.CommSplit = reinterpret_cast<decltype(a.CommSplit)>(dlsym(lib, "ncclCommSplit"));  // (may be absent: see tgp_comm_create)
   g_rccl = a;
   return TGP_OK;
 }
@@ -109,7 +112,13 @@ inline ncclDataType_t nccl_dtype(int dtype) { return dtype == TGP_F64 ? ncclFloa
 
 struct tgp_comm {
   tgp_ctx* ctx = nullptr;
-  ncclComm_t comm = nullptr;
+  // ONE communicator PER STREAM (round 6).  RCCL orders the operations of a communicator and inserts
+  // cross-stream dependencies when the stream changes: with one communicator on both streams the look-ahead broadcast of a
+  // panel (priority stream) and a main-stream reduce / all-reduce would be ordered against each other -- the overlap the
+  // block-column driver is built on would silently serialise on a real node (at world size 1 it is invisible).
+  // comm[0]: main stream, comm[1]: priority stream (a split of comm[0], or a second ncclCommInitRank whose id rank 0
+  // sends through comm[0] when the library has no ncclCommSplit).
+  ncclComm_t comm[2] = {nullptr, nullptr};
   int world = 1, rank = 0;
   // stream-to-stream ordering around the collectives (a broadcast issued on the priority stream, consumed on the main
   // stream): a small ring of events; a ticket names the event AND its generation, a stale ticket is an error
@@ -129,6 +138,7 @@ struct tgp_comm {
   TGP_HIP_TRY(hipSetDevice((c)->ctx->device))
 
 static hipStream_t comm_stream(tgp_comm* c, int which) { return which == 0 ? c->ctx->stream : c->ctx->panel_stream; }
+static ncclComm_t comm_of(tgp_comm* c, int which) { return c->comm[which == 0 ? 0 : 1]; }
 
 extern "C" {
 
@@ -160,11 +170,39 @@ int tgp_comm_create(tgp_ctx* ctx, int32_t world, int32_t rank, const void* id, t
   c->ctx = ctx;
   c->world = world;
   c->rank = rank;
-  ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, uid, rank);
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm[0], world, uid, rank);
   if (r != ncclSuccess) {
     set_error("ncclCommInitRank(world %d, rank %d) failed: %s", world, rank, g_rccl.GetErrorString(r));
     delete c;
     return TGP_E_HIP;
+  }
+  // the priority stream's own communicator
+  r = ncclInternalError;
+  if (g_rccl.CommSplit != nullptr && getenv("TGP_COMM_NO_SPLIT") == nullptr)
+    r = g_rccl.CommSplit(c->comm[0], 0, rank, &c->comm[1], nullptr);
+  if (r != ncclSuccess || c->comm[1] == nullptr) {
+    // no ncclCommSplit (or it refused): a second id, generated by rank 0 and sent through the first communicator
+    c->comm[1] = nullptr;
+    ncclUniqueId id2;
+    std::memset(&id2, 0, sizeof(id2));
+    if (rank == 0) r = g_rccl.GetUniqueId(&id2);
+    void* dbuf = nullptr;
+    hipError_t he = hipMalloc(&dbuf, sizeof(id2));
+    if (he == hipSuccess) he = hipMemcpy(dbuf, &id2, sizeof(id2), hipMemcpyHostToDevice);
+    ncclResult_t rb = ncclInternalError;
+    if (he == hipSuccess) rb = g_rccl.Broadcast(dbuf, dbuf, sizeof(id2), ncclChar, 0, c->comm[0], ctx->stream);
+    if (he == hipSuccess && rb == ncclSuccess) he = hipStreamSynchronize(ctx->stream);
+    if (he == hipSuccess && rb == ncclSuccess) he = hipMemcpy(&id2, dbuf, sizeof(id2), hipMemcpyDeviceToHost);
+    if (dbuf) hipFree(dbuf);
+    ncclResult_t r2 = ncclInternalError;
+    if (he == hipSuccess && rb == ncclSuccess) r2 = g_rccl.CommInitRank(&c->comm[1], world, id2, rank);
+    if (r2 != ncclSuccess) {
+      set_error("second communicator (priority stream) failed: hip %s, broadcast %s, init %s", hipGetErrorString(he),
+                g_rccl.GetErrorString(rb), g_rccl.GetErrorString(r2));
+      g_rccl.CommDestroy(c->comm[0]);
+      delete c;
+      return TGP_E_HIP;
+    }
   }
   for (auto& e : c->ev) {
     hipError_t he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -180,14 +218,22 @@ int tgp_comm_create(tgp_ctx* ctx, int32_t world, int32_t rank, const void* id, t
 
 int tgp_comm_destroy(tgp_comm* c) {
   if (!c) return TGP_OK;
-  if (c->ctx) {
-    hipSetDevice(c->ctx->device);
-    for (hipStream_t q : {c->ctx->panel_stream, c->ctx->stream})
-      if (q) hipStreamSynchronize(q);
+  {
+    // under the context's lock (advisor r5): no other thread may be enqueueing on these streams while they are drained and
+    // the communicators go away.  The caller keeps the context alive until this returns (tinygp_amd/comm.py holds a
+    // reference; BlockCyclicCholesky.close closes the communicator it created BEFORE its operations and their context).
+    std::unique_lock<std::recursive_mutex> lk;
+    if (c->ctx) {
+      lk = std::unique_lock<std::recursive_mutex>(c->ctx->mu);
+      hipSetDevice(c->ctx->device);
+      for (hipStream_t q : {c->ctx->panel_stream, c->ctx->stream})
+        if (q) hipStreamSynchronize(q);
+    }
+    for (int q = 1; q >= 0; --q)
+      if (c->comm[q] && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm[q]);
+    for (auto e : c->ev)
+      if (e) hipEventDestroy(e);
   }
-  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-  for (auto e : c->ev)
-    if (e) hipEventDestroy(e);
   delete c;
   return TGP_OK;
 }
@@ -206,7 +252,7 @@ int tgp_comm_broadcast(tgp_comm* c, int which, void* buf, int64_t count, int dty
   TGP_ARG_CHECK((which == 0 || which == 1) && buf != nullptr && count >= 0 && root >= 0 && root < c->world,
                 "broadcast: bad argument");
   if (count == 0) return TGP_OK;
-  TGP_NCCL_TRY(g_rccl.Broadcast(buf, buf, size_t(count), nccl_dtype(dtype), root, c->comm, comm_stream(c, which)));
+  TGP_NCCL_TRY(g_rccl.Broadcast(buf, buf, size_t(count), nccl_dtype(dtype), root, comm_of(c, which), comm_stream(c, which)));
   return TGP_OK;
 }
 
@@ -215,7 +261,7 @@ int tgp_comm_reduce(tgp_comm* c, int which, void* buf, int64_t count, int dtype,
   TGP_ARG_CHECK((which == 0 || which == 1) && buf != nullptr && count >= 0 && root >= 0 && root < c->world,
                 "reduce: bad argument");
   if (count == 0) return TGP_OK;
-  TGP_NCCL_TRY(g_rccl.Reduce(buf, buf, size_t(count), nccl_dtype(dtype), ncclSum, root, c->comm, comm_stream(c, which)));
+  TGP_NCCL_TRY(g_rccl.Reduce(buf, buf, size_t(count), nccl_dtype(dtype), ncclSum, root, comm_of(c, which), comm_stream(c, which)));
   return TGP_OK;
 }
 
@@ -225,7 +271,7 @@ int tgp_comm_all_reduce(tgp_comm* c, int which, void* buf, int64_t count, int dt
   TGP_ARG_CHECK((which == 0 || which == 1) && buf != nullptr && count >= 0 && op >= 0 && op <= 2, "all_reduce: bad argument");
   if (count == 0) return TGP_OK;
   const ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMin : ncclMax);
-  TGP_NCCL_TRY(g_rccl.AllReduce(buf, buf, size_t(count), nccl_dtype(dtype), rop, c->comm, comm_stream(c, which)));
+  TGP_NCCL_TRY(g_rccl.AllReduce(buf, buf, size_t(count), nccl_dtype(dtype), rop, comm_of(c, which), comm_stream(c, which)));
   return TGP_OK;
 }
 

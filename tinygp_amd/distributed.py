@@ -362,6 +362,39 @@ class HipBlockOps:
             pass
 
 
+# One default communicator per (context, process group): ncclCommInitRank is a collective with a TCP id exchange and tens
+# of MB of communicator memory -- a solver per hyper-parameter point must not pay (or leak) it every time (advisor r5).
+_DEFAULT_COMMS: dict = {}
+
+
+def _shared_default_comm(ops, dist, group):
+    key = (id(ops.ctx), id(group) if group is not None else None, None if dist is None else id(dist))
+    ent = _DEFAULT_COMMS.get(key)
+    if ent is None:
+        ent = [BlockCyclicCholesky._make_default_comm(ops, dist, group), 0, key]
+        _DEFAULT_COMMS[key] = ent
+    ent[1] += 1
+    ent[0]._tgp_default_key = key
+    return ent[0]
+
+
+def _release_default_comm(comm):
+    key = getattr(comm, "_tgp_default_key", None)
+    ent = _DEFAULT_COMMS.get(key)
+    if ent is None or ent[0] is not comm:  # (not from the cache: the CPU stand-in's TorchComm has nothing to release)
+        if hasattr(comm, "close") and key is None and not isinstance(comm, type(None)):
+            try:
+                comm.close()
+            except Exception:
+                pass
+        return
+    ent[1] -= 1
+    if ent[1] <= 0:
+        del _DEFAULT_COMMS[key]
+        if hasattr(comm, "close"):
+            comm.close()
+
+
 class BlockCyclicCholesky:
     """Distributed dense GP: ``log_probability`` and the posterior mean of ``condition``.
 
@@ -382,8 +415,10 @@ class BlockCyclicCholesky:
     def __init__(self, kernel, X, noise_diag, *, nb: int = 1024, ops=None, group=None, dist=None, comm=None):
         if nb % 128 or nb <= 0:
             raise ValueError("nb must be a positive multiple of 128")
+        self._own_ops = ops is None
         if ops is None:
             ops = HipBlockOps(int(os.environ.get("LOCAL_RANK", "0")))
+        self._own_comm = comm is None  # a communicator this object made: close() releases it, BEFORE the operations
         if comm is None:
             comm = self._default_comm(ops, dist, group)
         self.comm = comm
@@ -419,12 +454,37 @@ class BlockCyclicCholesky:
     def owner(self, j: int) -> int:
         return j % self.G
 
+    def close(self, close_ops: bool | None = None):
+        """Release what this object created, in dependency order: the communicator (its destroy drains the context's
+        streams under the context's lock) first, then the operations -- never left to ``__del__`` order at interpreter
+        exit, where the context could go first (advisor r5).  A default RCCL communicator is shared by every driver of
+        the same context and process group and is released with the LAST of them.  Operations the CALLER passed in are
+        closed only on request (``close_ops=True``)."""
+        comm, self.comm = getattr(self, "comm", None), None
+        if comm is not None and getattr(self, "_own_comm", False):
+            _release_default_comm(comm)
+        ops = getattr(self, "ops", None)
+        if ops is not None and hasattr(ops, "close") and (getattr(self, "_own_ops", False) if close_ops is None else close_ops):
+            ops.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
     @staticmethod
     def _default_comm(ops, dist, group):
         from tinygp_amd import comm as _comm
 
         if not isinstance(ops, HipBlockOps):  # the CPU stand-in of the tests: torch tensors under gloo
             return _comm.TorchComm(dist, group)
+        return _shared_default_comm(ops, dist, group)
+
+    @staticmethod
+    def _make_default_comm(ops, dist, group):
+        from tinygp_amd import comm as _comm
+
         if dist is None:
             import sys
 

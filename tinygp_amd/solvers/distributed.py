@@ -186,4 +186,4 @@ class DistributedDirectSolver(Solver):
         return self._bc.factor()
 
     def close(self):
-        self._bc.ops.close()
+        self._bc.close(close_ops=True)  # (the communicator it made, then the operations: tinygp_amd/distributed.py)
