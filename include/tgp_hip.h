@@ -40,7 +40,8 @@ extern "C" {
  *  chain_fast_update / host_join, chain_polls = 3 (stream wait-value); tgp_dist_fwd_partial / _fwd_solve_left,
  *  tgp_dist_bwd_*_multi, tgp_dist_gather_owned, tgp_dist_identity_cols,
  *  tgp_dist_grad_* -- multi-RHS backward solve and gradient on the block-column path;
- *  round 5 -> 6: tgp_chain_tasks (the chain launch's task TABLE with its K-batched updates), options chain_batch /
+ *  round 5 -> 6: tgp_chain_tasks (the chain launch's task TABLE with its K-batched updates), tgp_dist_gram_pair_owned, tgp_dist_load_matrix,
+ *  options chain_fwd_tasks, chain_batch /
  *  chain_batch_lag / chain_batch_rowlag / chain_batch_minrows, trsv_groups; tgp_solver_timings ms[7]) */
 #define TGP_ABI_VERSION 6
 
@@ -356,6 +357,9 @@ int tgp_dist_create(tgp_ctx* ctx, int dtype, int64_t n, int32_t d, const void* X
                     const void* noise_diag_host, int64_t nb, int32_t world, int32_t rank,
                     void* ring0_dev, void* ring1_dev, void* ring2_dev, void* x_dev, tgp_dist** out);
 int tgp_dist_destroy(tgp_dist* h);
+/* INSTEAD of tgp_dist_assemble: this rank's block columns of a host matrix (n x n row-major, symmetric, noise included) --
+ * the seam's `covariance=` argument and non-diagonal noise (reference solvers/direct.py:36,50-52) on the block-column path */
+int tgp_dist_load_matrix(tgp_dist* h, const void* K_host);
 /* hipStream_t of the context: which = 0 main (updates), 1 panel (chain + pack); the host makes
  * its RCCL calls wait on / be waited on by these */
 int tgp_dist_stream(tgp_dist* h, int which, void** stream_out);
@@ -420,6 +424,10 @@ int tgp_dist_cross_cov(tgp_dist* h, const tgp_kop* prog, int nops, int64_t m, co
  * (direct.py:95; column-major nrhs x nrhs) over the rows of its OWNED blocks; the host all-reduces */
 int tgp_dist_colsumsq_owned(tgp_dist* h, int64_t nrhs, const void* x_dev, void* out_dev);
 int tgp_dist_gram_owned(tgp_dist* h, int64_t nrhs, const void* x_dev, void* out_dev);
+/* block (i, j) of the same product for two sets of solved columns (round 6: condition_gram in chunks of test points):
+ * out (nrhs_i x nrhs_j, column-major) = this rank's share of x_i^T x_j */
+int tgp_dist_gram_pair_owned(tgp_dist* h, int64_t nrhs_i, const void* xi_dev, int64_t nrhs_j, const void* xj_dev,
+                             void* out_dev);
 /* after a rank-local failure: joins every stream and forgets the interrupted pass's markers (a retry starts from a
  * quiet device) */
 int tgp_dist_abort(tgp_dist* h);

@@ -75,6 +75,21 @@ class NumpyBlockOps:
                 if i >= n2:
                     C[j0 + i, i] = 1.0
 
+    def load_matrix(self, K):
+        self.calls.append(("load_matrix",))
+        nb, n = self.nb, self.n
+        K = np.asarray(K, dtype=self.dtype)
+        for l in range(self.nloc):
+            j0 = (l * self.G + self.rank) * nb
+            Cc = self._col(l)
+            Cc[:] = 0.0
+            n1, n2 = max(n - j0, 0), max(min(nb, n - j0), 0)
+            if n1 and n2:
+                Cc[j0:j0 + n1, :n2] = K[j0:j0 + n1, j0:j0 + n2]
+            for i in range(nb):  # identity padding
+                if i >= n2:
+                    Cc[j0 + i, i] = 1.0
+
     def begin(self, resid):
         self.calls.append(("begin",))
         self.info = 0
@@ -372,6 +387,10 @@ class NumpyBlockOps:
     def gram_owned(self, nrhs, x):
         a = x.numpy()[self._owned_rows()]
         return torch.from_numpy(np.ascontiguousarray(a.T @ a))
+
+    def gram_pair_owned(self, ni, xi, nj, xj):
+        a, b = xi.numpy()[self._owned_rows()], xj.numpy()[self._owned_rows()]
+        return torch.from_numpy(np.ascontiguousarray((a.T @ b).T))  # (nj, ni): the device's column-major (ni x nj) block
 
     def set_x(self, buf):
         self.xn[:] = buf.numpy()

@@ -70,8 +70,37 @@ def _worker(rank, world, port, mode, q):
                        dot=s.dot_triangular(y), dotR=s.dot_triangular(Y),
                        cvar=s.condition_variance(k, xt), ccov=s.condition(k, xt, gp.noise.__class__(np.full(23, 0.02))),
                        alpha=s.alpha(2.0 * y - 0.5)[0], mean=np.array(gp.condition(y, xt).gp.loc))
+            # round 6: the conditional covariance in CHUNKS of test points (three chunks of 128 / 128 / 44 here) against
+            # the single pass over the same 300 points
+            xt2 = np.linspace(X[0], X[-1], 300)
+            one = s._bc.condition_gram(xt2)
+            s._bc.GRAM_CHUNK = 128
+            out["gram_chunked"], out["gram_one"] = s._bc.condition_gram(xt2), one
+            s._bc.GRAM_CHUNK = 4096
             out["panels_before"], out["panels_after"] = panels, sum(1 for c in ops.calls if c[0] == "panel")
             out["reduces"] = sum(1 for c in ops.calls if c[0] == "fwd_block")
+        elif mode == "covariance":
+            # round 6: the seam's `covariance=` argument and a non-diagonal noise model on the block-column path
+            from tinygp_amd import noise as noise_mod
+
+            n, nb = 500, 128
+            X, y = synthetic.make_inputs(n, 1)
+            k = 1.5**2 * kernels.ExpSquared(2.5) + 0.3 * kernels.Matern32(1.2)
+            rng = np.random.default_rng(21)
+            B = rng.normal(size=(n, 4)) * 0.05
+            Nd = B @ B.T + 0.02 * np.eye(n)                 # a dense noise matrix (low rank + diagonal)
+            xt = np.linspace(X[0], X[-1], 17)
+            gp = GaussianProcess(k, X, noise=noise_mod.Dense(Nd), solver=DistributedDirectSolver, nb=nb, ops=NumpyBlockOps(),
+                                 dist=dist)
+            cond = gp.condition(y, xt)
+            from tinygp_amd.kernels.base import host_matrix
+
+            Kfull = np.asarray(host_matrix(k, X, X)) + Nd
+            ops2 = NumpyBlockOps()
+            gp2 = GaussianProcess(k, X, diag=0.02, solver=DistributedDirectSolver, nb=nb, ops=ops2, dist=dist, covariance_value=Kfull)
+            out = dict(ll=float(gp.log_probability(y)), loc=np.array(cond.gp.loc), var=np.array(cond.gp.variance),
+                       ll_cov=float(gp2.log_probability(y)), cov_back=np.array(gp2.solver.covariance()),
+                       loaded=("load_matrix",) in ops2.calls, assembled=("assemble",) in ops2.calls)
         elif mode.startswith("grad"):
             n, nb = (460, 128) if mode == "grad" else (300, 128)
             rng = np.random.default_rng(11)
@@ -135,6 +164,40 @@ def _run(world, mode):
 TOL = dict(rtol=5e-7, atol=5e-7)  # the reference's own tolerance in fp64 (tests/test_utils.py:16)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_covariance_argument_and_dense_noise_on_the_block_column_path(world):
+    """Reference solvers/direct.py:36,44-52: `covariance=` is used as it is; a non-diagonal noise goes through
+    `kernel(X, X) + noise` -- here every rank uploads its own block columns of that host matrix."""
+    import scipy.linalg as sla
+    from oracle import tinygp_np as o
+    from tinygp_amd import synthetic
+
+    n = 500
+    X, y = synthetic.make_inputs(n, 1)
+    k = 1.5**2 * o.ExpSquared(2.5) + 0.3 * o.Matern32(1.2)
+    rng = np.random.default_rng(21)
+    B = rng.normal(size=(n, 4)) * 0.05
+    Nd = B @ B.T + 0.02 * np.eye(n)
+    K = k(X, X) + Nd
+    L = sla.cholesky(K, lower=True)
+    a = sla.solve_triangular(L, y, lower=True)
+    want = -0.5 * a @ a - np.sum(np.log(np.diag(L))) - 0.5 * n * np.log(2 * np.pi)
+    xt = np.linspace(X[0], X[-1], 17)
+    Ks = k(X, xt)
+    A = sla.solve_triangular(L, Ks, lower=True)
+    loc = Ks.T @ sla.solve_triangular(L, a, lower=True, trans=1)
+    var = np.diag(k(xt, xt)) - np.sum(A * A, axis=0)
+    res = _run(world, "covariance")
+    for r in res:
+        np.testing.assert_allclose(r["ll"], want, rtol=1e-9)
+        np.testing.assert_allclose(r["ll_cov"], want, rtol=1e-9)
+        np.testing.assert_allclose(r["loc"], loc, **TOL)
+        np.testing.assert_allclose(r["var"], var, **TOL)
+        np.testing.assert_allclose(r["cov_back"], K, rtol=1e-12, atol=1e-12)
+        assert r["loaded"] and not r["assembled"]
+    assert len({r["ll"] for r in res}) == 1  # bit-identical on every rank
+
+
 def test_reference_solver_cases_through_gaussian_process_at_world_size_2():
     from oracle import tinygp_np as o
 
@@ -182,6 +245,9 @@ def test_solves_on_the_resident_distributed_factor(world):
         np.testing.assert_allclose(res["dotR"], L @ Y, rtol=1e-11, atol=1e-12)
         np.testing.assert_allclose(res["cvar"], np.diag(k(xt, xt)) - np.sum(A * A, axis=0), **TOL)
         np.testing.assert_allclose(res["ccov"], k(xt, xt) + 0.02 * np.eye(23) - A.T @ A, **TOL)
+        A2 = sla.solve_triangular(L, k(X, np.linspace(X[0], X[-1], 300)), lower=True)
+        np.testing.assert_allclose(res["gram_one"], A2.T @ A2, **TOL)
+        np.testing.assert_allclose(res["gram_chunked"], res["gram_one"], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(res["alpha"], np.linalg.solve(K, 2.0 * y - 0.5), rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(res["mean"], gp.predict(y, xt), **TOL)
         # a new right-hand side never factors a panel again: O(N^2) on the resident factor (reference gp.py:330-334)

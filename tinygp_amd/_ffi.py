@@ -127,6 +127,8 @@ SIGNATURES = {
     "tgp_dist_cross_cov": [_vp, _pkop, _int, _i64, _vp, _i64, _vp],
     "tgp_dist_colsumsq_owned": [_vp, _i64, _vp, _vp],
     "tgp_dist_gram_owned": [_vp, _i64, _vp, _vp],
+    "tgp_dist_gram_pair_owned": [_vp, _i64, _vp, _i64, _vp, _vp],
+    "tgp_dist_load_matrix": [_vp, _vp],
     "tgp_dist_abort": [_vp],
     "tgp_dist_fwd_partial": [_vp, _i64, _i64, _vp, _vp, _i64],
     "tgp_dist_fwd_solve_left": [_vp, _i64, _i64, _vp, _vp, _vp, _vp],
