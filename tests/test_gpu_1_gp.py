@@ -457,6 +457,15 @@ def test_poll_timeout_option_round_trips_and_rejects_nonsense():
         assert ctx.get_option("poll_timeout_ms") == 2500
         with pytest.raises(ValueError):
             ctx.set_option("poll_timeout_ms", 0)
+        # ONE value per process and device (it lives in a device global of the library): a second context reads and
+        # sets the same one, and the first context's get_option follows (advisor r5: a copy per context went stale)
+        other = _ffi.Ctx(device=0)
+        try:
+            assert other.get_option("poll_timeout_ms") == 2500
+            other.set_option("poll_timeout_ms", 3100)
+            assert ctx.get_option("poll_timeout_ms") == 3100
+        finally:
+            other.close() if hasattr(other, "close") else None
     finally:
         ctx.set_option("poll_timeout_ms", old)
 

@@ -350,6 +350,7 @@ int tgp_ctx_get_option(tgp_ctx* ctx, const char* key, int64_t* value) {
   TGP_ARG_CHECK(ctx != nullptr && key != nullptr && value != nullptr, "null argument");
   int64_t* slot = option_slot(ctx, key);
   TGP_ARG_CHECK(slot != nullptr, "unknown option '%s'", key);
+  if (slot == &ctx->poll_timeout_ms && ctx->has_device) ctx->poll_timeout_ms = tgp::poll_limit_ms();  // (one value per process)
   *value = *slot;
   return TGP_OK;
 }

@@ -17,6 +17,7 @@
 //         Y_j = inv(L_jj) (B_j^T - sum_{k<j} L_jk Y_k) so that an MFMA result (D layout)
 //         is directly the next MFMA's B operand -- no LDS, no shuffles.
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <type_traits>
 
@@ -296,7 +297,7 @@ __device__ __forceinline__ void trsm_fold_body(T* S, int it, const T* __restrict
     if (tid == 0) {
       uint32_t seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       PollClock clk;
-      for (int spin = 0; seen != epoch; ++spin) {
+      for (unsigned spin = 0; seen != epoch; ++spin) {  // (unsigned: a wait of up to an hour wraps, it does not overflow)
         __builtin_amdgcn_s_sleep(2);
         seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (clk.expired(spin)) break;
@@ -484,7 +485,7 @@ __device__ __forceinline__ void chain_wait(const uint32_t* f0, uint32_t v0, cons
     const uint32_t* f = lane == 0 ? f0 : (lane == 1 ? f1 : (lane == 2 ? f2 : nullptr));
     const uint32_t want = lane == 0 ? v0 : (lane == 1 ? v1 : v2);
     bool ok = f == nullptr || __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
-    int spin = 0;
+    unsigned spin = 0;
     PollClock clk;
     while (!__all(ok)) {
       __builtin_amdgcn_s_sleep(NAP);
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(64) void chain_poll_kernel(const int32_t* __restric
                                                         int32_t* __restrict__ info) {
   if (threadIdx.x != 0) return;
   PollClock clk;
-  for (int spin = 0;; ++spin) {
+  for (unsigned spin = 0;; ++spin) {
     if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
     __builtin_amdgcn_s_sleep(16);
     if ((spin & 255) == 255 && (clk.expired(spin) || poisoned(info))) {
@@ -993,7 +994,7 @@ struct ChainStream {
 // returns what it saw, so that a reader that is several steps behind polls ONCE
 __device__ __forceinline__ uint32_t chain_wave_wait_ge(const uint32_t* word, uint32_t want, int32_t* info) {
   PollClock clk;
-  for (int spin = 0;; ++spin) {
+  for (unsigned spin = 0;; ++spin) {
     const uint32_t v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (int32_t(v - want) >= 0 && int32_t(v - want) < 128) return v;
     __builtin_amdgcn_s_sleep(1);
@@ -1012,7 +1013,7 @@ __device__ __forceinline__ void chain_lds_barrier() {
 // wave-level wait until the counter *p (zeroed per launch) has reached `want`; returns what it saw
 __device__ __forceinline__ int chain_wave_wait_count(const int32_t* p, int want, int32_t* info) {
   PollClock clk;
-  for (int spin = 0;; ++spin) {
+  for (unsigned spin = 0;; ++spin) {
     const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v >= want) return v;
     __builtin_amdgcn_s_sleep(1);
@@ -1180,7 +1181,7 @@ __device__ __forceinline__ void chain_wait_counts(const int32_t* p0, int want0, 
       return lane == 1 ? v == want : v >= want;
     };
     bool ok = f == nullptr || ready();
-    int spin = 0;
+    unsigned spin = 0;
     PollClock clk;
     while (!__all(ok)) {
       __builtin_amdgcn_s_sleep(4);
@@ -2193,10 +2194,16 @@ int run_deferred_asm(tgp_ctx* ctx, hipStream_t behind) {
   return f();
 }
 
+// The bound lives in ONE device global of the library, shared by every context of the process on that device; the host
+// keeps ONE mirror of it (advisor r5: with a copy per context, the host deadline of join_bounded and get_option of a context
+// disagreed with the device as soon as another context had set the option).
+static std::atomic<int64_t> g_poll_ms_host{4000};
+int64_t poll_limit_ms() { return g_poll_ms_host.load(); }
 int set_poll_limit(tgp_ctx* ctx, int64_t ms) {
   TGP_ARG_CHECK(ms >= 1 && ms <= 3600000, "poll_timeout_ms must be in [1, 3600000]");
   const long long ticks = (long long)ms * 100000LL;  // s_memrealtime: 100 MHz
   TGP_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_poll_limit), &ticks, sizeof(ticks)));
+  g_poll_ms_host.store(ms);
   ctx->poll_timeout_ms = ms;
   return TGP_OK;
 }
@@ -2211,7 +2218,7 @@ int set_poll_limit(tgp_ctx* ctx, int64_t ms) {
 int join_bounded(tgp_ctx* ctx, hipStream_t st, int64_t n) {
   TGP_TRY(ev_record(ctx, ctx->ev_join, st));
   const auto t0 = std::chrono::steady_clock::now();
-  const double budget_ms = double(ctx->poll_timeout_ms) + 3.0 * (double(n) * double(n) * double(n) / 3.0) / 2e13 * 1e3;
+  const double budget_ms = double(poll_limit_ms()) + 3.0 * (double(n) * double(n) * double(n) / 3.0) / 2e13 * 1e3;
   for (long spin = 0;; ++spin) {
     const hipError_t e = hipEventQuery(ctx->ev_join);
     if (e == hipSuccess) return TGP_OK;

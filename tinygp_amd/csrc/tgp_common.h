@@ -345,6 +345,7 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
                  T* y0 = nullptr, bool fprev = false);
 int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, int64_t R, int64_t c, bool first_external);
 int set_poll_limit(tgp_ctx* ctx, int64_t ms);
+int64_t poll_limit_ms();  // the process-wide value behind every context's "poll_timeout_ms"
 int join_bounded(tgp_ctx* ctx, hipStream_t st, int64_t n);
 int run_deferred_asm(tgp_ctx* ctx, hipStream_t behind);
 template <typename T>
