@@ -6,6 +6,12 @@ textbook identity
     d ll / d theta = 1/2 alpha^T (dK/dtheta) alpha - 1/2 tr(K^-1 dK/dtheta),  alpha = K^-1 r,
 with dK/dtheta taken by central differences of the ORACLE's own kernel matrix, and
 cross-checks it against central differences of the oracle's log-likelihood itself.
+
+HOW THIS IS PINNED: not to the reference's autodiff (JAX cannot run in this image) but THROUGH FINITE DIFFERENCES OF A
+PINNED SCALAR -- the log-likelihood of ``oracle/tinygp_np.py`` is pinned to the reference's own execution
+(``tests/golden/ref_gp.npz``, ``tests/test_reference_pin.py``), this gradient must agree with central differences of that
+scalar to 1e-4 (``tests/test_oracle.py``), and the closed forms dk/dtheta the device evaluates are restated a second time in
+NumPy (``oracle/kernel_derivs_np.py``) and held against central differences of the oracle's kernel matrices at 2e-7.
 """
 import numpy as np
 

@@ -4,17 +4,19 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``tinygp_amd/`` may import this file;
 only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg use it, and only as the checker / the reported CPU baseline.
 
-PARITY UNPINNED (against reference *outputs*): the reference (`/root/reference`,
-dfm/tinygp) cannot be imported in the build container (needs ``jax`` + ``equinox``,
-Python >= 3.11) and ships no golden vectors or known-answer files for this path
-(SURVEY.md section 8c).  Its arithmetic lives in the un-vendored, un-pinned third
-party dependency ``jax``/``jaxlib`` (``pyproject.toml:18``): ``jax.scipy.linalg.
-cholesky`` / ``solve_triangular`` which lower to LAPACK ``?potrf`` / BLAS ``?trsm``
-on CPU.  This file restates the reference's algorithm line by line on top of the
-same LAPACK family (SciPy/OpenBLAS) and is pinned the only way the reference's
-own tests pin the path -- by agreement between independent implementations
-(closed forms, ``np.linalg.solve``, and the independent plain-C restatement in
-``oracle/ref_c.c``); see ``tests/test_oracle.py``.
+PARITY PINNED to the reference's own execution (since round 3).  The reference (`/root/reference`, dfm/tinygp) needs
+``jax`` + ``equinox`` and Python >= 3.11, none of which this image has, and ships no golden vectors for this path
+(SURVEY.md section 8c); its arithmetic lives in the un-vendored third-party ``jax`` / ``jaxlib`` (``pyproject.toml:18``:
+``jax.scipy.linalg.cholesky`` / ``solve_triangular``, LAPACK ``?potrf`` / BLAS ``?trsm`` on CPU).  ``oracle/refshim/``
+therefore holds NumPy stand-ins for the dozen jax / equinox primitives the reference uses (``vmap`` = a Python loop,
+``jit`` = identity, ``cholesky`` / ``solve_triangular`` = LAPACK) and ``oracle/refshim/make_ref_golden.py`` imports THE
+UNMODIFIED REFERENCE PACKAGE as it lies under ``/root/reference`` and writes ``tests/golden/ref_{kernels,gp,configs,
+transforms}.npz`` -- 19 kernels x 3 shapes, 16 GP cases, BASELINE config 1 in full, the transforms and ``noise.Dense``.
+This file reproduces those kernel matrices bit for bit and the GP results to 1e-12 ... 1e-9 (``tests/test_oracle.py``),
+and where the reference tree exists the generation is re-run and must reproduce the committed fixtures
+(``tests/test_reference_pin.py``).  The full-size configs (N >= 16 384) are pinned to this oracle's LAPACK arithmetic, which
+is chained to the reference at N <= 4 096 (the shim's looped ``vmap`` is N^2 Python calls).  Independent second
+restatement: plain C, ``oracle/ref_c.c``.
 
 Every function cites the reference ``file:line`` it follows (paths relative to
 ``/root/reference/src/tinygp``).
