@@ -81,8 +81,8 @@ def accesses(rec, T):
             for ti in range(m):
                 if lower and ti < tj:
                     continue
-                if role == 3 and ti == 0 and tj == 0:
-                    continue  # folded into the next potf2
+                if role in (3, 5) and ti == 0 and tj == 0:
+                    continue  # folded into the next potf2 (3) / updated and factored on the side stream (5)
                 R.add(("A", cr + ti, cc + tj)); W.add(("A", cr + ti, cc + tj))
         R |= {("A", ar + ti, ac + kk) for ti in range(m) for kk in range(k)}
         R |= {("A", brr + tj, bcc + kk) for tj in range(n) for kk in range(k)}
@@ -270,6 +270,11 @@ CONFIGS = [
     (5120, 512, 1, 3, 1100, 3, 0, dict(chain_kernel=1, chain_full_rows=2048)),
     (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_full_rows=8192)),
     (16384, 1024, 1, 5, 1100, 2, 0, dict(chain_kernel=1, chain_full_rows=0)),
+    # ... the next panel's first diagonal block updated and factored on the update stream beside the gate: chain_gate_split = 1
+    (5120, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_gate_split=1)),
+    (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_gate_split=1)),
+    (16384, 1024, 1, 5, 1100, 2, 0, dict(chain_kernel=1, chain_gate_split=1)),
+    (16384, 512, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_full_rows=0)),
     # ... round 5's followers (forward steps as launches behind pollers) are still there: chain_fwd_tasks = 0
     (5120, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_fwd_tasks=0)),
     (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_fwd_tasks=0)),
@@ -306,7 +311,8 @@ def test_schedule_has_no_data_race(cfg):
     assert order == list(range(T))
     if len(cfg) > 7 and cfg[7].get("chain_kernel"):
         assert not any(r[0] in (2, 10) for r in recs)            # no trsm / panel-step launches ...
-        assert not any(r[0] == 3 and r[1] == 3 for r in recs)    # ... and nothing on the update stream's GEMM queue
+        # ... and nothing on the update stream's GEMM queue but the next panel's first diagonal block (chain_gate_split)
+        assert all(r[5] == 128 and r[6] == 128 and cfg[7].get("chain_gate_split") for r in recs if r[0] == 3 and r[1] == 3)
     elif cfg[5] & 2:
         assert not any(r[0] == 10 for r in recs)
     else:
@@ -345,6 +351,20 @@ def test_checker_sees_a_missing_dependency():
     no_chain_wait = [r for r in recs if not (r[0] == 6 and r[1] == 0 and r[2] == 1)]  # main waits ev_b
     assert len(no_chain_wait) < len(recs)
     assert find_races(no_chain_wait, T)
+
+
+def test_checker_sees_a_missing_join_of_the_split_gate():
+    """chain_gate_split: the next panel's first diagonal block is updated and factored on the update stream beside the gate.
+    Without the event that makes the side stream wait for the gate's inputs, or the one that joins it in front of the chain
+    launch, the checker must report the race."""
+    recs = trace(16384, 1024, 1, 5, 1100, 3, 0, chain_kernel=1, chain_gate_split=1)
+    T = 16384 // 128
+    assert any(r[0] == 3 and r[1] == 3 for r in recs) and any(r[0] == 1 and r[1] == 3 for r in recs)  # product + potf2 on stream 3
+    assert find_races(recs, T) == []
+    for ev, who in ((10, 3), (11, 1)):  # ev_i: side stream behind the gate's inputs; ev_j: chain launch behind the potf2
+        dropped = [r for r in recs if not (r[0] == 6 and r[1] == who and r[2] == ev)]
+        assert len(dropped) < len(recs)
+        assert find_races(dropped, T), ev
 
 
 def test_checker_sees_a_missing_poll_of_the_persistent_chain():

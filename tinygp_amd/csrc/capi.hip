@@ -205,6 +205,8 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_g1, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_g2, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_h, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_i, hipEventDisableTiming));
+  TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_j, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   TGP_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
@@ -252,6 +254,8 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
   if (ctx->ev_g1) hipEventDestroy(ctx->ev_g1);
   if (ctx->ev_g2) hipEventDestroy(ctx->ev_g2);
   if (ctx->ev_h) hipEventDestroy(ctx->ev_h);
+  if (ctx->ev_i) hipEventDestroy(ctx->ev_i);
+  if (ctx->ev_j) hipEventDestroy(ctx->ev_j);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
   if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
@@ -298,6 +302,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "chain_lds_pad")) return &ctx->chain_lds_pad;
   if (!strcmp(key, "chain_depth2")) return &ctx->chain_depth2;
   if (!strcmp(key, "chain_pre_wait")) return &ctx->chain_pre_wait;
+  if (!strcmp(key, "chain_gate_split")) return &ctx->chain_gate_split;
   if (!strcmp(key, "chain_polls")) return &ctx->chain_polls;
   if (!strcmp(key, "chain_fwd_tasks")) return &ctx->chain_fwd_tasks;
   if (!strcmp(key, "chain_fast_update")) return &ctx->chain_fast_update;
@@ -1300,6 +1305,8 @@ int tgp_trace_factor(int64_t n_pad, const char* options, int32_t fused, int64_t*
   ctx.ev_g1 = (hipEvent_t)fake(0x170);
   ctx.ev_g2 = (hipEvent_t)fake(0x180);
   ctx.ev_h = (hipEvent_t)fake(0x190);
+  ctx.ev_i = (hipEvent_t)fake(0x1a0);
+  ctx.ev_j = (hipEvent_t)fake(0x1b0);
   TGP_TRY(apply_options(&ctx, options));  // every option of tgp_ctx_set_option, library defaults otherwise
   std::vector<tgp_trace_rec> recs;
   ctx.trace = &recs;

@@ -2670,7 +2670,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   const std::function<int(hipEvent_t)> no_mid = [](hipEvent_t) { return TGP_OK; };
   auto trailing = [&](hipStream_t sq, int64_t m, int64_t nn, int64_t kb, const T* P, T* C, int role) -> int {
     ProfSpan sp{};
-    const bool prof = prof_on && role != 4;  // spans time the 128x128-tile kernel only
+    const bool prof = prof_on && role != 4 && role != 5;  // spans time the 128x128-tile kernel only
     if (prof) {
       TGP_TRY(prof_event(ctx, &sp.e0));
       TGP_TRY(prof_event(ctx, &sp.e1));
@@ -2767,9 +2767,26 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       auto chain_part = [&]() -> int {
         if (p >= 1) TGP_TRY(st_wait(ctx, S1, ev_pre[(p - 1) & 1]));
         if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S1, ctx->ev_asm));
-        TGP_TRY(trailing(S1, mt, wn, kb, A + s0[p] * ld + next, A + next * ld + next, first_role(mt, wn)));
-        TGP_TRY(potf2_at(S1, next, false));
-        if (pre_waits) TGP_TRY(ev_record(ctx, ctx->ev_h, S1));
+        const int grole = first_role(mt, wn);
+        // chain_gate_split: the next panel's first diagonal block on the update stream (idle with the persistent chain once
+        // the forward steps are chain tasks) beside the gate -- its own 128 x 128 x kb product, then potf2; the gate skips it
+        const bool gsplit = ctx->chain_gate_split != 0 && grole == 4 && mt > TILE && ctx->update_stream != nullptr &&
+                            (y == nullptr || ctx->chain_fwd_tasks != 0 || ctx->solve_on_update == 0);
+        if (gsplit) {
+          hipStream_t S3 = ctx->update_stream;
+          TGP_TRY(ev_record(ctx, ctx->ev_i, S1));  // (everything the gate waits for)
+          TGP_TRY(st_wait(ctx, S3, ctx->ev_i));
+          TGP_TRY(trailing(S3, TILE, TILE, kb, A + s0[p] * ld + next, A + next * ld + next, 4));
+          TGP_TRY(potf2_at(S3, next, false));
+          TGP_TRY(ev_record(ctx, ctx->ev_j, S3));
+          if (pre_waits) TGP_TRY(ev_record(ctx, ctx->ev_h, S3));
+          TGP_TRY(trailing(S1, mt, wn, kb, A + s0[p] * ld + next, A + next * ld + next, 5));
+          TGP_TRY(st_wait(ctx, S1, ctx->ev_j));
+        } else {
+          TGP_TRY(trailing(S1, mt, wn, kb, A + s0[p] * ld + next, A + next * ld + next, grole));
+          TGP_TRY(potf2_at(S1, next, false));
+          if (pre_waits) TGP_TRY(ev_record(ctx, ctx->ev_h, S1));
+        }
         TGP_TRY(panel(S1, next, wn, true, 0, no_mid));
         TGP_TRY(ev_record(ctx, ev_chain[(p + 1) & 1], S1));
         return TGP_OK;

@@ -873,8 +873,10 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   g.band = (int)ctx->tile_band;
   TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");
   // short-K updates, and (role 4) a latency-bound update with too few big tiles to fill the chip
-  if ((((role == 1 || role == 3) && k <= 256) || role == 4) && (mode == 0 || mode == 1)) {
-    g.skip00 = (role == 3);
+  // role 5 (round 6): role 4 without the first 128 x 128 diagonal block -- the gate of the next panel while that block is
+  // updated and factored on a side stream (potrf, chain_gate_split)
+  if ((((role == 1 || role == 3) && k <= 256) || role == 4 || role == 5) && (mode == 0 || mode == 1)) {
+    g.skip00 = (role == 3 || role == 5);
     g.A = A; g.B = B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.tm = int(m / SM); g.tn = int(n / SM);

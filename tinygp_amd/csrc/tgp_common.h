@@ -90,6 +90,7 @@ struct tgp_ctx {
   hipEvent_t ev_f = nullptr;  // second marker of the far in-panel updates (fused panel step: they alternate)
   hipEvent_t ev_g1 = nullptr, ev_g2 = nullptr;  // split gate: column block 1 / column blocks 2.. of the next panel updated
   hipEvent_t ev_h = nullptr;  // depth-2 schedule: the next panel's first potf2 has been issued (priority stream)
+  hipEvent_t ev_i = nullptr, ev_j = nullptr;  // chain_gate_split: the gate's inputs are ready / the next panel's first block is factored
   bool gate_pending = false;  // set by potrf in front of a panel whose block column arrives in those pieces
   int64_t nb_outer = 1024;  // measured best for N = 4k .. 32k (profiles/r01_f_nb_sweep.txt)
   int64_t lookahead = 1;
@@ -191,6 +192,13 @@ struct tgp_ctx {
   int64_t poll_timeout_ms = 4000;  // wall-clock bound of every device-side wait (chol.hip, PollClock)
   int64_t timeout_retries = 0;     // factorisations repeated on the launch-per-block path after a TGP_E_TIMEOUT
   int64_t chain_pre_wait = 0;  // (measured: no effect at N = 16 384, -3 % at N = 8 192 -- off)
+  // depth-2 schedule (round 6): the next panel's FIRST diagonal block is updated (a 128 x 128 product of its own) and
+  // factored on the idle update stream BESIDE the gate, which skips that block: the one-workgroup potf2 launch waits 50-200 us
+  // for a compute unit while a trailing update fills the chip (rocprofv3: 177 us per launch on average at N = 16 384 against
+  // 27 us of work) -- between the gate and the chain launch, on the chain pipeline.  BUILT, race-checked, MEASURED FLAT
+  // (profiles/r06_b: c2 25.43 / 25.31 vs 25.35 / 25.34 ms, N = 8 192 4.78 vs 4.81): the chain pipeline is not what the
+  // evaluation waits for.  Off.
+  int64_t chain_gate_split = 0;
   int64_t chain_lds_pad = 10240;      // dynamic LDS per chain workgroup that nobody uses: one chain workgroup per CU
   int64_t chain_stamps = 0;           // 1: every chain task records its phases' time stamps (tgp_chain_stamps)
   long long* d_chain_stamps = nullptr;  // CHAIN_STAMP_TASKS x 16, allocated on first use
@@ -239,6 +247,8 @@ inline int64_t trace_event_id(const tgp_ctx* ctx, hipEvent_t ev) {
   if (ev == ctx->ev_g1) return 7;
   if (ev == ctx->ev_g2) return 8;
   if (ev == ctx->ev_h) return 9;
+  if (ev == ctx->ev_i) return 10;
+  if (ev == ctx->ev_j) return 11;
   return -1;
 }
 template <typename T>
