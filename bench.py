@@ -79,7 +79,7 @@ def traced_update_bytes(options: dict, n_pad: int, itemsize: int):
                                            C.byref(n)), "tgp_trace_factor")
     total, launches, flops = 0, 0, 0.0
     for r in out[: n.value * 10].reshape(-1, 10):
-        if r[0] == 3 and (r[8] >> 8) == 0:  # gemm, role 0 (128x128 tiles: the profiled kernel), whatever the stream
+        if r[0] == 3 and ((r[8] >> 8) & 0xFF) == 0:  # gemm, role 0 (128x128 tiles: the profiled kernel; bits 16..: its prefix)
             m, nn, k = int(r[5]), int(r[6]), int(r[7])
             entries = nn * m - nn * (nn - 1) // 2
             total += itemsize * (2 * entries + m * k)

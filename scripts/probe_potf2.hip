@@ -10,6 +10,13 @@ int launch_gemm_nt(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const T*, i
                    int64_t, int, int, int) { return 0; }
 template int launch_gemm_nt<float>(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, int, int, int);
 template int launch_gemm_nt<double>(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, int, int, int);
+template <typename T>
+int launch_gemm_tri(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t, int, int, int,
+                    int64_t, int64_t, int64_t) { return 0; }
+template int launch_gemm_tri<float>(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, int, int, int, int64_t, int64_t, int64_t);
+template int launch_gemm_tri<double>(tgp_ctx*, hipStream_t, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, int, int, int, int64_t, int64_t, int64_t);
+int ensure_solve_stream(tgp_ctx*) { return 0; }
+int ensure_work(tgp_ctx*, size_t) { return 0; }
 }
 int main() {
   const int n = 128;

@@ -18,7 +18,7 @@ from tinygp_amd import _ffi
 NSTREAMS = 5
 EV_G1, EV_G2 = 7, 8  # split gate: column block 1 / column blocks 2.. of the next panel
 KIND = {1: "potf2", 2: "trsm", 3: "gemm", 4: "trsv_step", 5: "record", 6: "wait", 7: "assembly",
-        8: "residual_copy", 9: "reductions", 10: "panel_step", 11: "chain", 12: "chain_poll"}
+        8: "residual_copy", 9: "reductions", 10: "panel_step", 11: "chain", 12: "chain_poll", 13: "prefix_poll"}
 
 
 def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1, wide_rows=0, **more):
@@ -41,7 +41,7 @@ def trace(n_pad, nb=1024, lookahead=1, first_split=5, first_small=1100, fused=1,
     return out[: n.value * 10].reshape(-1, 10).tolist()
 
 
-def accesses(rec, T):
+def accesses(rec, T, part=None):
     """(reads, writes): sets of resources.  ('A', tr, tc) matrix tile, ('D', j) 16x16 inverses
     of block j, ('Y', j) 128 entries of the solved vector."""
     kind, _, *v = rec
@@ -76,8 +76,11 @@ def accesses(rec, T):
         ld = v[7]
         (ar, ac), (brr, bcc), (cr, cc) = tile(v[0], ld), tile(v[1], ld), tile(v[2], ld)
         m, n, k = v[3] // 128, v[4] // 128, v[5] // 128
-        lower, role = v[6] & 0xFF, v[6] >> 8
-        for tj in range(n):
+        lower, role, pfx = v[6] & 0xFF, (v[6] >> 8) & 0xFF, v[6] >> 16
+        # a merged trailing update (round 6) is stepped through in two parts: its PREFIX (the first pfx tile columns, what a
+        # prefix poll waits for) and the rest; `part` = None for an ordinary launch
+        cols = range(n) if part is None else (range(pfx) if part == 0 else range(pfx, n))
+        for tj in cols:
             for ti in range(m):
                 if lower and ti < tj:
                     continue
@@ -85,7 +88,7 @@ def accesses(rec, T):
                     continue  # folded into the next potf2 (3) / updated and factored on the side stream (5)
                 R.add(("A", cr + ti, cc + tj)); W.add(("A", cr + ti, cc + tj))
         R |= {("A", ar + ti, ac + kk) for ti in range(m) for kk in range(k)}
-        R |= {("A", brr + tj, bcc + kk) for tj in range(n) for kk in range(k)}
+        R |= {("A", brr + tj, bcc + kk) for tj in cols for kk in range(k)}
     elif kind == 10:  # fused panel step: potf2 (has_p) + per row tile below: pending update, trsm
         ld, m, has_p = v[3], v[2] // 128, v[4]
         tr, tc = tile(v[0], ld)
@@ -188,6 +191,23 @@ def find_races(recs, T, limit=5):
             assert key in snap, ("poll without a chain launch in front of it (host order)", rec)
             clock[s] = [max(a, b) for a, b in zip(clock[s], snap[key])]
             continue
+        if kind == 13:  # one-wave poll: this stream continues once the PREFIX of the merged update at `off` is complete
+            key = ("prefix", rec[2])
+            assert key in snap, ("prefix poll without its update in front of it (host order)", rec)
+            clock[s] = [max(a, b) for a, b in zip(clock[s], snap[key])]
+            continue
+        if kind == 3 and (rec[8] >> 16) > 0:  # merged trailing update: the prefix, then the rest
+            for part in (0, 1):
+                clock[s][s] += 1
+                now = list(clock[s])
+                me = (s, now[s], idx)
+                R, W = accesses(rec, T, part)
+                check_and_register(R, W, now, me, idx)
+                if part == 0:
+                    snap[("prefix", rec[4])] = list(clock[s])
+            if len(races) >= limit:
+                break
+            continue
         if kind == 11:
             # the launch makes its block columns final one after the other; a poller waits for ONE of them: step
             # through the columns, each with its own tick and its own snapshot for the pollers
@@ -286,6 +306,13 @@ CONFIGS = [
 ]
 
 
+# round 6: the default schedule with the persistent chain is the MERGED trailing update (one launch per panel, the next
+# panel's block column first, its chain behind a prefix poll); every chain configuration above is also run on round 5's
+# depth-2 schedule (gate | pre | rest)
+CONFIGS += [c[:7] + (dict(c[7], chain_merged=0),) for c in CONFIGS
+            if len(c) > 7 and c[7].get("chain_kernel") and "chain_merged" not in c[7]]
+
+
 def _cfg_id(c):
     s = f"n{c[0]}-nb{c[1]}-la{c[2]}-fs{c[3]}-st{c[4]}-f{c[5]}" + (f"-wide{c[6]}" if len(c) > 6 and c[6] else "")
     return s + ("".join(f"-{k}{v}" for k, v in c[7].items()) if len(c) > 7 else "")
@@ -357,7 +384,7 @@ def test_checker_sees_a_missing_join_of_the_split_gate():
     """chain_gate_split: the next panel's first diagonal block is updated and factored on the update stream beside the gate.
     Without the event that makes the side stream wait for the gate's inputs, or the one that joins it in front of the chain
     launch, the checker must report the race."""
-    recs = trace(16384, 1024, 1, 5, 1100, 3, 0, chain_kernel=1, chain_gate_split=1)
+    recs = trace(16384, 1024, 1, 5, 1100, 3, 0, chain_kernel=1, chain_gate_split=1, chain_merged=0)
     T = 16384 // 128
     assert any(r[0] == 3 and r[1] == 3 for r in recs) and any(r[0] == 1 and r[1] == 3 for r in recs)  # product + potf2 on stream 3
     assert find_races(recs, T) == []
@@ -367,12 +394,32 @@ def test_checker_sees_a_missing_join_of_the_split_gate():
         assert find_races(dropped, T), ev
 
 
+def test_checker_sees_a_missing_prefix_poll_of_the_merged_update():
+    """The merged trailing update (round 6): the chain of the next panel starts behind a one-wave poll of the update's
+    PREFIX (that panel's block column) while the rest of the launch still runs.  Without the poll, or without the wait that
+    keeps the next update behind that chain, the checker must report the race; the poll must follow its update in host
+    order."""
+    recs = trace(16384, 1024, 1, 5, 1100, 3, 0, chain_kernel=1)
+    T = 16384 // 128
+    merged = [r for r in recs if r[0] == 3 and (r[8] >> 16) > 0]
+    polls = [r for r in recs if r[0] == 13]
+    assert len(merged) == len(polls) == 11 and all((r[8] >> 8) & 0xFF == 0 and r[1] == 0 for r in merged)
+    assert not any(r[0] == 3 and (r[8] >> 8) & 0xFF in (4, 5) for r in recs)  # no 64 x 64-tile launch is left
+    assert find_races(recs, T) == []
+    assert find_races([r for r in recs if r[0] != 13], T)                      # chain of panel p+1 beside its own columns' update
+    no_chain_wait = [r for r in recs if not (r[0] == 6 and r[1] == 0 and r[2] in (1, 7))]  # main waits ev_chain (ev_b / ev_g1)
+    assert len(no_chain_wait) < len(recs) and find_races(no_chain_wait, T)
+    # the tail (the last panel covers every remaining column) waits for the WHOLE update: no poll for it
+    last = [r for r in recs if r[0] == 3][-1]
+    assert (last[8] >> 16) == 0
+
+
 def test_checker_sees_a_missing_poll_of_the_persistent_chain():
     """Persistent chain: the forward-substitution step of block j and the early share of the next block-column
     update start behind a one-wave poll of block column j's count of final tiles while the launch still runs.
     Without the polls (or without the event that keeps a poller behind the zeroing of the counters, or the one that
     keeps the next launch's zeroing behind the last poller) the checker must report the race / refuse the order."""
-    recs = trace(5120, 1024, 1, 5, 1100, 3, 0, chain_kernel=1, chain_full_rows=0, chain_fwd_tasks=0)
+    recs = trace(5120, 1024, 1, 5, 1100, 3, 0, chain_kernel=1, chain_full_rows=0, chain_fwd_tasks=0, chain_merged=0)
     T = 5120 // 128
     assert find_races(recs, T) == []
     polls = [r for r in recs if r[0] == 12]
@@ -411,8 +458,14 @@ def test_bench_accounting_comes_from_the_launch_records():
     _, launches, flops = bench.traced_update_bytes(dict(chain_kernel=0), 16384, 8)  # the per-block chain's schedule
     assert launches == 14
     assert 1.0e12 < flops < 16384**3 / 3  # the rest of the N^3 / 3 runs on the 64 x 64-tile kernel (gates, in-panel)
-    # library defaults (persistent chain, depth-2 schedule, the last 4 096 rows ONE chain launch): the ten `rest`
-    # updates of panels 0..9; gates and pre-updates have at most 1 100 tiles and run on the 64 x 64-tile kernel
-    _, launches, flops = bench.traced_update_bytes({}, 16384, 8)
+    # round 5's depth-2 schedule (persistent chain, the last 4 096 rows ONE chain launch): the ten `rest` updates of panels
+    # 0..9; gates and pre-updates have at most 1 100 tiles and run on the 64 x 64-tile kernel
+    _, launches, flops = bench.traced_update_bytes(dict(chain_merged=0), 16384, 8)
     assert launches == 10
     assert 0.8e12 < flops < 16384**3 / 3  # (less than the per-block schedule: the last 4 096 rows are chain tasks)
+    # library defaults (round 6): ONE merged update per panel 0..11 on the 128 x 128-tile kernel -- every flop of the
+    # factorisation outside the chain launches: sum over panels of m^2 nb with m = the rows right of the panel
+    _, launches, flops = bench.traced_update_bytes({}, 16384, 8)
+    assert launches == 12
+    want = sum(2.0 * (m * m - m * (m - 1) // 2) * 1024 for m in range(16384 - 1024, 4096 - 1, -1024))
+    assert flops == want and 1.2e12 < flops < 16384**3 / 3

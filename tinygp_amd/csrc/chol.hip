@@ -451,6 +451,8 @@ constexpr int CHAIN_XSTEP_OFF = 160;  // [160 + c] column blocks of X_{c,c-1} co
 constexpr int CHAIN_ZFLAG_OFF = 224;   // [224 + c] z_c = L_cc^-1 y_c is in memory (forward substitution as tasks: fsolve -> fupdate)
 constexpr int CHAIN_YSTATE_OFF = 288;  // [288 + g] block columns of this launch applied to the rows of group g of y
 constexpr int CHAIN_TICKET_WORDS = CHAIN_YSTATE_OFF + int(CHAIN_MAX_ROW_TILES) / CHAIN_FWD_GROUP;
+// (outside the words a chain launch zeroes) [CHAIN_PREFIX_OFF + q]: finished prefix tiles of the merged trailing update q & 3
+constexpr int CHAIN_PREFIX_OFF = CHAIN_TICKET_WORDS + 16;
 
 template <typename T>
 struct ChainArgs {
@@ -2415,6 +2417,18 @@ int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, 
   return TGP_OK;
 }
 
+// `st` continues once the PREFIX (the next panel's block column: `target` tiles) of the merged trailing update that is
+// running (or queued) on the main stream is complete (gemm.hip, GemmArgs::prefix_done).  Bounded like every poll.
+int launch_prefix_poll(tgp_ctx* ctx, hipStream_t st, const int32_t* counter, int64_t target, int64_t c_off, int64_t ld) {
+  if (ctx->trace) {  // v: C offset of the update the poll belongs to, ld
+    trace_push(ctx, 13, st, c_off, ld);
+    return TGP_OK;
+  }
+  hipLaunchKernelGGL(chain_poll_kernel, dim3(1), dim3(64), 0, st, counter, (int32_t)target, ctx->d_info);
+  TGP_HIP_TRY(hipGetLastError());
+  return TGP_OK;
+}
+
 template <typename T>
 int compute_dinv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* dinv) {
   if (n == 0) return TGP_OK;
@@ -2710,6 +2724,62 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     return rem < w ? rem : w;
   };
   const bool la = ctx->lookahead != 0 && S1 != nullptr;
+  if (la && ctx->chain_kernel != 0 && ctx->chain_merged != 0) {
+    // MERGED TRAILING UPDATE (round 6).  Panel p updates EVERYTHING to its right in ONE launch of the 128 x 128-tile kernel,
+    //   T(p):  A[next.., next..] -= P_p P_p^T   (lower, K = the panel's width),
+    // whose tile ids start with the block column of panel p+1 (the PREFIX: stored write-through and counted, gemm.hip); the
+    // priority stream's chain of panel p+1 follows a one-wave poll of that count -- it runs beside the rest of T(p), and
+    // T(p+1) waits for it.  The depth-2 schedule below cuts the same work into gate(p) | pre(p) | rest(p): two of the three on
+    // the 64 x 64-tile kernel (a third of the flops at a lower MFMA duty), 26 launch ramps on the main stream instead of 13,
+    // the next gate queued behind a whole rest(p-1).  The last panel (the one-launch tail) needs the whole update: no prefix.
+    std::vector<int64_t> s0;
+    for (int64_t k0 = 0; k0 < n; k0 += width(k0)) s0.push_back(k0);
+    s0.push_back(n);
+    const int64_t P = (int64_t)s0.size() - 1;
+    hipEvent_t ev_chain[2] = {ctx->ev_b, ctx->ev_g1}, ev_pfx[2] = {ctx->ev_g2, ctx->ev_e}, ev_T[2] = {ctx->ev_i, ctx->ev_j};
+    const bool asm_side = ctx->asm_pending;  // columns right of the first panel are still being assembled
+    ctx->asm_pending = false;
+    TGP_TRY(ev_record(ctx, ctx->ev_a, S0));
+    TGP_TRY(st_wait(ctx, S1, ctx->ev_a));
+    TGP_TRY(panel(S1, 0, s0[1] - s0[0], false, 0, no_mid));
+    TGP_TRY(run_deferred_asm(ctx, nullptr));
+    TGP_TRY(ev_record(ctx, ev_chain[0], S1));
+    for (int64_t p = 0; p + 1 < P; ++p) {
+      const int64_t kb = s0[p + 1] - s0[p], next = s0[p + 1], wn = s0[p + 2] - s0[p + 1], mt = n - next;
+      const T* Pp = A + s0[p] * ld + next;
+      T* C = A + next * ld + next;
+      // main stream: T(p), behind chain(p) (and T(p-1), by stream order)
+      TGP_TRY(st_wait(ctx, S0, ev_chain[p & 1]));
+      if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S0, ctx->ev_asm));
+      // the chain of panel p+1 behind the prefix -- unless it covers every column (the tail), the poll is switched off
+      // (chain_polls = 0: the default under a counter-collecting profiler, which runs kernels one at a time)
+      const bool prefix = wn < mt && ctx->chain_polls != 0;
+      int32_t* counter = ctx->d_chain_ticket + CHAIN_PREFIX_OFF + (p & 3);
+      if (prefix) {
+        if (!ctx->trace) TGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int32_t), S0));
+        TGP_TRY(ev_record(ctx, ev_pfx[p & 1], S0));  // (the counter is zero: the poller may start)
+        ctx->prefix_hint_cols = wn;
+        ctx->prefix_hint_counter = counter;
+      }
+      const int64_t t = mt / TILE;
+      if (t * (t + 1) / 2 <= ctx->reserve_max_tiles) ctx->reserve_hint = ctx->chain_reserve;
+      TGP_TRY(trailing(S0, mt, mt, kb, Pp, C, 0));
+      if (!prefix) TGP_TRY(ev_record(ctx, ev_T[p & 1], S0));
+      // priority stream: potf2 + chain of panel p+1
+      if (prefix) {
+        const int64_t tm = mt / TILE, tp = wn / TILE;
+        TGP_TRY(st_wait(ctx, S1, ev_pfx[p & 1]));
+        TGP_TRY(launch_prefix_poll(ctx, S1, counter, tp * tm - tp * (tp - 1) / 2, trace_off(ctx, C), ld));
+      } else {
+        TGP_TRY(st_wait(ctx, S1, ev_T[p & 1]));
+      }
+      if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S1, ctx->ev_asm));
+      TGP_TRY(potf2_at(S1, next, false));
+      TGP_TRY(panel(S1, next, wn, true, 0, no_mid));
+      TGP_TRY(ev_record(ctx, ev_chain[(p + 1) & 1], S1));
+    }
+    TGP_TRY(st_wait(ctx, S0, ev_chain[(P - 1) & 1]));
+  } else
   if (la && ctx->chain_kernel != 0 && ctx->chain_depth2 != 0) {
     // Persistent chain, depth-2 schedule: the CHAIN PIPELINE -- gate(p): panel p applied to the columns of panel
     // p+1, then potf2 + the chain launch of panel p+1 -- lives on the priority stream and depends on the main stream

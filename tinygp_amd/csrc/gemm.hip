@@ -86,6 +86,12 @@ struct GemmArgs {
   int batch;
   int64_t sA, sB, sC;
   int band;  // tile order: 0 column by column, > 0 bands of that many tile rows (tile_order.h; ctx option tile_band)
+  // PREFIX (round 6, the merged trailing update of potrf): the first `prefix_tn` tile columns of a lower update -- the next
+  // panel's block column -- take the lowest `prefix_cnt` workgroup ids, are stored WRITE-THROUGH and counted in *prefix_done
+  // (one increment per finished tile, behind a drained barrier): a one-wave poll on another stream lets that panel's chain
+  // start while the rest of THIS launch still runs.  0: no prefix.
+  int prefix_tn, prefix_cnt;
+  int32_t* prefix_done;
 };
 
 // Linear workgroup id -> (ti, tj): tile_order.h (shared with the CPU test hook).  band == 0: column by column (tj major) so
@@ -142,10 +148,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     nsl = g.split_s;
     bid = g.split_first + tail_idx;
   }
+  // (with a prefix the two ranges of ids are remapped each within itself: the prefix must spread over ALL XCDs)
+  const bool in_prefix = g.prefix_cnt > 0 && bid < g.prefix_cnt;
   {
-    const int nx = 8, q = g.nblk / nx, r = g.nblk % nx;
-    const int xcd = bid % nx, idx = bid / nx;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int base = g.prefix_cnt > 0 ? (in_prefix ? 0 : g.prefix_cnt) : 0;
+    const int cnt = g.prefix_cnt > 0 ? (in_prefix ? g.prefix_cnt : g.nblk - g.prefix_cnt) : g.nblk;
+    const int loc = bid - base;
+    const int nx = 8, q = cnt / nx, r = cnt % nx;
+    const int xcd = loc % nx, idx = loc / nx;
+    bid = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   int ti, tj, gt;
   const T* gA = g.A;
@@ -187,6 +198,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
   } else
   if (g.dG > 0) {
     decode_tile_dist<T>(bid, g, ti, tj, gt);
+  } else if (g.prefix_cnt > 0) {
+    if (in_prefix) {  // the first prefix_tn tile columns (rows from the diagonal down), band order among themselves
+      decode_tile(bid, g.tm, g.prefix_tn, 1, ti, tj, g.band);
+    } else {          // the lower triangle right of them, shifted
+      decode_tile(bid - g.prefix_cnt, g.tm - g.prefix_tn, g.tn - g.prefix_tn, 1, ti, tj, g.band);
+      ti += g.prefix_tn;
+      tj += g.prefix_tn;
+    }
+    gt = tj;
   } else {
     decode_tile(bid, g.tm, g.tn, g.lower, ti, tj, g.band);
     gt = tj;
@@ -390,6 +410,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
       }
     } else
     if (pipe) {
+      if (ROLE == 0 && in_prefix) {
+        // write-through (sc1: what an agent-scope relaxed store emits), base + 32-bit lane offset as everywhere here; then
+        // every wave drains, a barrier, ONE lane counts the tile (Guideline 16, form R1 -- the consumer is a kernel that
+        // starts behind a poll of this counter, its start is the acquire)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const char* cb = Cu + (int64_t(a * 16) * g.ldc + b * 16) * 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(voff[t]), "v"(acc[a][b][t]), "s"(cb) : "memory");
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(g.prefix_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -398,6 +436,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) *reinterpret_cast<double*>(cb + voff[t]) = acc[a][b][t];
         }
+      }
       }
     } else if (g.mode == 0) {
       // short k: the read-modify-write is batched: 32 independent loads in flight, then 32
@@ -541,12 +580,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = -acc[a][b];
     }
+    if (ROLE == 0 && in_prefix) {  // (see the fp64 path)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(centry(a, b, r)), __float_as_uint(acc[a][b][r]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(g.prefix_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) *centry(a, b, r) = acc[a][b][r];
+    }
   }
   }  // tiles of this workgroup
 }
@@ -861,8 +914,13 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
                 (long long)m, (long long)n, (long long)k);
   if (m == 0 || n == 0) return TGP_OK;
   if (ctx->trace) {  // v: A, B, C offsets, m, n, k, lower | role << 8, ld (all operands share it)
+    // (bits 16..: tile columns of the PREFIX of a merged trailing update -- the hints are consumed here as in a real launch)
+    const int64_t pfx = role == 0 ? ctx->prefix_hint_cols / BN : 0;
+    ctx->prefix_hint_cols = 0;
+    ctx->prefix_hint_counter = nullptr;
+    if (role == 0) ctx->reserve_hint = 0;
     trace_push(ctx, 3, st, trace_off(ctx, A), trace_off(ctx, B), trace_off(ctx, C), m, n, k,
-               int64_t(lower) | (int64_t(role) << 8), ldc);
+               int64_t(lower) | (int64_t(role) << 8) | (pfx << 16), ldc);
     return TGP_OK;
   }
   GemmArgs<T> g;
@@ -871,6 +929,8 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   g.split_first = 0; g.split_s = 1; g.ngrid = 0; g.ws = nullptr; g.cnt = nullptr;
   g.batch = 1; g.sA = g.sB = g.sC = 0;
   g.band = (int)ctx->tile_band;
+  g.prefix_tn = g.prefix_cnt = 0;
+  g.prefix_done = nullptr;
   TGP_ARG_CHECK(role != 3 || (k <= 256 && mode == 0), "role 3 needs the small-tile path");
   // short-K updates, and (role 4) a latency-bound update with too few big tiles to fill the chip
   // role 5 (round 6): role 4 without the first 128 x 128 diagonal block -- the gate of the next panel while that block is
@@ -903,12 +963,22 @@ int launch_gemm_nt(tgp_ctx* ctx, hipStream_t st, int64_t m, int64_t n, int64_t k
   }
   const int64_t reserve = role == 0 ? ctx->reserve_hint : 0;
   ctx->reserve_hint = 0;
+  if (role == 0 && ctx->prefix_hint_cols > 0) {  // the merged trailing update: the next panel's block column first (see GemmArgs)
+    TGP_ARG_CHECK(lower && mode == 0 && m == n && ctx->prefix_hint_cols % BN == 0 && ctx->prefix_hint_cols < n &&
+                      k / BK >= 8 && ctx->prefix_hint_counter != nullptr,
+                  "gemm_nt: a prefix needs a lower square update with at least 128 k-columns");
+    g.prefix_tn = int(ctx->prefix_hint_cols / BN);
+    g.prefix_cnt = tile_count(g.tm, g.prefix_tn, 1);
+    g.prefix_done = ctx->prefix_hint_counter;
+  }
+  ctx->prefix_hint_cols = 0;
+  ctx->prefix_hint_counter = nullptr;
   g.split_first = g.nblk; g.split_s = 1; g.ngrid = g.nblk; g.ws = nullptr; g.cnt = nullptr;
   // Split tail (option split_tail, fp64 trailing updates on the main stream that run one workgroup per tile): the
   // launch's last round of tiles fills R < slots workgroup slots for the duration of a full k-loop (250 us at
   // K = 1024) -- up to 24 % of a 3-round launch at N = 16 384.  Those R tiles are given S = 2, 4 or 8 workgroups
   // each, over 1 / S of the k-range, so that the last round is R S <= slots short workgroups.
-  if (ctx->split_tail != 0 && role == 0 && mode == 0 && reserve <= 0 && sizeof(T) == 8 && st == ctx->stream) {
+  if (ctx->split_tail != 0 && role == 0 && mode == 0 && reserve <= 0 && sizeof(T) == 8 && st == ctx->stream && g.prefix_cnt == 0) {
     const int slots = 2 * (ctx->cus > 0 ? ctx->cus : 256);
     const int R = g.nblk % slots, nkt = g.k / BK;
     int S = 1;

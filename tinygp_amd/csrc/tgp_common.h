@@ -127,6 +127,8 @@ struct tgp_ctx {
   int64_t split_tail = 0;  // trailing update: the last, partly filled round of tiles is split along k (gemm.hip)
   int64_t gemm_role = 1;     // role tgp_gemm_nt launches with (measurement hook: 4 = the 64x64-tile kernel at any k)
   int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
+  int64_t prefix_hint_cols = 0;             // ... the same for the merged trailing update's prefix (gemm.hip, GemmArgs)
+  int32_t* prefix_hint_counter = nullptr;
   uint32_t* d_step_flag = nullptr;  // the flag potf2's workgroup publishes; value = step_epoch of the launch
   uint32_t step_epoch = 0;
   // persistent panel chain (chol.hip, chain_kernel): ONE launch per panel (two with an early share) factors its
@@ -160,6 +162,9 @@ struct tgp_ctx {
   int64_t chain_full_rows = 4096;     // with at most this many rows left the WHOLE rest is one chain launch (measured
                                       // at N = 16 384: 4096 26.6 ms, 6144 26.9, 8192 27.6; per-block chain 28.2)
   int64_t chain_depth2 = 1;           // gate + chain of the next panel on the priority stream, two panels ahead
+  // round 6: ONE trailing-update launch per panel on the 128 x 128-tile kernel, the next panel's block column first
+  // (write-through, counted), the next chain behind a one-wave poll of that count (chol.hip, potrf)
+  int64_t chain_merged = 1;
   // depth-2 schedule, chain-bound panels (the big update has at most reserve_max_tiles tiles): pre(p) starts behind
   // the next panel's first potf2 -- issued at once it fills every compute unit with three 48-KB workgroups, and the
   // one-workgroup potf2 (74 KB) on the chain pipeline waited 120-290 us for room (profiles/r04_c)
@@ -354,6 +359,7 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
                  int64_t nblk, int64_t cb, int64_t ce, bool head_done, hipEvent_t counters_ready = nullptr,
                  T* y0 = nullptr, bool fprev = false);
 int launch_chain_poll(tgp_ctx* ctx, hipStream_t st, const void* A0, int64_t ld, int64_t R, int64_t c, bool first_external);
+int launch_prefix_poll(tgp_ctx* ctx, hipStream_t st, const int32_t* counter, int64_t target, int64_t c_off, int64_t ld);
 int set_poll_limit(tgp_ctx* ctx, int64_t ms);
 int64_t poll_limit_ms();  // the process-wide value behind every context's "poll_timeout_ms"
 int join_bounded(tgp_ctx* ctx, hipStream_t st, int64_t n);
