@@ -6,6 +6,8 @@ Tolerances: log-likelihood 1e-8 relative (BASELINE.json north_star); posterior m
 variance / covariance rtol = atol = 5e-7, the reference's fp64 tolerance
 (src/tinygp/test_utils.py:16); fp32 5e-4 (:15).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -446,6 +448,45 @@ def test_a_timed_out_hand_off_is_released_and_the_pass_repeated_on_the_per_block
     want2 = float(o.GaussianProcess(1.2**2 * o.ExpSquared(2.0), X, diag=0.01).log_probability(y))
     np.testing.assert_allclose(gp.solver.log_probability(y), want2, rtol=LL_RTOL)
     assert ctx.get_option("timeout_retries") == before + 1
+
+
+@pytest.mark.parametrize("env", [dict(AMD_SERIALIZE_KERNEL="3"), dict(TGP_SERIALIZED_KERNELS="1"), dict(TGP_HIP_OPTIONS="chain_merged=0")],
+                         ids=["AMD_SERIALIZE_KERNEL=3", "serialising-tool-defaults", "depth-2-schedule"])
+def test_kernel_serialising_environments_give_the_same_bits_without_a_timeout(env):
+    """The default schedule hangs two kinds of work on device-side polls: the tasks of a chain launch (inside ONE launch)
+    and -- round 6 -- the next chain behind the PREFIX of the merged trailing update (a one-wave poll kernel on the priority
+    stream).  A runtime that serialises kernels (AMD_SERIALIZE_KERNEL=3: every launch completes before the next is
+    submitted) or a tool that runs them one at a time in an order of its own (a context created under such a tool defaults
+    to chain_polls = 0: the next chain behind the WHOLE update) must still give the same bits, and no wait may run into
+    poll_timeout_ms.  Also: round 5's depth-2 schedule against the merged one (the same updates cut differently: 1e-12)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    code = ("import time, numpy as np\n"
+            "from tinygp_amd import kernels, noise, synthetic, _ffi\n"
+            "from tinygp_amd.solvers import DirectSolver\n"
+            "X, y = synthetic.make_inputs(8192, 1)\n"
+            "s = DirectSolver(1.5**2 * kernels.ExpSquared(2.5), X, noise.Diagonal(np.full(8192, 0.01)))\n"
+            "s.set_residual(y)\n"
+            "s.factor_log_probability(None, 1.5**2 * kernels.ExpSquared(2.5))\n"
+            "t0 = time.perf_counter()\n"
+            "v = s.factor_log_probability(None, 1.4**2 * kernels.ExpSquared(2.2))\n"
+            "print('RESULT', repr(float(v)), time.perf_counter() - t0, _ffi.default_ctx().get_option('timeout_retries'))\n")
+    out = {}
+    for name, e in (("plain", {}), ("env", env)):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(root), timeout=600,
+                           env=dict(os.environ, PYTHONPATH=str(root), **e))
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stdout[-1000:] + r.stderr[-2000:]
+        _, val, secs, retries = line[0].split()
+        out[name] = (val, float(secs), int(retries))
+    if "TGP_HIP_OPTIONS" in env:  # another cut of the same updates (64 x 64 tiles for two of three): equal to rounding
+        np.testing.assert_allclose(float(out["env"][0]), float(out["plain"][0]), rtol=1e-12)
+    else:
+        assert out["env"][0] == out["plain"][0]      # the same launches in another order of execution: bit-identical
+    assert out["env"][2] == 0 and out["env"][1] < 1.0  # no hand-off timed out (poll_timeout_ms is 4 s), no retry
 
 
 def test_poll_timeout_option_round_trips_and_rejects_nonsense():

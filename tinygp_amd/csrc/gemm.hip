@@ -90,8 +90,8 @@ struct GemmArgs {
   // panel's block column -- take the lowest `prefix_cnt` workgroup ids, are stored WRITE-THROUGH and counted in *prefix_done
   // (one increment per finished tile, behind a drained barrier): a one-wave poll on another stream lets that panel's chain
   // start while the rest of THIS launch still runs.  0: no prefix.
-  int prefix_tn, prefix_cnt;
-  int32_t* prefix_done;
+  int prefix_tn = 0, prefix_cnt = 0;  // (default member initialisers: every launcher that fills a GemmArgs by hand gets "none")
+  int32_t* prefix_done = nullptr;
 };
 
 // Linear workgroup id -> (ti, tj): tile_order.h (shared with the CPU test hook).  band == 0: column by column (tj major) so
