@@ -166,6 +166,8 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "nb_first"          width of the first panel, whose chain nothing hides (0: nb_outer)
  *   "split_tail"        1: the last, partly filled round of tiles of a trailing update is split along k
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
+ *   "late_join"         1 (default, round 6): a fused evaluation joins the device ONCE -- the potrf `info` comes back with the two
+ *                       scalars behind the reductions (0: a join behind the factorisation and another behind the reductions)
  *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming
  *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block;
  *                       "trsv_groups" (0 = by size: 3 / 4 / 6): workgroups per block row of the forward launch -- G - 1

@@ -321,6 +321,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "split_tail")) return &ctx->split_tail;
   if (!strcmp(key, "gemm_role")) return &ctx->gemm_role;
   if (!strcmp(key, "host_join")) return &ctx->host_join;
+  if (!strcmp(key, "late_join")) return &ctx->late_join;
   if (!strcmp(key, "asm_defer")) return &ctx->asm_defer;
   if (!strcmp(key, "tile_band")) return &ctx->tile_band;
   if (!strcmp(key, "fault_inject")) return &ctx->fault_inject;
@@ -733,7 +734,10 @@ static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void*
     }
     if (prof) TGP_HIP_TRY(hipEventRecord(e1, ctx->stream));
     int32_t inf = 0;
+    ctx->defer_join = ctx->late_join != 0;  // (one host round trip per evaluation: `info` comes back with the scalars below)
+    ctx->join_deferred = false;
     int st = potrf<T>(ctx, s->npad, A, s->npad, (T*)s->dinv, &inf, fused ? (T*)s->vec : (T*)nullptr);
+    ctx->defer_join = false;
     if (st < 0) return st;
     s->info = inf;
     if (prof) TGP_HIP_TRY(hipEventRecord(e2, ctx->stream));
@@ -743,8 +747,20 @@ static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void*
   });
   if (status < 0) return status;
   double two[2] = {0, 0};
+  int32_t inf_late = 0;
+  const bool late = ctx->join_deferred;
+  ctx->join_deferred = false;
   TGP_HIP_TRY(hipMemcpyAsync(two, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (late) TGP_HIP_TRY(hipMemcpyAsync(&inf_late, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   TGP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (late) {  // what potrf does behind its own join: a timed-out hand-off is an error (retried by factor_impl), a pivot is `info`
+    if (inf_late == INT32_MIN) {
+      tgp::set_error("potrf: a device-side hand-off did not arrive within poll_timeout_ms (a lost or starved chain launch)");
+      if (prof) { hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2); }
+      return TGP_E_TIMEOUT;
+    }
+    s->info = inf_late;
+  }
   s->ms[5] = std::chrono::duration<double, std::milli>(ctx->submitted - host0).count();  // (potrf's last enqueue)
   s->logdet_half = two[1];
   if (fused && logprob)

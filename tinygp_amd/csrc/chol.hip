@@ -2982,6 +2982,16 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   }
   int32_t info = 0;
   ctx->submitted = std::chrono::steady_clock::now();
+  // Round 6: the fused evaluation (capi.hip, factor_body) reads `info` together with its two scalars behind the reductions
+  // it queues next -- ONE host round trip per evaluation instead of two (the first cost ~35 us between the last chain task
+  // and the first reduction: 8 % of an evaluation at N = 1 024).  It asks for that with ctx->defer_join; profiled passes
+  // (event pairs are read below) and passes with stream wait-values in flight (joined with a deadline) keep the join here.
+  if (ctx->defer_join && !ctx->trace && !prof_on && !(ctx->wait_values_inflight && ctx->host_join != 0)) {
+    ctx->wait_values_inflight = false;
+    ctx->join_deferred = true;
+    if (info_host) *info_host = 0;
+    return TGP_OK;
+  }
   if (!ctx->trace) {
     TGP_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, S0));
     if (ctx->wait_values_inflight && ctx->host_join != 0) {

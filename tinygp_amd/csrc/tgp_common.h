@@ -126,6 +126,9 @@ struct tgp_ctx {
   int64_t nb_first = 0;    // width of the FIRST panel, whose chain nothing hides (0: nb_outer)
   int64_t split_tail = 0;  // trailing update: the last, partly filled round of tiles is split along k (gemm.hip)
   int64_t gemm_role = 1;     // role tgp_gemm_nt launches with (measurement hook: 4 = the 64x64-tile kernel at any k)
+  int64_t late_join = 1;       // fused evaluation: ONE host join per evaluation, `info` read with the scalars (0: round 5's two)
+  bool defer_join = false;     // set by the fused evaluation around its potrf call: do not join, `info` is read with the scalars
+  bool join_deferred = false;  // ... and potrf's answer: it did leave the join (and the check of d_info) to the caller
   int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
   int64_t prefix_hint_cols = 0;             // ... the same for the merged trailing update's prefix (gemm.hip, GemmArgs)
   int32_t* prefix_hint_counter = nullptr;
