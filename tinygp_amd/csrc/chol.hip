@@ -2739,6 +2739,12 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     hipEvent_t ev_chain[2] = {ctx->ev_b, ctx->ev_g1}, ev_pfx[2] = {ctx->ev_g2, ctx->ev_e}, ev_T[2] = {ctx->ev_i, ctx->ev_j};
     const bool asm_side = ctx->asm_pending;  // columns right of the first panel are still being assembled
     ctx->asm_pending = false;
+    if (P == 1 && !asm_side) {
+      // the whole matrix is ONE chain launch (N <= chain_full_rows): nothing to run beside it -- on the main stream, without the
+      // two cross-stream event hops (12 + 17 us of the 0.42-ms evaluation at N = 1 024: profiles/r06_h)
+      TGP_TRY(panel(S0, 0, s0[1] - s0[0], false, 0, no_mid));
+      TGP_TRY(run_deferred_asm(ctx, nullptr));
+    } else {
     TGP_TRY(ev_record(ctx, ctx->ev_a, S0));
     TGP_TRY(st_wait(ctx, S1, ctx->ev_a));
     TGP_TRY(panel(S1, 0, s0[1] - s0[0], false, 0, no_mid));
@@ -2779,6 +2785,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       TGP_TRY(ev_record(ctx, ev_chain[(p + 1) & 1], S1));
     }
     TGP_TRY(st_wait(ctx, S0, ev_chain[(P - 1) & 1]));
+    }
   } else
   if (la && ctx->chain_kernel != 0 && ctx->chain_depth2 != 0) {
     // Persistent chain, depth-2 schedule: the CHAIN PIPELINE -- gate(p): panel p applied to the columns of panel
