@@ -168,6 +168,8 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "profile"           1: time the trailing-update launches with events (tgp_solver_timings)
  *   "late_join"         1 (default, round 6): a fused evaluation joins the device ONCE -- the potrf `info` comes back with the two
  *                       scalars behind the reductions (0: a join behind the factorisation and another behind the reductions)
+ *   "chain_reduce"      1 (default, round 6): the fused evaluation's two reductions (sum z^2, sum log L_ii) are left by the chain
+ *                       launches' forward-substitution tasks, block by block in a fixed order (0: two reduction launches)
  *   "stream_trsv"       1 (default): triangular solves on a resident factor run as ONE streaming
  *                       launch (chol.hip, trsv_fwd/bwd_stream_kernel); 0: one launch pair per block;
  *                       "trsv_groups" (0 = by size: 3 / 4 / 6): workgroups per block row of the forward launch -- G - 1

@@ -583,6 +583,34 @@ def test_multi_stream_schedule_is_deterministic(n, reps, fwd_tasks):
         ctx.set_option("chain_fwd_tasks", keep)
 
 
+@pytest.mark.parametrize("n", [100, 128, 1000, 4096, 5000, 9000])
+def test_reductions_left_by_the_chain_match_the_reduction_kernels(n):
+    """Round 6: the fused evaluation's two sums (z.z and sum log L_ii) come from the chain launches' forward-substitution
+    tasks -- per-block partial sums in a fixed tree, added up by the task of the matrix's last block -- instead of two
+    reduction launches (ctx option chain_reduce).  Both orders are fixed; they differ in rounding only, and both match the
+    oracle (reference gp.py:313-320)."""
+    from tinygp_amd import _ffi
+
+    ctx = _ffi.default_ctx()
+    X, y = _cases.synthetic.make_inputs(n, 1)
+    k = 1.5**2 * kernels.ExpSquared(2.5)
+    got = {}
+    for mode in (1, 0):
+        keep = ctx.set_option("chain_reduce", mode)
+        try:
+            solver = DirectSolver(k, X, noise.Diagonal(np.full(n, 0.01)))
+            solver.set_residual(y)
+            got[mode] = [float(solver.factor_log_probability(None, k)) for _ in range(3)]
+            assert got[mode][0] == got[mode][1] == got[mode][2]
+            # ... and the resident factor's own value (separate solve + reductions)
+            np.testing.assert_allclose(float(solver.log_probability(y)), got[mode][0], rtol=1e-12)
+        finally:
+            ctx.set_option("chain_reduce", keep)
+    np.testing.assert_allclose(got[1][0], got[0][0], rtol=1e-13)
+    want = float(o.GaussianProcess(1.5**2 * o.ExpSquared(2.5), X, diag=0.01).log_probability(y))
+    np.testing.assert_allclose(got[1][0], want, rtol=LL_RTOL)
+
+
 def _deterministic_evaluations(n, reps):
     X, y = _cases.synthetic.make_inputs(n, 1)
     ks = [1.5**2 * kernels.ExpSquared(2.5), 1.4**2 * kernels.ExpSquared(2.2)]

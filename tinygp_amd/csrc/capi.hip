@@ -219,6 +219,7 @@ int tgp_ctx_create(int device, void* stream, tgp_ctx** out) {
   TGP_HIP_TRY(hipMemset(ctx->d_chain_flags, 0, size_t(tgp::CHAIN_MAX_ROW_TILES) * 64 * sizeof(uint32_t)));
   TGP_HIP_TRY(hipMalloc(&ctx->d_chain_ticket, 4096));  // (CHAIN_TICKET_WORDS of chol.hip: 544 words)
   TGP_HIP_TRY(hipMemset(ctx->d_chain_ticket, 0, 4096));
+  TGP_HIP_TRY(hipMalloc(&ctx->d_chain_red, size_t(2) * CHAIN_MAX_ROW_TILES * sizeof(double)));
   hipDeviceProp_t prop;
   TGP_HIP_TRY(hipGetDeviceProperties(&prop, device));
   ctx->cus = prop.multiProcessorCount;
@@ -264,6 +265,7 @@ int tgp_ctx_destroy(tgp_ctx* ctx) {
   if (ctx->d_step_flag) hipFree(ctx->d_step_flag);
   if (ctx->d_chain_flags) hipFree(ctx->d_chain_flags);
   if (ctx->d_chain_ticket) hipFree(ctx->d_chain_ticket);
+  if (ctx->d_chain_red) hipFree(ctx->d_chain_red);
   if (ctx->d_chain_stamps) hipFree(ctx->d_chain_stamps);
   for (auto& kv : ctx->chain_tables)
     if (kv.second.dev) hipFree(kv.second.dev);
@@ -322,6 +324,7 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "gemm_role")) return &ctx->gemm_role;
   if (!strcmp(key, "host_join")) return &ctx->host_join;
   if (!strcmp(key, "late_join")) return &ctx->late_join;
+  if (!strcmp(key, "chain_reduce")) return &ctx->chain_reduce;
   if (!strcmp(key, "asm_defer")) return &ctx->asm_defer;
   if (!strcmp(key, "tile_band")) return &ctx->tile_band;
   if (!strcmp(key, "fault_inject")) return &ctx->fault_inject;
@@ -736,13 +739,20 @@ static int factor_body(tgp_solver* s, const tgp_kop* prog, int nops, const void*
     int32_t inf = 0;
     ctx->defer_join = ctx->late_join != 0;  // (one host round trip per evaluation: `info` comes back with the scalars below)
     ctx->join_deferred = false;
+    // (the chain's fsolve tasks leave both sums when the forward substitution rides in the chain launches: chol.hip)
+    ctx->chain_red_total = fused && ctx->chain_reduce != 0 ? s->npad / 128 : 0;
+    ctx->reductions_done = false;
     int st = potrf<T>(ctx, s->npad, A, s->npad, (T*)s->dinv, &inf, fused ? (T*)s->vec : (T*)nullptr);
     ctx->defer_join = false;
+    ctx->chain_red_total = 0;
     if (st < 0) return st;
     s->info = inf;
     if (prof) TGP_HIP_TRY(hipEventRecord(e2, ctx->stream));
-    TGP_TRY(launch_sum_log_diag<T>(ctx, s->n, A, s->npad, 1));
-    if (fused) TGP_TRY(launch_sum_squares<T>(ctx, s->n, (const T*)s->vec, 0));
+    if (!ctx->reductions_done) {
+      TGP_TRY(launch_sum_log_diag<T>(ctx, s->n, A, s->npad, 1));
+      if (fused) TGP_TRY(launch_sum_squares<T>(ctx, s->n, (const T*)s->vec, 0));
+    }
+    ctx->reductions_done = false;
     return TGP_OK;
   });
   if (status < 0) return status;

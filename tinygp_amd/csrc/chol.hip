@@ -475,6 +475,12 @@ struct ChainArgs {
   T* y;                   // forward substitution as tasks: the right-hand side's rows from the panel's first row on (or NULL)
   int32_t fgs;            // row tiles per fupdate task
   int32_t fprev;          // rows / columns in FRONT of the panel exist: fsolve(0) applies tile (0, -1) of the previous panel
+  // the evaluation's two reductions ride along (round 6): fsolve(c) leaves sum_i z_i^2 and sum_i log L_ii of ITS block in
+  // red[2 g] / red[2 g + 1] (g = the block's global index) and the fsolve of the matrix's LAST block adds all of them up in a
+  // fixed order into scal[0] / scal[1] -- no reduction launch behind the factorisation (NULL: off)
+  double* red;
+  double* scal;
+  int32_t red_total;      // > 0: this launch holds the matrix's last block; blocks of the whole matrix
 };
 
 // all threads; wave 0 polls up to three state words (lane l: word f[l] == v[l]; NULL: nothing to wait for),
@@ -1261,6 +1267,61 @@ __device__ __forceinline__ void chain_fsolve(const ChainArgs<T>& q, T* S, int c,
     }
   }
   if (act) st_agent(y + r, t);
+  if (q.red != nullptr) {
+    // sum of z_i^2 and of log L_ii over this block: a fixed tree over 128 values each (the padding rows hold z = 0, L = 1)
+    __syncthreads();
+    double* ra = reinterpret_cast<double*>(S);  // [128] + [128] (S is at least 36 * 256 elements of T)
+    double* rq = ra + 128;
+    if (act) {
+      const double zv = double(t);
+      ra[r] = zv * zv;
+      rq[r] = log(double(Lkk[int64_t(r) * ld + r]));
+    }
+    __syncthreads();
+    for (int sft = 64; sft > 0; sft >>= 1) {
+      if (r < sft) {
+        ra[r] += ra[r + sft];
+        rq[r] += rq[r + sft];
+      }
+      __syncthreads();
+    }
+    const int g = q.pivot_base / TILE + c;
+    if (r == 0) {
+      st_agent(q.red + 2 * g, ra[0]);
+      st_agent(q.red + 2 * g + 1, rq[0]);
+    }
+    if (q.red_total > 0 && g == q.red_total - 1) {
+      // the matrix's last block: every earlier fsolve has published (z_{c-1} was waited for, block by block, launch by launch
+      // in stream order) -- their partial sums are in memory.  Thread r adds the blocks r, r + 512, ... of both, then the tree.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      double* ta = ra + 256;  // [512] + [512]
+      double* tb = ta + 512;
+      double a = 0, b = 0;
+      for (int gg = r; gg < q.red_total; gg += 512) {
+        const unsigned long long ua = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q.red + 2 * gg), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long ub = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q.red + 2 * gg + 1),
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a += __longlong_as_double((long long)ua);
+        b += __longlong_as_double((long long)ub);
+      }
+      ta[r] = a;
+      tb[r] = b;
+      __syncthreads();
+      for (int sft = 256; sft > 0; sft >>= 1) {
+        if (r < sft) {
+          ta[r] += ta[r + sft];
+          tb[r] += tb[r + sft];
+        }
+        __syncthreads();
+      }
+      if (r == 0) {
+        q.scal[0] = ta[0];
+        q.scal[1] = tb[0];
+      }
+    }
+  }
 }
 
 // fupdate(c, g): y_i -= X_ic z_c for the row tiles i > c + 1 of group g (`fgs` tiles; row c + 1 is fsolve(c + 1)'s): wave w
@@ -2372,6 +2433,15 @@ int launch_chain(tgp_ctx* ctx, hipStream_t st, T* A0, int64_t ld, T* dinv0, int6
   q.y = y0;
   q.fgs = CHAIN_FWD_GROUP;
   q.fprev = fprev ? 1 : 0;
+  q.red = nullptr; q.scal = nullptr; q.red_total = 0;
+  if (fwd != 0 && ctx->chain_red_total > 0 && ctx->chain_red_total <= CHAIN_MAX_ROW_TILES && pivot_base % TILE == 0) {
+    q.red = ctx->d_chain_red;
+    q.scal = ctx->d_scal;
+    if (pivot_base / TILE + ce == ctx->chain_red_total) {  // the launch with the matrix's last block adds the partial sums up
+      q.red_total = (int32_t)ctx->chain_red_total;
+      ctx->reductions_done = true;
+    }
+  }
   if (ctx->chain_stamps != 0 && ctx->chain_stamp_base + tasks <= CHAIN_STAMP_TASKS) {
     if (ctx->d_chain_stamps == nullptr)
       TGP_HIP_TRY(hipMalloc((void**)&ctx->d_chain_stamps, size_t(CHAIN_STAMP_TASKS) * 16 * sizeof(long long)));

@@ -127,6 +127,12 @@ struct tgp_ctx {
   int64_t split_tail = 0;  // trailing update: the last, partly filled round of tiles is split along k (gemm.hip)
   int64_t gemm_role = 1;     // role tgp_gemm_nt launches with (measurement hook: 4 = the 64x64-tile kernel at any k)
   int64_t late_join = 1;       // fused evaluation: ONE host join per evaluation, `info` read with the scalars (0: round 5's two)
+  // fused evaluation: sum z^2 and sum log L_ii are left by the chain's fsolve tasks (chol.hip, ChainArgs::red) -- no reduction
+  // launch behind the factorisation (0: the two kernels of util.hip)
+  int64_t chain_reduce = 1;
+  double* d_chain_red = nullptr;   // [2 * CHAIN_MAX_ROW_TILES] per-block partial sums
+  int64_t chain_red_total = 0;     // set by the fused evaluation around its potrf call: blocks of the matrix (0: off)
+  bool reductions_done = false;    // ... and the answer: the launch with the matrix's last block left both sums in d_scal[0..1]
   bool defer_join = false;     // set by the fused evaluation around its potrf call: do not join, `info` is read with the scalars
   bool join_deferred = false;  // ... and potrf's answer: it did leave the join (and the check of d_info) to the caller
   int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
