@@ -134,6 +134,9 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       the host then joins the pass with a deadline); 0: behind the whole launch -- the DEFAULT of a
  *                       context created under a counter-collecting profiler (ROCPROF_COUNTER_COLLECTION, i.e.
  *                       rocprofv3 --pmc, or TGP_SERIALIZED_KERNELS=1), which runs kernels one at a time in its own order;
+ *                       In the merged schedule ("chain_merged") the one poll that is left -- the next panel's chain behind
+ *                       the PREFIX of the trailing update -- is the first thing that panel's potf2 launch does (1; no poll
+ *                       kernel at all), a one-wave kernel of its own with 2, off with 0;
  *                       "chain_fwd_tasks" (1, round 6): the fused forward substitution (gp.py:318-320) as TASKS of the chain
  *                       launch -- no poller and no forward-step launch at all, chain_polls then only concerns the early
  *                       shares of the non-default schedules; 0: round 5's followers on the solve stream;

@@ -27,7 +27,7 @@ int main() {
   long long hs[64];
   for (int rep = 0; rep < 3; ++rep) {
     hipMemcpy(dA, h.data(), n * n * 8, hipMemcpyHostToDevice); hipMemset(info, 0, 4);
-    hipLaunchKernelGGL((tgp::potf2_kernel<double, false>), dim3(1), dim3(512), 0, 0, dA, (int64_t)n, dinv, info, 0, (const double*)nullptr, (int64_t)0);
+    hipLaunchKernelGGL((tgp::potf2_kernel<double, false>), dim3(1), dim3(512), 0, 0, dA, (int64_t)n, dinv, info, 0, (const double*)nullptr, (int64_t)0, (const int32_t*)nullptr, 0);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(hs, HIP_SYMBOL(tgp::g_potf2_stamps), sizeof(hs));
     printf("rep %d total %lld cycles; load %lld; store %lld\n", rep, hs[34] - hs[0], hs[1] - hs[0], hs[34] - hs[33]);

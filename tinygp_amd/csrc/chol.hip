@@ -136,15 +136,28 @@ __device__ long long g_potf2_stamps[64];
 
 // waves_per_eu(4): at most 128 VGPRs, so that two potf2 waves fit on a SIMD beside one wave of the
 // trailing-update GEMM (<= 251 VGPRs) -- otherwise potf2 waits for the whole update to drain.
+// (round 6) `wait_count` != NULL: the launch starts with the stream-side end of a hand-off -- thread 0 polls the counter
+// (the PREFIX of the merged trailing update that is running on the main stream: gemm.hip), one acquire, barrier.  As a
+// kernel of its own in front of this one (chain_poll_kernel, one wave) the poll got its slot at once and potf2 -- 74 KB of
+// LDS -- was dispatched when the prefix was complete, i.e. right after the update's SECOND round of tiles had taken every
+// slot: it waited a whole round, 290 of the 316 us it took beside the updates with 7 168 / 8 192 rows (profiles/r06_i).
+// Dispatched with the poll inside, it takes the first slot the first round frees and is through 27 us after the prefix.
+__device__ void potf2_prefix_wait(const int32_t* count, int32_t target, int32_t* info);
+
 template <typename T, bool FOLD>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void potf2_kernel(T* __restrict__ A, int64_t ld,
                                                     T* __restrict__ dinv,
                                                     int32_t* __restrict__ info,
                                                     int32_t pivot_base,
-                                                    const T* __restrict__ Xp, int64_t ldx) {
+                                                    const T* __restrict__ Xp, int64_t ldx,
+                                                    const int32_t* __restrict__ wait_count, int32_t wait_target) {
   __shared__ __attribute__((aligned(16))) T S[36 * 256];
   __shared__ T Rs[2 * 16];                                 // 1 / L_ii of the current / previous block
   __shared__ T Dg[256];  // copy of the current diagonal 16 x 16 block for the eliminating waves of group >= 1
+  if (wait_count != nullptr) {
+    if (threadIdx.x == 0) potf2_prefix_wait(wait_count, wait_target, info);
+    __syncthreads();
+  }
 #include "potf2_body.inc"
 }
 
@@ -521,6 +534,19 @@ __device__ __forceinline__ void chain_publish(uint32_t* word, uint32_t value, in
     __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (colcnt != nullptr) __hip_atomic_fetch_add(colcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+__device__ void potf2_prefix_wait(const int32_t* count, int32_t target, int32_t* info) {
+  PollClock clk;
+  for (unsigned spin = 0;; ++spin) {
+    if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+    __builtin_amdgcn_s_sleep(8);
+    if ((spin & 255) == 255 && (clk.expired(spin) || poisoned(info))) {
+      atomicExch(info, STEP_TIMEOUT);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // Stream-side end of a hand-off: ONE wave that returns once block column c of the running chain launch is final
@@ -1931,7 +1957,7 @@ __global__ __launch_bounds__(256) void trsv_fwd_stream_kernel(int nblk, const T*
   // vector product and one reduction away from x_b.  Round 5 had one helper and the primary streamed every other tile: what
   // followed the arrival of x_{b-2} -- its tile's product, the helper's hand-off, W_b's product: four L2 round trips and
   // four barriers, 4.3 us -- had to fit into ONE hop, and the period was 2.47 us per block whatever the bandwidth (N = 16 384:
-  // 0.316 ms = 3.4 TB/s; more workgroups per row alone: slower, profiles/r06_h).
+  // 0.316 ms = 3.4 TB/s; more workgroups per row alone: slower, profiles/r06_b).
   const int tk = __builtin_amdgcn_readfirstlane(sb);
   const int b = tk / G;
   const int role = tk - b * G;
@@ -2320,10 +2346,13 @@ int launch_potf2(tgp_ctx* ctx, hipStream_t st, T* A, int64_t ld, T* dinv, int32_
     trace_push(ctx, 1, st, trace_off(ctx, A), trace_off(ctx, Xp), ld);
     return TGP_OK;
   }
+  const int32_t* wc = ctx->potf2_wait_counter;  // (set by the merged schedule in front of a panel's first potf2: potrf)
+  const int32_t wt = (int32_t)ctx->potf2_wait_target;
+  ctx->potf2_wait_counter = nullptr;
   if (Xp != nullptr)
-    hipLaunchKernelGGL((potf2_kernel<T, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info, pivot_base, Xp, ldx);
+    hipLaunchKernelGGL((potf2_kernel<T, true>), dim3(1), dim3(512), 0, st, A, ld, dinv, info, pivot_base, Xp, ldx, wc, wt);
   else
-    hipLaunchKernelGGL((potf2_kernel<T, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info, pivot_base, Xp, ldx);
+    hipLaunchKernelGGL((potf2_kernel<T, false>), dim3(1), dim3(512), 0, st, A, ld, dinv, info, pivot_base, Xp, ldx, wc, wt);
   TGP_HIP_TRY(hipGetLastError());
   return TGP_OK;
 }
@@ -2845,7 +2874,14 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       if (prefix) {
         const int64_t tm = mt / TILE, tp = wn / TILE;
         TGP_TRY(st_wait(ctx, S1, ev_pfx[p & 1]));
-        TGP_TRY(launch_prefix_poll(ctx, S1, counter, tp * tm - tp * (tp - 1) / 2, trace_off(ctx, C), ld));
+        // the poll: the first thing the panel's potf2 launch does (potf2_kernel); a kernel of its own in the traced replay
+        // (tests/test_schedule.py models the poll as record 13) and with chain_polls = 2 (round 6's first form)
+        if (ctx->trace || ctx->chain_polls == 2) {
+          TGP_TRY(launch_prefix_poll(ctx, S1, counter, tp * tm - tp * (tp - 1) / 2, trace_off(ctx, C), ld));
+        } else {
+          ctx->potf2_wait_counter = counter;
+          ctx->potf2_wait_target = tp * tm - tp * (tp - 1) / 2;
+        }
       } else {
         TGP_TRY(st_wait(ctx, S1, ev_T[p & 1]));
       }

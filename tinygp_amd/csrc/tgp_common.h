@@ -138,6 +138,8 @@ struct tgp_ctx {
   int64_t reserve_hint = 0;  // set by potrf in front of such a launch, consumed by launch_gemm_nt
   int64_t prefix_hint_cols = 0;             // ... the same for the merged trailing update's prefix (gemm.hip, GemmArgs)
   int32_t* prefix_hint_counter = nullptr;
+  const int32_t* potf2_wait_counter = nullptr;  // consumed by the next launch_potf2: poll this counter first (chol.hip)
+  int64_t potf2_wait_target = 0;
   uint32_t* d_step_flag = nullptr;  // the flag potf2's workgroup publishes; value = step_epoch of the launch
   uint32_t step_epoch = 0;
   // persistent panel chain (chol.hip, chain_kernel): ONE launch per panel (two with an early share) factors its
@@ -182,6 +184,8 @@ struct tgp_ctx {
   // 1: a one-wave poll kernel on the block column's counter, bounded by wall clock (default); 3: hipStreamWaitValue32 on
   // it (the runtime's own one-wave wait kernel: as fast, no timeout -- measured, not the default); 0: they wait for the
   // whole launch (the default under a counter-collecting profiler, which runs kernels one at a time in its own order)
+  // merged schedule: the poll of the update's prefix counter is the first thing the next panel's potf2 launch does (1),
+  // a one-wave kernel of its own in front of it (2), off (0)
   int64_t chain_polls = 1;
   // Round 6: the fused forward substitution as TASKS of the chain launch (chain_tasks.h F(c), chol.hip chain_fsolve /
   // chain_fupdate): no poller, no forward-step launch at all.  0: round 5's followers on the solve stream (chain_polls)
