@@ -137,6 +137,9 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *                       In the merged schedule ("chain_merged") the one poll that is left -- the next panel's chain behind
  *                       the PREFIX of the trailing update -- is the first thing that panel's potf2 launch does (1; no poll
  *                       kernel at all), a one-wave kernel of its own with 2, off with 0;
+ *                       "chain_sub_panel" (0 = off; measured slower, profiles/r06_i): the chain of a panel runs in sub-panels
+ *                       of this many columns, each applied to the panel's remaining columns by one product of the tiled
+ *                       kernel ("chain_sub_role", 4) on the same stream; "chain_sub_min_rows": only for panels that tall;
  *                       "chain_fwd_tasks" (1, round 6): the fused forward substitution (gp.py:318-320) as TASKS of the chain
  *                       launch -- no poller and no forward-step launch at all, chain_polls then only concerns the early
  *                       shares of the non-default schedules; 0: round 5's followers on the solve stream;

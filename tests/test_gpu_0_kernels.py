@@ -240,7 +240,9 @@ def test_potrf_block_sizes_agree(nb_outer):
                                   dict(chain_batch=8, chain_batch_lag=2, chain_batch_rowlag=3, chain_batch_minrows=0),
                                   dict(chain_gate_split=1), dict(chain_gate_split=1, chain_full_rows=0),
                                   # the merged schedule's prefix poll as a kernel of its own (default: inside the panel's potf2)
-                                  dict(chain_polls=2), dict(chain_polls=2, chain_full_rows=0)])
+                                  dict(chain_polls=2), dict(chain_polls=2, chain_full_rows=0),
+                                  # the chain of a panel sub-panel by sub-panel (measured, not the default: profiles/r06_i)
+                                  dict(chain_sub_panel=512), dict(chain_sub_panel=256, chain_sub_role=0, chain_full_rows=0)])
 def test_panel_chain_variants_agree(n, opts):
     """The schedules of the panel chain -- the default persistent chain (chain_kernel: tile tasks behind a ticket
     counter, the whole rest of the matrix in one launch once few rows are left), one fused launch per 128-column

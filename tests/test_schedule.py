@@ -303,6 +303,11 @@ CONFIGS = [
     (5120, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0, chain_fwd_tasks=0)),
     (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0, chain_fwd_tasks=0)),
     (16384, 1024, 0, 5, 1100, 3, 0, dict(chain_kernel=1, chain_polls=0)),
+    # ... the chain of a panel sub-panel by sub-panel, each finished sub-panel applied to the panel's remaining columns by one
+    # product on the priority stream (merged schedule only: chain_sub_panel)
+    (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_merged=1, chain_sub_panel=512)),
+    (16384, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_merged=1, chain_sub_panel=256, chain_sub_role=0)),
+    (9216, 1024, 1, 5, 1100, 3, 0, dict(chain_kernel=1, chain_merged=1, chain_sub_panel=512, chain_sub_min_rows=6144)),
 ]
 
 

@@ -307,7 +307,7 @@ class Ctx:
         return old.value
 
     # the options that shape the factorisation's schedule (tgp_trace_factor takes the same names)
-    SCHEDULE_OPTIONS = ("nb_outer", "lookahead", "first_split", "first_small_tiles", "nb_wide_rows", "fused_step", "chain_kernel", "chain_fast_update", "chain_batch", "chain_batch_lag", "chain_batch_rowlag", "chain_batch_minrows", "tile_band", "chain_full_rows", "chain_lds_pad", "chain_depth2", "chain_merged", "chain_pre_wait", "chain_polls", "chain_fwd_tasks", "chain_reduce",
+    SCHEDULE_OPTIONS = ("nb_outer", "lookahead", "first_split", "first_small_tiles", "nb_wide_rows", "fused_step", "chain_kernel", "chain_fast_update", "chain_batch", "chain_batch_lag", "chain_batch_rowlag", "chain_batch_minrows", "tile_band", "chain_full_rows", "chain_lds_pad", "chain_depth2", "chain_merged", "chain_sub_panel", "chain_sub_min_rows", "chain_sub_role", "chain_pre_wait", "chain_polls", "chain_fwd_tasks", "chain_reduce",
                         "gate_split", "chain_reserve", "reserve_max_tiles", "sub_panel", "sub_panel_min_rows",
                         "nb_first", "split_tail", "solve_on_update")
 

@@ -304,6 +304,9 @@ static int64_t* option_slot(tgp_ctx* ctx, const char* key) {
   if (!strcmp(key, "chain_lds_pad")) return &ctx->chain_lds_pad;
   if (!strcmp(key, "chain_depth2")) return &ctx->chain_depth2;
   if (!strcmp(key, "chain_merged")) return &ctx->chain_merged;
+  if (!strcmp(key, "chain_sub_panel")) return &ctx->chain_sub_panel;
+  if (!strcmp(key, "chain_sub_min_rows")) return &ctx->chain_sub_min_rows;
+  if (!strcmp(key, "chain_sub_role")) return &ctx->chain_sub_role;
   if (!strcmp(key, "chain_pre_wait")) return &ctx->chain_pre_wait;
   if (!strcmp(key, "chain_gate_split")) return &ctx->chain_gate_split;
   if (!strcmp(key, "chain_polls")) return &ctx->chain_polls;

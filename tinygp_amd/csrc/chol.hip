@@ -2822,6 +2822,26 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     if (ctx->chain_kernel != 0 && rem <= ctx->chain_full_rows && rem / TILE <= 64) w = rem;
     return rem < w ? rem : w;
   };
+  // TWO-LEVEL PANEL for the persistent chain (round 6, merged schedule; ctx option chain_sub_panel): the chain of a panel runs
+  // sub-panel by sub-panel -- its in-panel rank-128 update tasks stay inside `chain_sub_panel` columns -- and every finished
+  // sub-panel updates the panel's remaining columns with ONE K = chain_sub_panel product on the tiled MFMA kernel (the same
+  // stream: chain | product | potf2 | chain ...).  With 4-column sub-panels 16 of a row tile's 28 update tasks per panel
+  // (MFMA duty 0.41 inside the chain, one read-modify-write of the tile per K = 128) become 4 tiles of that product.  The
+  // panel's first diagonal block is factored by the caller.
+  auto chain_of_panel = [&](hipStream_t st, int64_t k0, int64_t w) -> int {
+    const int64_t sp = ctx->chain_sub_panel / TILE * TILE;
+    if (sp >= TILE && sp < w && w % sp == 0 && n - k0 > w && n - k0 >= ctx->chain_sub_min_rows) {
+      for (int64_t o = 0; o < w; o += sp) {
+        if (o > 0) TGP_TRY(potf2_at(st, k0 + o, false));
+        TGP_TRY(panel(st, k0 + o, sp, true, 0, no_mid));
+        const int64_t c0 = k0 + o + sp;
+        if (c0 < k0 + w)
+          TGP_TRY(trailing(st, n - c0, k0 + w - c0, sp, A + (k0 + o) * ld + c0, A + c0 * ld + c0, (int)ctx->chain_sub_role));
+      }
+      return TGP_OK;
+    }
+    return panel(st, k0, w, true, 0, no_mid);
+  };
   const bool la = ctx->lookahead != 0 && S1 != nullptr;
   if (la && ctx->chain_kernel != 0 && ctx->chain_merged != 0) {
     // MERGED TRAILING UPDATE (round 6).  Panel p updates EVERYTHING to its right in ONE launch of the 128 x 128-tile kernel,
@@ -2887,7 +2907,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
       }
       if (p == 0 && asm_side) TGP_TRY(st_wait(ctx, S1, ctx->ev_asm));
       TGP_TRY(potf2_at(S1, next, false));
-      TGP_TRY(panel(S1, next, wn, true, 0, no_mid));
+      TGP_TRY(chain_of_panel(S1, next, wn));
       TGP_TRY(ev_record(ctx, ev_chain[(p + 1) & 1], S1));
     }
     TGP_TRY(st_wait(ctx, S0, ev_chain[(P - 1) & 1]));

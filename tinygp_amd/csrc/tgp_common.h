@@ -176,6 +176,11 @@ struct tgp_ctx {
   // round 6: ONE trailing-update launch per panel on the 128 x 128-tile kernel, the next panel's block column first
   // (write-through, counted), the next chain behind a one-wave poll of that count (chol.hip, potrf)
   int64_t chain_merged = 1;
+  // two-level panel for the chain in the merged schedule (chol.hip, chain_of_panel): sub-panel width in columns (0: off), only
+  // for panels with at least chain_sub_min_rows rows, the sub-panel's product on role chain_sub_role (4: 64 x 64 tiles)
+  int64_t chain_sub_panel = 0;
+  int64_t chain_sub_min_rows = 0;
+  int64_t chain_sub_role = 4;
   // depth-2 schedule, chain-bound panels (the big update has at most reserve_max_tiles tiles): pre(p) starts behind
   // the next panel's first potf2 -- issued at once it fills every compute unit with three 48-KB workgroups, and the
   // one-workgroup potf2 (74 KB) on the chain pipeline waited 120-290 us for room (profiles/r04_c)
