@@ -58,7 +58,7 @@ pmc)
     timeout 200 rocprofv3 --pmc $cn --kernel-trace -d $O/pmc_$cn -o bench -- python bench.py --steps 2 --warmup 1 $B --no-profile > $O/pmc_$cn.log 2>&1
     echo "-- c2 $cn rc=$?"; python scripts/pmc_summary.py $(ls $O/pmc_$cn/*.db | head -1) $cn | head -5
   done
-  python scripts/pmc_to_bench.py $(ls $O/pmc_FETCH_SIZE/*.db | head -1) $(ls $O/pmc_WRITE_SIZE/*.db | head -1) profiles/${TAG}_evidence.md | cut -c1-400
+  python scripts/pmc_to_bench.py $(ls $O/pmc_FETCH_SIZE/*.db | head -1) $(ls $O/pmc_WRITE_SIZE/*.db | head -1) profiles/${TAG}_final_evidence.md | cut -c1-400
   cp gpurun_out/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
   rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE ;;
 whole)
