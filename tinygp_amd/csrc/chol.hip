@@ -2847,8 +2847,8 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
     // MERGED TRAILING UPDATE (round 6).  Panel p updates EVERYTHING to its right in ONE launch of the 128 x 128-tile kernel,
     //   T(p):  A[next.., next..] -= P_p P_p^T   (lower, K = the panel's width),
     // whose tile ids start with the block column of panel p+1 (the PREFIX: stored write-through and counted, gemm.hip); the
-    // priority stream's chain of panel p+1 follows a one-wave poll of that count -- it runs beside the rest of T(p), and
-    // T(p+1) waits for it.  The depth-2 schedule below cuts the same work into gate(p) | pre(p) | rest(p): two of the three on
+    // priority stream's [potf2 | chain] of panel p+1 follows a poll of that count -- the first thing that potf2 launch does
+    // (potf2_kernel) --, runs beside the rest of T(p), and T(p+1) waits for it.  The depth-2 schedule below cuts the same work into gate(p) | pre(p) | rest(p): two of the three on
     // the 64 x 64-tile kernel (a third of the flops at a lower MFMA duty), 26 launch ramps on the main stream instead of 13,
     // the next gate queued behind a whole rest(p-1).  The last panel (the one-launch tail) needs the whole update: no prefix.
     std::vector<int64_t> s0;
