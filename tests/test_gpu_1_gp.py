@@ -611,6 +611,32 @@ def test_reductions_left_by_the_chain_match_the_reduction_kernels(n):
     np.testing.assert_allclose(got[1][0], want, rtol=LL_RTOL)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [100, 128, 129, 1000, 4096, 9000])
+def test_resident_residual_is_solved_in_place_with_the_same_bits(n, dtype):
+    """`tgp_solver_logprob` with the RESIDENT residual (NULL host pointer; what bench.py's secondary roofline times) lets the
+    streaming solve read it where it is -- no copy into the work vector, none inside the solve's preparation -- and gives the
+    bits of the same call with the residual uploaded from the host (reference gp.py:313-320 on a kept factor)."""
+    import ctypes as C
+
+    from tinygp_amd import _ffi
+
+    X, y = _cases.synthetic.make_inputs(n, 1)
+    X, y = X.astype(dtype), y.astype(dtype)
+    k = 1.5**2 * kernels.ExpSquared(2.5)
+    solver = DirectSolver(k, X, noise.Diagonal(np.full(n, 0.01, dtype=dtype)))
+    solver.set_residual(y)
+    fused = float(solver.factor_log_probability(None, k))
+    out, out2 = C.c_double(), C.c_double()
+    for _ in range(3):
+        _ffi.check(_ffi.lib().tgp_solver_logprob(solver._handle, None, C.byref(out)), "tgp_solver_logprob")
+        _ffi.check(_ffi.lib().tgp_solver_logprob(solver._handle, _ffi.ptr(np.ascontiguousarray(y)), C.byref(out2)), "tgp_solver_logprob")
+        assert out.value == out2.value
+    np.testing.assert_allclose(out.value, fused, rtol=1e-12 if dtype is np.float64 else 5e-5)
+    # ... and the resident residual itself is untouched: the next fused evaluation gives the same value
+    assert float(solver.factor_log_probability(None, k)) == fused
+
+
 def _deterministic_evaluations(n, reps):
     X, y = _cases.synthetic.make_inputs(n, 1)
     ks = [1.5**2 * kernels.ExpSquared(2.5), 1.4**2 * kernels.ExpSquared(2.2)]

@@ -926,12 +926,15 @@ int tgp_solver_set_resid(tgp_solver* s, const void* resid_host) {
 static int logprob_device(tgp_solver* s, const void* resid_host, double* out) {
   tgp_ctx* ctx = s->ctx;
   const size_t es = esize(s->dtype);
+  // the resident residual is read in place by the streaming solve (no copy into the work vector); the launch-per-block
+  // path (stream_trsv = 0, or a factor with a failed pivot) solves in place and needs the copy
+  const bool in_place_rhs = !resid_host && ctx->stream_trsv != 0 && s->info == 0;
   if (resid_host) {
     TGP_TRY(upload_vec(s, s->vec, resid_host));
   } else {
     TGP_ARG_CHECK(s->has_resid, "no resident residual: call tgp_solver_set_resid first");
-    TGP_HIP_TRY(hipMemcpyAsync(s->vec, s->resid, size_t(s->npad) * es, hipMemcpyDeviceToDevice,
-                               ctx->stream));
+    if (!in_place_rhs)
+      TGP_HIP_TRY(hipMemcpyAsync(s->vec, s->resid, size_t(s->npad) * es, hipMemcpyDeviceToDevice, ctx->stream));
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool prof = ctx->profile != 0;
@@ -947,7 +950,8 @@ static int logprob_device(tgp_solver* s, const void* resid_host, double* out) {
       TGP_TRY(ensure_winv<T>(s));
       winv = (const T*)s->winv;
     }
-    TGP_TRY(trsv<T>(ctx, s->npad, (const T*)s->A, s->npad, (const T*)s->dinv, 0, (T*)s->vec, winv));
+    TGP_TRY(trsv<T>(ctx, s->npad, (const T*)s->A, s->npad, (const T*)s->dinv, 0, (T*)s->vec, winv,
+                    in_place_rhs ? (const T*)s->resid : (const T*)nullptr));
     return launch_sum_squares<T>(ctx, s->n, (const T*)s->vec, 0);
   }));
   if (prof) TGP_HIP_TRY(hipEventRecord(e1, ctx->stream));

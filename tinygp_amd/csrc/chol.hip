@@ -1856,7 +1856,7 @@ __global__ __launch_bounds__(256) void trsv_prep_kernel(int64_t n, T* __restrict
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (i == 0) *ticket = 0;
   if (i < n) {
-    tmp[i] = y[i];
+    if (tmp != nullptr) tmp[i] = y[i];  // (NULL: the right-hand side is a buffer of its own, the solve reads it in place)
     y[i] = bits_to<T>(Sent<T>::value);
     for (int h = 0; h < nparts; ++h) part[int64_t(h) * n + i] = bits_to<T>(Sent<T>::value);  // the helpers' partial sums
   }
@@ -3185,8 +3185,9 @@ int compute_winv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* winv) {
 
 template <typename T>
 int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int transpose, T* y,
-         const T* winv) {
+         const T* winv, const T* yin) {
   TGP_ARG_CHECK(n % TILE == 0, "trsv: n must be a multiple of %d", TILE);
+  TGP_ARG_CHECK(yin == nullptr || (winv != nullptr && yin != y), "trsv: a separate right-hand side needs the streaming solve");
   hipStream_t st = ctx->stream;
   const int64_t nb = n / TILE;
   if (winv != nullptr && n > 0) {  // one streaming launch (trsv_fwd_stream_kernel / trsv_bwd_stream_kernel)
@@ -3198,14 +3199,17 @@ int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int tra
     T* tmp = static_cast<T*>(ctx->d_work);
     int32_t* ticket = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->d_work) + size_t(n) * sizeof(T) + 64);
     T* part = static_cast<T*>(ctx->d_work) + n + 64;  // the helpers' partial sums, (G - 1) x n entries
-    hipLaunchKernelGGL((trsv_prep_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, y, tmp, ticket,
-                       part, G - 1);
+    // yin != NULL: the right-hand side stays where it is (the resident residual of log_probability: no copy into the work
+    // vector in front of the solve, no copy inside the prep kernel: 0.294 -> 0.286 ms at N = 16 384, profiles/r06_f section 8)
+    const T* rhs = yin != nullptr ? yin : (const T*)tmp;
+    hipLaunchKernelGGL((trsv_prep_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, y,
+                       yin != nullptr ? (T*)nullptr : tmp, ticket, part, G - 1);
     if (!transpose)
       hipLaunchKernelGGL((trsv_fwd_stream_kernel<T>), dim3((unsigned)(G * nb)), dim3(256), 0, st, (int)nb, L, ld, winv,
-                         winv + 2 * nb * 16384, winv + 3 * nb * 16384, (const T*)tmp, y, ticket, part, G);
+                         winv + 2 * nb * 16384, winv + 3 * nb * 16384, rhs, y, ticket, part, G);
     else
       hipLaunchKernelGGL((trsv_bwd_stream_kernel<T>), dim3((unsigned)(2 * nb)), dim3(512), 0, st, (int)nb, L, ld,
-                         winv + nb * 16384, (const T*)tmp, y, ticket, part);
+                         winv + nb * 16384, rhs, y, ticket, part);
     TGP_HIP_TRY(hipGetLastError());
     return TGP_OK;
   }
@@ -3439,7 +3443,7 @@ int spd_inverse_lower(tgp_ctx* ctx, int64_t n, const T* L, int64_t ldl, const T*
   template int panel_chain<T>(tgp_ctx*, hipStream_t, int64_t, T*, int64_t, T*, int64_t, int64_t, \
                               int64_t, bool, T*, int64_t, const std::function<int(hipEvent_t)>&, int64_t, int64_t); \
   template int potrf<T>(tgp_ctx*, int64_t, T*, int64_t, T*, int32_t*, T*);                           \
-  template int trsv<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, int, T*, const T*);       \
+  template int trsv<T>(tgp_ctx*, int64_t, const T*, int64_t, const T*, int, T*, const T*, const T*); \
   template int compute_winv<T>(tgp_ctx*, int64_t, const T*, int64_t, T*);                        \
   template int gemv_sub<T>(tgp_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*);                          \
   template int trsm_right_lt<T>(tgp_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*,     \

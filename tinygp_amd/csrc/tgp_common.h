@@ -399,7 +399,7 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
 // single-launch streaming solve; otherwise one pair of launches per 128-block
 template <typename T>
 int trsv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, const T* dinv, int transpose, T* y,
-         const T* winv = nullptr);
+         const T* winv = nullptr, const T* yin = nullptr);  // yin: right-hand side in a buffer of its own (streaming solve only)
 template <typename T>
 int compute_winv(tgp_ctx* ctx, int64_t n, const T* L, int64_t ld, T* winv);
 template <typename T>
