@@ -163,7 +163,7 @@ int tgp_ctx_sync(tgp_ctx* ctx);
  *   "kmat_plain_div"    1: the straight-line assembly kernel takes r / l, r^2 / l^2 by the division sequence instead
  *                       of the bit-identical reciprocal + FMA form (kmat.hip, UDiv) -- the tests' switch
  *   "chain_reserve"     workgroup slots (of two per CU) that a trailing update running beside a panel
- *                       chain leaves to the chain's kernels (default 128; 0: the update fills the chip)
+ *                       chain leaves to the chain's kernels (default 96; 0: the update fills the chip)
  *   "reserve_max_tiles" ... when the update has at most this many 128x128 tiles (default 1200)
  *   "sub_panel"         two-level panel: the in-panel rank-128 updates stay inside sub-panels of this many
  *                       columns (a divisor of nb_outer, >= 256) and each finished sub-panel updates the

@@ -113,7 +113,9 @@ struct tgp_ctx {
   int64_t fused_step = 0;  // measured (profiles/r02_r): parity-green but 0-8 % slower than the separate launches
   // workgroup slots (of 2 per CU) that a trailing update which runs beside a panel chain leaves free
   // for the chain's kernels (gemm.hip: the update is persistent over its tiles, so its grid is its footprint)
-  int64_t chain_reserve = 128;
+  // (96 since round 6's last batches: 128 -> 96 is -0.04 ... -0.13 ms at c2 on three boxes and lifts the updates with 6 144 /
+  // 5 120 / 4 096 rows from 44-45 to 45-52 TFLOP/s; 64 and 80 are flat: profiles/r06_i section 6)
+  int64_t chain_reserve = 96;
   int64_t reserve_max_tiles = 1200;  // ... when the update has at most this many 128 x 128 tiles (chain-bound panels)
   // the block-column update between two chains (the `gate`) is issued column block 0 | 1 | 2..: the chain starts
   // behind the first piece and meets the others at its second and third block (fused panel step only)
