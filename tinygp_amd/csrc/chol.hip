@@ -2745,6 +2745,11 @@ int potrf(tgp_ctx* ctx, int64_t n, T* A, int64_t ld, T* dinv, int32_t* info_host
   TGP_ARG_CHECK(n % TILE == 0 && ld >= n, "potrf: n must be a multiple of %d and ld >= n", TILE);
   if (info_host) *info_host = 0;
   if (n == 0) return TGP_OK;
+  // (hints a previous call may have left behind an error return: each is consumed by the launch it was set for)
+  ctx->potf2_wait_counter = nullptr;
+  ctx->prefix_hint_cols = 0;
+  ctx->prefix_hint_counter = nullptr;
+  ctx->reserve_hint = 0;
   hipStream_t S0 = ctx->stream, S1 = ctx->panel_stream;
   if (ctx->solve_on_update == 0 && y != nullptr) TGP_TRY(ensure_solve_stream(ctx));
   hipStream_t S2 = ctx->solve_on_update != 0 ? ctx->update_stream : ctx->solve_stream;
